@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py -- Msamples/s of the IQ hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the north-star chain (u8 -> c64 -> Shift(-fs/8) -> 1024-tap
+FIR -> decimate-by-8, one fused kernel) over one 2^24-sample synthetic buffer
+already resident in HBM.  With N > 1 every rank runs its own independent stream
+("single-stream chains stay on one GPU": replicas, weak scaling, no data-path
+collective) and the line also carries the 4-channel Beamform measurement sharded
+over the ranks with its RCCL exchange (the other half of the metric).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel against HBM
+peak with its algorithmic bytes (3 B per input sample) and the
+HIP-event duration measured inside the timed region; `cpu_baseline` times the
+oracle (a scalar port of the reference algorithms) on a bounded sample.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_PEAK_TFLOPS = 157.3    # vector f32
+
+
+def splitmix64(seed, n):
+    idx = np.arange(1, n + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def synth_u8(seed, n):
+    return (splitmix64(seed, 2 * n) >> np.uint64(56)).astype(np.uint8).reshape(n, 2)
+
+
+def synth_i16(seed, n):
+    # Gaussian sigma 4096, clipped (SURVEY 8d cfg 4) from two uniform words (Box-Muller)
+    u = (splitmix64(seed, 4 * n) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    g = np.sqrt(-2.0 * np.log(u[0::2] + 1e-300)) * np.cos(2 * np.pi * u[1::2])
+    return np.clip(np.rint(g * 4096), -32768, 32767).astype(np.int16).reshape(n, 2)
+
+
+def synth_c64(seed, n):
+    u = (splitmix64(seed, 2 * n) >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+    return (u * 2.0 - 1.0).astype(np.float32).view(np.complex64).reshape(n)
+
+
+def lowpass_taps(ntaps, cutoff_frac):
+    """windowed-sinc low-pass, cutoff = cutoff_frac * fs, Hamming (SURVEY 8d cfg 3)."""
+    k = np.arange(ntaps) - (ntaps - 1) / 2
+    h = 2 * cutoff_frac * np.sinc(2 * cutoff_frac * k) * np.hamming(ntaps)
+    return h.astype(np.complex64)
+
+
+def timed(torch, fn, steps, warmup):
+    """-> (wall seconds for `steps` calls, list of per-call HIP-event ms)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return wall, [a.elapsed_time(b) for a, b in evs]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--log2n", type=int, default=24, help="samples per buffer = 2^log2n")
+    ap.add_argument("--no-extra", action="store_true", help="skip the per-config side measurements")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    hz = importlib.import_module("go-sdr_amd")
+    ctx = hz.Context(local_rank, hz.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+
+    n = 1 << args.log2n
+    fs, D, ntaps = 20_000_000, 8, 1024
+    shift = -fs / 8
+    taps = lowpass_taps(ntaps, 1.0 / 16)
+
+    # ---- the headline step: fused north-star chain ---------------------------------
+    x = torch.from_numpy(synth_u8(9 + rank, n)).cuda()
+    y = torch.zeros(n // D, dtype=torch.complex64, device="cuda")
+    chain = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D)
+
+    def step():
+        chain.run(x, y)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    value = world * n * args.steps / elapsed / 1e6  # Msamples/s, whole job
+    alg_bytes = (2 + 8 / D) * n                     # 2 B read + 8/D B written per input sample
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    nfft, valid = 4096, 3072
+    flops = (5 * nfft * 12 * 2 + 6 * nfft) / valid * n  # fwd + bwd FFT + bin multiply per input sample
+    result = {
+        "metric": "Msamples/s: u8->c64->Shift->FIR-decimate chain @1 GPU; 4-ch Beamform @1/2/4 GPU",
+        "value": round(value, 1),
+        "unit": "Msamples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8->c64(f32), NCO phase f64",
+        "data": "synthetic (splitmix64 u8 IQ, seed 9+rank); windowed-sinc taps",
+        "config": {
+            "workload": "north-star chain: u8->c64->Shift(-fs/8)->1024-tap FIR->decimate-by-8, "
+                        "fused in one kernel (overlap-save N_fft=4096), input resident in HBM",
+            "samples_per_buffer": n, "sample_rate": fs, "taps": ntaps, "decimation": D,
+            "parallelism": "1 stream per GPU (replicas)" if world > 1 else "1 GPU",
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "hz::fir_decimate_kernel<4096, u8>", "kernel_ms": round(kernel_ms, 4),
+            "algorithmic_bytes_per_launch": int(alg_bytes),
+            "note": "3 B/sample puts this chain above the ridge: f32 vector work binds, not HBM",
+            "fp32_vector_frac": round(flops / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+        },
+    }
+    chain.close()
+
+    # ---- side measurements: the other BASELINE configs (rank 0, N = 1 semantics) ----
+    if rank == 0 and not args.no_extra:
+        extra = {}
+        k, w = max(5, args.steps // 5), 2
+
+        def rate(nsamp, ms, bytes_per_sample):
+            return {"Msamples_per_s": round(nsamp / (ms * 1e-3) / 1e6, 1), "kernel_ms": round(ms, 4),
+                    "GBps": round(bytes_per_sample * nsamp / (ms * 1e-3) / 1e9, 1),
+                    "hbm_frac": round(bytes_per_sample * nsamp / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+        c = torch.from_numpy(synth_c64(2, n)).cuda()
+        out = torch.zeros(n, dtype=torch.complex64, device="cuda")
+        # cfg 1 kernel: u8 -> c64 (10 B/sample)
+        _, ms = timed(torch, lambda: ctx.convert(out, x), k, w)
+        extra["convert_u8_c64"] = rate(n, float(np.mean(ms)), 10)
+        # cfg 2: Shift + Gain fused (16 B/sample)
+        ch = ctx.chain(hz.FMT_C64, fs).shift(2.5e6).gain(0.5)
+        _, ms = timed(torch, lambda: ch.run(c, out), k, w)
+        extra["shift_gain_c64"] = rate(n, float(np.mean(ms)), 16)
+        ch.close()
+        # cfg 3: reference ConvolutionReader semantics, 1024 bins (16 B/sample)
+        H = torch.from_numpy(np.fft.fft(np.asarray(taps, np.complex128) / ntaps).astype(np.complex64)).cuda()
+        _, ms = timed(torch, lambda: ctx.convolution_blocks(out, c, H), k, w)
+        extra["convolution_1024_circular"] = rate(n, float(np.mean(ms)), 16)
+        # cfg 4: Downsample by 8 from i16 (5 B/input sample)
+        xi = torch.from_numpy(synth_i16(4, n)).cuda()
+        o8 = torch.zeros(n // 8, dtype=torch.complex64, device="cuda")
+        _, ms = timed(torch, lambda: ctx.downsample(o8, xi, 8), k, w)
+        extra["downsample8_i16"] = rate(n, float(np.mean(ms)), 5)
+        del xi, o8
+        # cfg 5 on one GPU: 4-channel c64 beamform (40 B/output sample)
+        chans = [torch.from_numpy(synth_c64(5 + i, n)).cuda() for i in range(4)]
+        wts = hz.beamform_angles(433e6, 30.0, [0.0, 0.1, 0.2, 0.3])
+        _, ms = timed(torch, lambda: ctx.beamform(out, chans, wts), k, w)
+        extra["beamform4_c64_1gpu"] = rate(n, float(np.mean(ms)), 40)
+        del chans, c, out
+        result["extra"] = extra
+
+    # ---- Beamform sharded over the ranks (one exchange step: RCCL reduce) ------------
+    if world > 1:
+        from importlib import import_module
+        mg = import_module("go-sdr_amd.multigpu")
+        result["beamform"] = mg.bench_beamform(hz, ctx, torch, dist, rank, world, n,
+                                               steps=max(5, args.steps // 5), warmup=2,
+                                               synth=synth_c64)
+
+    # ---- CPU baseline: the oracle (scalar port), bounded sample, rank 0 only ----------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as orc
+        ns = 1 << 21  # sample: 2^21 of the 2^24 input samples
+        xs = synth_u8(9, ns)
+        buf = np.zeros(ns, np.complex64)
+        outc = np.zeros(ns // D, np.complex64)
+        t0 = time.perf_counter()
+        orc.convert(buf, xs)
+        orc.Shifter(fs)(shift, buf)
+        orc.fir_decimate_f64(outc, buf, taps, D)
+        dt = time.perf_counter() - t0
+        result["cpu_baseline"] = {
+            "value": round(ns / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"first 2^21 samples of the same chain (convert, Shift with math.Sincos restated, "
+                      f"1024-tap direct-form FIR at the decimated rate, float64 accumulate), {dt:.1f} s",
+        }
+
+    if rank == 0:
+        print(json.dumps(result))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+"""ctypes declarations for libhzsdr_hip.so (include/hzsdr.h).
+
+The product path is the HIP library: if it is missing this module raises at
+import time -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhzsdr_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libhzsdr_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C go-sdr_amd/csrc` (needs hipcc); there is no CPU fallback")
+
+lib = C.CDLL(LIB_PATH)
+
+FMT_C64, FMT_U8, FMT_I16, FMT_I8 = 1, 2, 3, 4
+MEM_HOST, MEM_DEVICE = 0, 1
+FFT_BACKWARD, FFT_FORWARD = 0, 1
+CONV_CONVOLVE, CONV_CROSS_CORRELATE = 0, 1
+
+(OK, ERR_FORMAT_MISMATCH, ERR_FORMAT_UNKNOWN, ERR_DST_TOO_SMALL, ERR_CONVERSION_NOT_IMPLEMENTED,
+ ERR_LENGTH_MISMATCH, ERR_INVALID_ARGUMENT, ERR_NO_DEVICE, ERR_HIP, ERR_OUT_OF_MEMORY) = range(10)
+
+
+class NcoSegment(C.Structure):
+    _fields_ = [("first", C.c_uint64), ("count", C.c_uint64), ("t0", C.c_double),
+                ("step", C.c_double)]
+
+
+vp, sz, i32, u32, i64, u64, f32, f64 = (C.c_void_p, C.c_size_t, C.c_int, C.c_uint, C.c_int64,
+                                        C.c_uint64, C.c_float, C.c_double)
+psz = C.POINTER(C.c_size_t)
+pvp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes); every symbol include/hzsdr.h declares
+SIGNATURES = {
+    "hzsdr_backend": (C.c_char_p, []),
+    "hzsdr_version": (C.c_char_p, []),
+    "hzsdr_strerror": (C.c_char_p, [i32]),
+    "hzsdr_format_size": (i32, [i32]),
+    "hzsdr_device_count": (i32, [C.POINTER(i32)]),
+    "hzsdr_open": (i32, [i32, i32, pvp]),
+    "hzsdr_close": (i32, [vp]),
+    "hzsdr_last_error": (C.c_char_p, [vp]),
+    "hzsdr_memspace": (i32, [vp]),
+    "hzsdr_set_stream": (i32, [vp, vp]),
+    "hzsdr_get_stream": (vp, [vp]),
+    "hzsdr_synchronize": (i32, [vp]),
+    "hzsdr_malloc_device": (i32, [vp, sz, pvp]),
+    "hzsdr_free_device": (i32, [vp, vp]),
+    "hzsdr_malloc_pinned": (i32, [vp, sz, pvp]),
+    "hzsdr_free_pinned": (i32, [vp, vp]),
+    "hzsdr_memcpy_h2d": (i32, [vp, vp, vp, sz]),
+    "hzsdr_memcpy_d2h": (i32, [vp, vp, vp, sz]),
+    "hzsdr_convert": (i32, [vp, i32, vp, sz, i32, vp, sz, psz]),
+    "hzsdr_i16_shift_lsb_to_msb": (i32, [vp, vp, sz, i32]),
+    "hzsdr_lut_create": (i32, [vp, i32, i32, vp, sz, pvp]),
+    "hzsdr_lut_lookup": (i32, [vp, i32, vp, sz, i32, vp, sz, psz]),
+    "hzsdr_lut_free": (i32, [vp]),
+    "hzsdr_lut_identity": (i32, [vp]),
+    "hzsdr_scale": (i32, [vp, vp, sz, f32]),
+    "hzsdr_rotate": (i32, [vp, vp, sz, f32, f32]),
+    "hzsdr_add": (i32, [vp, vp, sz, vp, sz, vp, sz]),
+    "hzsdr_sum": (i32, [vp, i32, vp, pvp, i32, sz]),
+    "hzsdr_rotlut_create": (i32, [vp, i32, f32, f32, pvp]),
+    "hzsdr_rotlut_set_multiplier": (i32, [vp, f32, f32]),
+    "hzsdr_rotlut_apply": (i32, [vp, vp, sz]),
+    "hzsdr_rotlut_free": (i32, [vp]),
+    "hzsdr_nco_create": (i32, [vp, u64, pvp]),
+    "hzsdr_nco_shift": (i32, [vp, f64, vp, sz]),
+    "hzsdr_nco_get_time": (i32, [vp, C.POINTER(f64)]),
+    "hzsdr_nco_set_time": (i32, [vp, f64]),
+    "hzsdr_nco_free": (i32, [vp]),
+    "hzsdr_nco_segments": (i32, [u64, f64, u64, C.POINTER(NcoSegment), sz, psz, C.POINTER(f64)]),
+    "hzsdr_decimate": (i32, [vp, i32, vp, sz, i32, vp, sz, u32, i64, psz]),
+    "hzsdr_downsample": (i32, [vp, i32, vp, sz, i32, vp, sz, u32, i64, psz]),
+    "hzsdr_fft_plan": (i32, [vp, vp, sz, vp, sz, i32, pvp]),
+    "hzsdr_fft_plan_batch": (i32, [vp, vp, vp, sz, sz, i32, pvp]),
+    "hzsdr_fft_transform": (i32, [vp]),
+    "hzsdr_fft_free": (i32, [vp]),
+    "hzsdr_convolve_create": (i32, [vp, vp, sz, vp, sz, vp, sz, i32, pvp]),
+    "hzsdr_convolve_freq_create": (i32, [vp, vp, sz, vp, sz, vp, sz, pvp]),
+    "hzsdr_conv_exec": (i32, [vp]),
+    "hzsdr_conv_free": (i32, [vp]),
+    "hzsdr_convolution_blocks": (i32, [vp, vp, sz, vp, sz, vp, sz, psz]),
+    "hzsdr_beamform_angles_2d": (i32, [f64, f64, C.POINTER(f64), C.POINTER(f64), i32,
+                                       C.POINTER(f32)]),
+    "hzsdr_beamform_angles": (i32, [f64, f64, C.POINTER(f64), i32, C.POINTER(f32)]),
+    "hzsdr_beamform": (i32, [vp, vp, i32, pvp, C.POINTER(f32), i32, sz]),
+    "hzsdr_beamform_partial": (i32, [vp, vp, i32, pvp, C.POINTER(f32), i32, sz, i32]),
+    "hzsdr_chain_create": (i32, [vp, i32, u64, pvp]),
+    "hzsdr_chain_shift": (i32, [vp, f64]),
+    "hzsdr_chain_gain": (i32, [vp, f32]),
+    "hzsdr_chain_rotate": (i32, [vp, f32, f32]),
+    "hzsdr_chain_decimate": (i32, [vp, u32]),
+    "hzsdr_chain_downsample": (i32, [vp, u32]),
+    "hzsdr_chain_convolution": (i32, [vp, vp, sz, u32]),
+    "hzsdr_chain_fir_decimate": (i32, [vp, C.POINTER(f32), sz, u32]),
+    "hzsdr_chain_plan": (i32, [vp, sz, psz, psz]),
+    "hzsdr_chain_run": (i32, [vp, vp, sz, vp, sz, psz, psz]),
+    "hzsdr_chain_reset": (i32, [vp]),
+    "hzsdr_chain_free": (i32, [vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header and library disagree
+    _fn.restype = _res
+    _fn.argtypes = _args

@@ -1,0 +1,745 @@
+// hz_chain.hip -- fused operator chains and the FFT-convolution kernels.
+//
+// A chain is nested stream.* Readers collapsed into one launch per buffer:
+// the "source functor" converts a raw input sample to complex64 and applies the
+// elementwise stages in order (Shift NCO, Gain, Multiply), and the terminal
+// stage decides how samples are consumed:
+//
+//   none / decimate / downsample  -> a streaming map kernel
+//   convolution (reference: block-circular, stream/convolution.go:36-82)
+//       -> per block: source functor -> forward FFT -> bins *= filter (Go
+//          complex64 multiply) -> backward FFT -> (optional DecimateReader pick)
+//   fir_decimate (north star: overlap-save FIR + decimate)
+//       -> per block of N_fft: history/source -> forward FFT -> bins *= H ->
+//          backward FFT -> keep the valid outputs on the decimation grid
+//
+// Every variant is one kernel on the context's stream; nothing is written to
+// HBM between stages.
+#include <math.h>
+
+#include "hz_common.h"
+#include "hz_device.h"
+#include "hz_fft.h"
+#include "hz_fft_api.h"
+#include "hz_nco.h"
+
+namespace hz {
+
+// ---- elementwise program -------------------------------------------------------------
+
+constexpr int kMaxEw = 6;
+enum EwKind { EW_SCALE = 1, EW_ROTATE = 2, EW_SHIFT = 3 };
+struct EwOp {
+    int kind;
+    float a, b;        // scale: a = r; rotate: a + ib
+    double tau_shift;  // shift: fl(2*pi * shift_hz)
+};
+struct EwProgram {
+    int n;
+    EwOp op[kMaxEw];
+    NcoSegs segs;  // one clock serves every Shift stage: same rate, same start, same length
+};
+
+__device__ __forceinline__ float2 ew_apply(const EwProgram &P, float2 v, uint64_t j) {
+    double ts = 0.0;
+    bool have_ts = false;
+    for (int i = 0; i < P.n; i++) {  // uniform
+        const EwOp &o = P.op[i];
+        if (o.kind == EW_SCALE) {
+            v = make_float2(__fmul_rn(v.x, o.a), __fmul_rn(v.y, o.a));  // stream/gain.go:39-48
+        } else if (o.kind == EW_ROTATE) {
+            v = go_cmul(v, make_float2(o.a, o.b));  // stream/multiply.go:46-70
+        } else {
+            if (!have_ts) {
+                ts = nco_ts(P.segs, j);
+                have_ts = true;
+            }
+            double ph = __dmul_rn(o.tau_shift, ts);  // stream/shifter.go:81
+            double s, c;
+            go_sincos(ph, s, c);
+            v = go_cmul(v, make_float2((float)c, (float)s));  // :82
+        }
+    }
+    return v;
+}
+
+template <int FMT> struct Raw;
+template <> struct Raw<HZSDR_FMT_C64> {
+    using t = float2;
+    static __device__ __forceinline__ float2 cvt(float2 r) { return r; }
+};
+template <> struct Raw<HZSDR_FMT_U8> {
+    using t = uint16_t;
+    static __device__ __forceinline__ float2 cvt(uint16_t r) { return make_float2(u8_to_f32(r & 0xFF), u8_to_f32(r >> 8)); }
+};
+template <> struct Raw<HZSDR_FMT_I8> {
+    using t = uint16_t;
+    static __device__ __forceinline__ float2 cvt(uint16_t r) { return make_float2(i8_to_f32((int8_t)(r & 0xFF)), i8_to_f32((int8_t)(r >> 8))); }
+};
+template <> struct Raw<HZSDR_FMT_I16> {
+    using t = uint32_t;
+    static __device__ __forceinline__ float2 cvt(uint32_t r) { return make_float2(i16_to_f32((int16_t)(r & 0xFFFF)), i16_to_f32((int16_t)(r >> 16))); }
+};
+
+// sample j of the buffer after conversion and the elementwise stages
+template <int FMT>
+__device__ __forceinline__ float2 chain_sample(const void *in, const EwProgram &P, uint64_t j) {
+    using R = typename Raw<FMT>::t;
+    return ew_apply(P, Raw<FMT>::cvt(((const R *)in)[j]), j);
+}
+
+// ---- streaming terminals ---------------------------------------------------------------
+
+// TERM 0: out[j] = f(j).  W samples per lane per step (vector load / store).
+template <int FMT, int W>
+__global__ __launch_bounds__(kThreads) void chain_map_kernel(const void *__restrict__ in,
+                                                             float2 *__restrict__ out, size_t nvec,
+                                                             uint64_t base, EwProgram P) {
+    using R = typename Raw<FMT>::t;
+    struct alignas(sizeof(R) * W) RV { R v[W]; };
+    struct alignas(8 * W) OV { float2 v[W]; };
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        RV x = ((const RV *)in)[i];
+        OV o;
+#pragma unroll
+        for (int l = 0; l < W; l++) o.v[l] = ew_apply(P, Raw<FMT>::cvt(x.v[l]), base + i * W + l);
+        ((OV *)out)[i] = o;
+    }
+}
+
+// DecimateReader: 32 Ki-sample blocks, `per` = 32768 / factor outputs per block,
+// out[blk*per + i] = f(blk*32768 + i*factor)  (stream/decimate.go:34-101)
+template <int FMT>
+__global__ __launch_bounds__(kThreads) void chain_decimate_kernel(const void *__restrict__ in,
+                                                                  float2 *__restrict__ out,
+                                                                  size_t n_out, size_t per,
+                                                                  size_t factor, EwProgram P) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += stride) {
+        const size_t blk = o / per, i = o - blk * per;
+        out[o] = chain_sample<FMT>(in, P, blk * kReaderBlock + i * factor);
+    }
+}
+
+// DownsampleReader: boxcar over `factor` samples inside 32 Ki-sample blocks
+// (stream/downsample.go:47-127), accumulated in order from +0.
+template <int FMT>
+__global__ __launch_bounds__(kThreads) void chain_downsample_kernel(const void *__restrict__ in,
+                                                                    float2 *__restrict__ out,
+                                                                    size_t n_out, size_t per,
+                                                                    unsigned factor, EwProgram P) {
+    const float div = (float)factor;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += stride) {
+        const size_t blk = o / per, i = o - blk * per;
+        const size_t j0 = blk * kReaderBlock + i * factor;
+        float sr = 0.0f, si = 0.0f;
+        for (unsigned k = 0; k < factor; k++) {
+            float2 c = chain_sample<FMT>(in, P, j0 + k);
+            sr = __fadd_rn(sr, c.x);
+            si = __fadd_rn(si, c.y);
+        }
+        out[o] = make_float2(__fdiv_rn(sr, div), __fdiv_rn(si, div));
+    }
+}
+
+// ---- reference convolution: block-circular, one workgroup pass per block ----------------
+
+// out stream position g -> optional DecimateReader pick over the conv output.
+__device__ __forceinline__ void conv_store(float2 *out, size_t g, float2 v, unsigned dec, size_t per) {
+    if (dec <= 1) {
+        out[g] = v;
+    } else {
+        const size_t blk = g / kReaderBlock, i = g - blk * kReaderBlock;
+        const size_t q = i / dec;
+        if (q * dec == i && q < per) out[blk * per + q] = v;
+    }
+}
+
+template <int N, int FMT>
+__global__ __launch_bounds__(fft_block(N)) void conv_blocks_kernel(const void *in, float2 *out,
+                                                                   const float2 *__restrict__ filt,
+                                                                   const float2 *__restrict__ tw,
+                                                                   size_t nblocks, unsigned dec,
+                                                                   size_t per, EwProgram P) {
+    constexpr int TPT = fft_tpt(N), XPB = fft_xpb(N), CNT = N / TPT;
+    __shared__ float2 lds_all[XPB * N];
+    const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
+    float2 *lds = lds_all + sub * N;
+    for (size_t b0 = (size_t)blockIdx.x * XPB; b0 < nblocks; b0 += (size_t)gridDim.x * XPB) {
+        const size_t b = b0 + sub;
+        const bool live = b < nblocks;
+        FftRegs<N> R;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < CNT; q++) {
+            const int idx = fft_odd(N) ? edge2_index<N>(q, lane) : edge4_index<N>(q, lane);
+            R.v[q] = live ? chain_sample<FMT>(in, P, b * N + idx) : make_float2(0.f, 0.f);
+        }
+        fft_forward_regs<N>(R, lds, tw, lane);
+#pragma unroll
+        for (int q = 0; q < CNT; q++)  // freq1[i] = freq1[i] * freq[i], fft/convolution.go:187-189
+            R.v[q] = go_cmul(R.v[q], filt[edge4_index<N>(q, lane)]);
+        fft_backward_regs<N>(R, lds, tw, lane);
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < CNT; q++) {
+                const int idx = fft_odd(N) ? edge2_index<N>(q, lane) : edge4_index<N>(q, lane);
+                conv_store(out, b * N + idx, R.v[q], dec, per);
+            }
+        }
+    }
+}
+
+// ---- north-star FIR-decimate: overlap-save ------------------------------------------------
+
+// Block b covers input positions [b*hop - off, b*hop - off + N); positions < 0
+// come from `hist` (the last `off` post-elementwise samples of the previous
+// run), positions >= n_in are zero.  Circular outputs at idx in [off, off+hop)
+// on the decimation grid are y[(b*hop + idx - off) / D].
+template <int N, int FMT>
+__global__ __launch_bounds__(fft_block(N)) void fir_decimate_kernel(
+    const void *in, float2 *out, const float2 *__restrict__ hist, const float2 *__restrict__ hfreq,
+    const float2 *__restrict__ tw, size_t nblocks, size_t n_in, unsigned hop, unsigned off, unsigned D,
+    EwProgram P) {
+    constexpr int TPT = fft_tpt(N), XPB = fft_xpb(N), CNT = N / TPT;
+    __shared__ float2 lds_all[XPB * N];
+    const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
+    float2 *lds = lds_all + sub * N;
+    for (size_t b0 = (size_t)blockIdx.x * XPB; b0 < nblocks; b0 += (size_t)gridDim.x * XPB) {
+        const size_t b = b0 + sub;
+        const bool live = b < nblocks;
+        FftRegs<N> R;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < CNT; q++) {
+            const int idx = fft_odd(N) ? edge2_index<N>(q, lane) : edge4_index<N>(q, lane);
+            const int64_t p = (int64_t)(b * hop) + idx - (int64_t)off;
+            float2 v = make_float2(0.f, 0.f);
+            if (live) {
+                if (p < 0) v = hist[p + off];
+                else if ((size_t)p < n_in) v = chain_sample<FMT>(in, P, (uint64_t)p);
+            }
+            R.v[q] = v;
+        }
+        fft_forward_regs<N>(R, lds, tw, lane);
+#pragma unroll
+        for (int q = 0; q < CNT; q++) R.v[q] = cmulf(R.v[q], hfreq[edge4_index<N>(q, lane)]);
+        fft_backward_regs<N>(R, lds, tw, lane);
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < CNT; q++) {
+                const unsigned idx = fft_odd(N) ? edge2_index<N>(q, lane) : edge4_index<N>(q, lane);
+                if (idx >= off && idx < off + hop && ((idx - off) % D) == 0) {
+                    const size_t p = b * hop + (idx - off);
+                    if (p < n_in) out[p / D] = R.v[q];
+                }
+            }
+        }
+    }
+}
+
+// New history = the last `off` samples of (old history ++ this run's samples).
+template <int FMT>
+__global__ void fir_history_kernel(const void *in, const float2 *__restrict__ old_hist,
+                                   float2 *__restrict__ new_hist, size_t n_in, unsigned off, EwProgram P) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < off; i += stride) {
+        const int64_t p = (int64_t)n_in - (int64_t)off + (int64_t)i;  // position in this run
+        new_hist[i] = p >= 0 ? chain_sample<FMT>(in, P, (uint64_t)p) : old_hist[p + off];
+    }
+}
+
+__global__ void scale_c64_kernel(float2 *buf, size_t n, float r) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        buf[i] = make_float2(buf[i].x * r, buf[i].y * r);
+}
+
+}  // namespace hz
+
+// =============================================================================
+
+enum ChainTerm { TERM_NONE = 0, TERM_DECIMATE, TERM_DOWNSAMPLE, TERM_CONV, TERM_FIR };
+
+struct hzsdr_chain {
+    hzsdr_ctx *ctx;
+    int src_fmt;
+    uint64_t sample_rate;
+    // elementwise stages
+    int n_ops = 0;
+    hz::EwOp ops[hz::kMaxEw];
+    bool has_shift = false;
+    double ts = 0.0;  // the shared NCO clock
+    // terminal
+    int term = TERM_NONE;
+    unsigned factor = 1;
+    // convolution
+    void *filt = nullptr;  // device, flen bins
+    size_t flen = 0;
+    // fir-decimate
+    void *hfreq = nullptr;  // device, nfft bins (FFT(taps)/nfft)
+    void *hist[2] = {nullptr, nullptr};
+    int hist_cur = 0;
+    size_t ntaps = 0;
+    unsigned nfft = 0, hop = 0, off = 0;
+};
+
+struct hzsdr_conv {
+    hzsdr_ctx *ctx;
+    int kind;  // 0 = ConvolveFreq, 1 = Convolve, 2 = CrossCorrelate
+    void *dst;
+    const void *src1, *src2;
+    size_t n;
+    void *filt;  // device copy of the frequency-domain filter (kind 0)
+};
+
+namespace hz {
+
+template <int N, int FMT>
+static void launch_conv_n(hzsdr_ctx *ctx, const void *in, void *out, const void *filt, const float2 *tw,
+                          size_t nblocks, unsigned dec, size_t per, const EwProgram &P) {
+    constexpr int XPB = fft_xpb(N);
+    size_t groups = (nblocks + XPB - 1) / XPB, cap = (size_t)ctx->num_cus * 16;
+    hipLaunchKernelGGL((conv_blocks_kernel<N, FMT>), dim3((unsigned)(groups < cap ? groups : cap)),
+                       dim3(fft_block(N)), 0, ctx->stream, in, (float2 *)out, (const float2 *)filt, tw,
+                       nblocks, dec, per, P);
+}
+
+template <int FMT>
+static int launch_conv_fmt(hzsdr_ctx *ctx, size_t n, const void *in, void *out, const void *filt,
+                           const float2 *tw, size_t nblocks, unsigned dec, size_t per, const EwProgram &P) {
+    switch (n) {
+    case 4: launch_conv_n<4, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
+    case 8: launch_conv_n<8, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
+    case 16: launch_conv_n<16, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
+    case 32: launch_conv_n<32, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
+    case 64: launch_conv_n<64, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
+    case 128: launch_conv_n<128, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
+    case 256: launch_conv_n<256, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
+    case 512: launch_conv_n<512, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
+    case 1024: launch_conv_n<1024, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
+    case 2048: launch_conv_n<2048, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
+    case 4096: launch_conv_n<4096, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
+    case 8192: launch_conv_n<8192, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
+    default: return HZSDR_ERR_INVALID_ARGUMENT;
+    }
+    return HZSDR_OK;
+}
+
+// Block-circular convolution of nblocks blocks of length n from a source of
+// format fmt with elementwise program P (device pointers).
+static int conv_blocks_device(hzsdr_ctx *ctx, int fmt, size_t n, const void *in, void *out,
+                              const void *filt, size_t nblocks, unsigned dec, size_t per,
+                              const EwProgram &P) {
+    if (nblocks == 0) return HZSDR_OK;
+    const float2 *tw;
+    HZ_TRY(get_twiddles(ctx, n, &tw));
+    switch (fmt) {
+    case HZSDR_FMT_C64: return launch_conv_fmt<HZSDR_FMT_C64>(ctx, n, in, out, filt, tw, nblocks, dec, per, P);
+    case HZSDR_FMT_U8: return launch_conv_fmt<HZSDR_FMT_U8>(ctx, n, in, out, filt, tw, nblocks, dec, per, P);
+    case HZSDR_FMT_I8: return launch_conv_fmt<HZSDR_FMT_I8>(ctx, n, in, out, filt, tw, nblocks, dec, per, P);
+    default: return launch_conv_fmt<HZSDR_FMT_I16>(ctx, n, in, out, filt, tw, nblocks, dec, per, P);
+    }
+}
+
+// Generic (any power of two) single-block path: three steps through scratch.
+static int conv_generic_device(hzsdr_ctx *ctx, void *dst, const void *src1, const void *src2_or_filt,
+                               size_t n, int kind) {
+    HZ_TRY(ensure_slot(ctx, 6, n * 8));
+    void *f1 = ctx->slots[6].ptr;
+    HZ_TRY(fft_device(ctx, src1, f1, n, 1, true));
+    if (kind == 0) {
+        pointwise_mul_device(ctx, f1, src2_or_filt, n, false);
+    } else {
+        HZ_TRY(ensure_slot(ctx, 7, n * 8));
+        void *f2 = ctx->slots[7].ptr;
+        HZ_TRY(fft_device(ctx, src2_or_filt, f2, n, 1, true));
+        pointwise_mul_device(ctx, f1, f2, n, kind == 2);
+    }
+    return fft_device(ctx, f1, dst, n, 1, false);
+}
+
+template <int FMT>
+static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, const EwProgram &P) {
+    using R = typename Raw<FMT>::t;
+    constexpr int W = 2;
+    const bool aligned = ((uintptr_t)in % (sizeof(R) * W) == 0) && ((uintptr_t)out % (8 * W) == 0);
+    size_t nvec = aligned ? n / W : 0;
+    if (nvec)
+        hipLaunchKernelGGL((chain_map_kernel<FMT, W>), dim3(blocks_for(ctx, nvec)), dim3(kThreads), 0,
+                           ctx->stream, in, (float2 *)out, nvec, (uint64_t)0, P);
+    size_t done = nvec * W;
+    if (done < n)
+        hipLaunchKernelGGL((chain_map_kernel<FMT, 1>), dim3(blocks_for(ctx, n - done)), dim3(kThreads), 0,
+                           ctx->stream, (const R *)in + done, (float2 *)out + done, n - done,
+                           (uint64_t)done, P);
+}
+
+template <int FMT>
+static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, size_t n_out,
+                   const EwProgram &P) {
+    hzsdr_ctx *ctx = c->ctx;
+    switch (c->term) {
+    case TERM_NONE: launch_map<FMT>(ctx, in, out, n_cons, P); break;
+    case TERM_DECIMATE:
+        hipLaunchKernelGGL((chain_decimate_kernel<FMT>), dim3(blocks_for(ctx, n_out)), dim3(kThreads), 0,
+                           ctx->stream, in, (float2 *)out, n_out, kReaderBlock / c->factor,
+                           (size_t)c->factor, P);
+        break;
+    case TERM_DOWNSAMPLE:
+        hipLaunchKernelGGL((chain_downsample_kernel<FMT>), dim3(blocks_for(ctx, n_out)), dim3(kThreads), 0,
+                           ctx->stream, in, (float2 *)out, n_out, kReaderBlock / c->factor, c->factor, P);
+        break;
+    case TERM_CONV:
+        return conv_blocks_device(ctx, FMT, c->flen, in, out, c->filt, n_cons / c->flen, c->factor,
+                                  c->factor > 1 ? kReaderBlock / c->factor : 0, P);
+    case TERM_FIR: {
+        const float2 *tw;
+        HZ_TRY(get_twiddles(ctx, c->nfft, &tw));
+        const size_t nblocks = (n_cons + c->hop - 1) / c->hop;
+        const float2 *hist = (const float2 *)c->hist[c->hist_cur];
+        float2 *nhist = (float2 *)c->hist[c->hist_cur ^ 1];
+        size_t cap = (size_t)ctx->num_cus * 16;
+        unsigned grid = (unsigned)(nblocks < cap ? nblocks : cap);
+#define HZ_FIR(N)                                                                                     \
+    hipLaunchKernelGGL((fir_decimate_kernel<N, FMT>), dim3(grid), dim3(fft_block(N)), 0, ctx->stream, \
+                       in, (float2 *)out, hist, (const float2 *)c->hfreq, tw, nblocks, n_cons, c->hop, \
+                       c->off, c->factor, P)
+        switch (c->nfft) {
+        case 256: HZ_FIR(256); break;
+        case 512: HZ_FIR(512); break;
+        case 1024: HZ_FIR(1024); break;
+        case 2048: HZ_FIR(2048); break;
+        case 4096: HZ_FIR(4096); break;
+        case 8192: HZ_FIR(8192); break;
+        default: return HZSDR_ERR_INVALID_ARGUMENT;
+        }
+#undef HZ_FIR
+        hipLaunchKernelGGL((fir_history_kernel<FMT>), dim3(blocks_for(ctx, c->off)), dim3(kThreads), 0,
+                           ctx->stream, in, hist, nhist, n_cons, c->off, P);
+        c->hist_cur ^= 1;
+        break;
+    }
+    }
+    return HZSDR_OK;
+}
+
+static int chain_terminal_set(hzsdr_chain *c) {
+    if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
+    if (c->term != TERM_NONE) return fail(c->ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: terminal stage already set");
+    return HZSDR_OK;
+}
+
+static int chain_push(hzsdr_chain *c, const EwOp &op) {
+    if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
+    if (c->term != TERM_NONE) return fail(c->ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: stage after the terminal stage");
+    if (c->n_ops >= kMaxEw) return fail(c->ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: too many elementwise stages");
+    c->ops[c->n_ops++] = op;
+    return HZSDR_OK;
+}
+
+}  // namespace hz
+
+extern "C" {
+
+int hzsdr_chain_create(hzsdr_ctx *ctx, int src_format, uint64_t sample_rate, hzsdr_chain **out) {
+    if (!ctx || !out) return HZSDR_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (hz::format_size(src_format) == 0) return hz::fail(ctx, HZSDR_ERR_FORMAT_UNKNOWN, "chain: unknown source format");
+    hzsdr_chain *c = new hzsdr_chain();
+    c->ctx = ctx;
+    c->src_fmt = src_format;
+    c->sample_rate = sample_rate;
+    *out = c;
+    return HZSDR_OK;
+}
+
+int hzsdr_chain_shift(hzsdr_chain *c, double shift_hz) {
+    if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
+    if (c->sample_rate == 0) return hz::fail(c->ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: shift needs a sample rate");
+    hz::EwOp op{};
+    op.kind = hz::EW_SHIFT;
+    op.tau_shift = (M_PI * 2) * shift_hz;
+    int rc = hz::chain_push(c, op);
+    if (rc == HZSDR_OK) c->has_shift = true;
+    return rc;
+}
+
+int hzsdr_chain_gain(hzsdr_chain *c, float r) {
+    hz::EwOp op{};
+    op.kind = hz::EW_SCALE;
+    op.a = r;
+    return hz::chain_push(c, op);
+}
+
+int hzsdr_chain_rotate(hzsdr_chain *c, float re, float im) {
+    if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
+    if (re == 1.0f && im == 0.0f) return HZSDR_OK;  // stream/multiply.go:59-62
+    hz::EwOp op{};
+    op.kind = hz::EW_ROTATE;
+    op.a = re;
+    op.b = im;
+    return hz::chain_push(c, op);
+}
+
+int hzsdr_chain_decimate(hzsdr_chain *c, unsigned factor) {
+    HZ_TRY(hz::chain_terminal_set(c));
+    if (factor == 0 || factor > hz::kReaderBlock) return hz::fail(c->ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: decimate factor");
+    // DecimateBuffer has no i8 case (stream/decimate.go:85-97); after a convert
+    // stage the stream is c64, so the restriction only bites a bare i8 chain.
+    c->term = TERM_DECIMATE;
+    c->factor = factor;
+    return HZSDR_OK;
+}
+
+int hzsdr_chain_downsample(hzsdr_chain *c, unsigned factor) {
+    HZ_TRY(hz::chain_terminal_set(c));
+    if (factor == 0 || factor > hz::kReaderBlock) return hz::fail(c->ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: downsample factor");
+    c->term = TERM_DOWNSAMPLE;
+    c->factor = factor;
+    return HZSDR_OK;
+}
+
+int hzsdr_chain_convolution(hzsdr_chain *c, const void *filter_freq, size_t filter_len,
+                            unsigned decimate_factor) {
+    using namespace hz;
+    HZ_TRY(chain_terminal_set(c));
+    hzsdr_ctx *ctx = c->ctx;
+    if (!filter_freq || !fft_lds_ok(filter_len))
+        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: filter length must be a power of two in 4..8192");
+    if (decimate_factor == 0 || decimate_factor > kReaderBlock) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: decimate factor");
+    HZ_TRY(enter(ctx));
+    HZ_HIP(ctx, hipMalloc(&c->filt, filter_len * 8));
+    hipMemcpyKind kind = ctx->memspace == HZSDR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    HZ_HIP(ctx, hipMemcpy(c->filt, filter_freq, filter_len * 8, kind));
+    c->flen = filter_len;
+    c->factor = decimate_factor;
+    c->term = TERM_CONV;
+    return HZSDR_OK;
+}
+
+int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps, size_t n_taps, unsigned factor) {
+    using namespace hz;
+    HZ_TRY(chain_terminal_set(c));
+    hzsdr_ctx *ctx = c->ctx;
+    if (!taps || n_taps == 0 || factor == 0) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: fir taps / factor");
+    // N_fft = next power of two >= 4 * taps, in [256, 8192]
+    unsigned nfft = 256;
+    while (nfft < 4 * n_taps && nfft < 8192) nfft <<= 1;
+    unsigned off = (unsigned)(n_taps - 1);
+    off = (off + factor - 1) / factor * factor;  // first valid output on the decimation grid
+    if (off + factor > nfft) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: too many taps for the 8192-point overlap-save block");
+    unsigned hop = (nfft - off) / factor * factor;
+    HZ_TRY(enter(ctx));
+    const size_t hb = (size_t)(off ? off : 1) * 8;
+    HZ_HIP(ctx, hipMalloc(&c->hfreq, (size_t)nfft * 8));
+    HZ_HIP(ctx, hipMalloc(&c->hist[0], hb));
+    HZ_HIP(ctx, hipMalloc(&c->hist[1], hb));
+    HZ_HIP(ctx, hipMemsetAsync(c->hist[0], 0, hb, ctx->stream));
+    HZ_HIP(ctx, hipMemsetAsync(c->hist[1], 0, hb, ctx->stream));
+    // H = FFT(taps zero-padded to N) / N, computed with this library's own transform
+    std::vector<float> padded(2 * (size_t)nfft, 0.0f);
+    memcpy(padded.data(), taps, n_taps * 8);
+    HZ_TRY(ensure_slot(ctx, 8, (size_t)nfft * 8));
+    HZ_HIP(ctx, hipMemcpy(ctx->slots[8].ptr, padded.data(), (size_t)nfft * 8, hipMemcpyHostToDevice));
+    HZ_TRY(fft_device(ctx, ctx->slots[8].ptr, c->hfreq, nfft, 1, true));
+    hipLaunchKernelGGL(scale_c64_kernel, dim3(blocks_for(ctx, nfft)), dim3(kThreads), 0, ctx->stream,
+                       (float2 *)c->hfreq, (size_t)nfft, 1.0f / (float)nfft);
+    HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    c->ntaps = n_taps;
+    c->nfft = nfft;
+    c->hop = hop;
+    c->off = off;
+    c->factor = factor;
+    c->term = TERM_FIR;
+    return HZSDR_OK;
+}
+
+int hzsdr_chain_plan(const hzsdr_chain *c, size_t n_in, size_t *n_consumed, size_t *n_out) {
+    if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
+    size_t cons = n_in, outn = n_in;
+    switch (c->term) {
+    case TERM_NONE: break;
+    case TERM_DECIMATE:
+    case TERM_DOWNSAMPLE:
+        cons = n_in / hz::kReaderBlock * hz::kReaderBlock;
+        outn = cons / hz::kReaderBlock * (hz::kReaderBlock / c->factor);
+        break;
+    case TERM_CONV: {
+        size_t blk = c->flen;
+        if (c->factor > 1 && blk < hz::kReaderBlock) blk = hz::kReaderBlock;
+        cons = n_in / blk * blk;
+        outn = c->factor > 1 ? cons / hz::kReaderBlock * (hz::kReaderBlock / c->factor) : cons;
+        break;
+    }
+    case TERM_FIR:
+        cons = n_in / c->factor * c->factor;
+        outn = cons / c->factor;
+        break;
+    }
+    if (n_consumed) *n_consumed = cons;
+    if (n_out) *n_out = outn;
+    return HZSDR_OK;
+}
+
+int hzsdr_chain_run(hzsdr_chain *c, const void *in, size_t n_in, void *out, size_t out_cap,
+                    size_t *n_consumed, size_t *n_out) {
+    using namespace hz;
+    if (n_consumed) *n_consumed = 0;
+    if (n_out) *n_out = 0;
+    if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
+    hzsdr_ctx *ctx = c->ctx;
+    size_t cons, outn;
+    hzsdr_chain_plan(c, n_in, &cons, &outn);
+    if (out_cap < outn) return fail(ctx, HZSDR_ERR_DST_TOO_SMALL, "chain: output buffer too small");
+    if (cons && (!in || !out)) return HZSDR_ERR_INVALID_ARGUMENT;
+    HZ_TRY(enter(ctx));
+    if (cons == 0) return HZSDR_OK;
+    EwProgram P{};
+    P.n = c->n_ops;
+    for (int i = 0; i < c->n_ops; i++) P.op[i] = c->ops[i];
+    double ts = c->ts;
+    if (c->has_shift) HZ_TRY(nco_plan(ctx, c->sample_rate, &ts, cons, &P.segs));
+    Stage st(ctx);
+    const void *din;
+    void *dout;
+    HZ_TRY(st.in(0, in, cons * format_size(c->src_fmt), &din));
+    HZ_TRY(st.out(1, out, outn * 8, &dout));
+    int rc;
+    switch (c->src_fmt) {
+    case HZSDR_FMT_C64: rc = run_fmt<HZSDR_FMT_C64>(c, din, cons, dout, outn, P); break;
+    case HZSDR_FMT_U8: rc = run_fmt<HZSDR_FMT_U8>(c, din, cons, dout, outn, P); break;
+    case HZSDR_FMT_I8: rc = run_fmt<HZSDR_FMT_I8>(c, din, cons, dout, outn, P); break;
+    default: rc = run_fmt<HZSDR_FMT_I16>(c, din, cons, dout, outn, P); break;
+    }
+    HZ_TRY(rc);
+    HZ_TRY(st.finish());
+    c->ts = ts;
+    if (n_consumed) *n_consumed = cons;
+    if (n_out) *n_out = outn;
+    return HZSDR_OK;
+}
+
+int hzsdr_chain_reset(hzsdr_chain *c) {
+    if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
+    hzsdr_ctx *ctx = c->ctx;
+    HZ_TRY(hz::enter(ctx));
+    c->ts = 0.0;
+    if (c->term == TERM_FIR) {
+        const size_t hb = (size_t)(c->off ? c->off : 1) * 8;
+        HZ_HIP(ctx, hipMemsetAsync(c->hist[0], 0, hb, ctx->stream));
+        HZ_HIP(ctx, hipMemsetAsync(c->hist[1], 0, hb, ctx->stream));
+    }
+    return HZSDR_OK;
+}
+
+int hzsdr_chain_free(hzsdr_chain *c) {
+    if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->filt) (void)hipFree(c->filt);
+    if (c->hfreq) (void)hipFree(c->hfreq);
+    if (c->hist[0]) (void)hipFree(c->hist[0]);
+    if (c->hist[1]) (void)hipFree(c->hist[1]);
+    delete c;
+    return HZSDR_OK;
+}
+
+// ---- fft.ConvolveFreq / Convolve / CrossCorrelate closures --------------------------------
+
+int hzsdr_convolve_freq_create(hzsdr_ctx *ctx, void *dst, size_t dst_len, const void *src,
+                               size_t src_len, const void *freq, size_t freq_len, hzsdr_conv **out) {
+    using namespace hz;
+    if (!ctx || !out) return HZSDR_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (src_len != dst_len || src_len != freq_len)  // fft/convolution.go:156-158
+        return fail(ctx, HZSDR_ERR_LENGTH_MISMATCH, "sdr/fft.Convolve: Lengths do not match exactly");
+    const size_t n = src_len;
+    if (n == 0 || (n & (n - 1)) || !dst || !src || !freq)
+        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "convolve: power-of-two length and non-null buffers");
+    HZ_TRY(enter(ctx));
+    void *filt = nullptr;
+    HZ_HIP(ctx, hipMalloc(&filt, n * 8));
+    hipMemcpyKind kind = ctx->memspace == HZSDR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    hipError_t e = hipMemcpy(filt, freq, n * 8, kind);
+    if (e != hipSuccess) {
+        (void)hipFree(filt);
+        return hip_fail(ctx, e, "filter upload", __FILE__, __LINE__);
+    }
+    *out = new hzsdr_conv{ctx, 0, dst, src, nullptr, n, filt};
+    return HZSDR_OK;
+}
+
+int hzsdr_convolve_create(hzsdr_ctx *ctx, void *dst, size_t dst_len, const void *iq1, size_t iq1_len,
+                          const void *iq2, size_t iq2_len, int mode, hzsdr_conv **out) {
+    using namespace hz;
+    if (!ctx || !out) return HZSDR_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (iq1_len != iq2_len || iq1_len != dst_len)  // fft/convolution.go:37-39
+        return fail(ctx, HZSDR_ERR_LENGTH_MISMATCH, "sdr/fft: IQ/Dest buffer lengths do not match exactly");
+    const size_t n = iq1_len;
+    if (n == 0 || (n & (n - 1)) || !dst || !iq1 || !iq2)
+        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "convolve: power-of-two length and non-null buffers");
+    if (mode != HZSDR_CONV_CONVOLVE && mode != HZSDR_CONV_CROSS_CORRELATE) return HZSDR_ERR_INVALID_ARGUMENT;
+    *out = new hzsdr_conv{ctx, mode == HZSDR_CONV_CONVOLVE ? 1 : 2, dst, iq1, iq2, n, nullptr};
+    return HZSDR_OK;
+}
+
+int hzsdr_conv_exec(hzsdr_conv *cv) {
+    using namespace hz;
+    if (!cv) return HZSDR_ERR_INVALID_ARGUMENT;
+    hzsdr_ctx *ctx = cv->ctx;
+    HZ_TRY(enter(ctx));
+    const size_t bytes = cv->n * 8;
+    Stage st(ctx);
+    const void *d1, *d2 = nullptr;
+    void *dd;
+    HZ_TRY(st.in(0, cv->src1, bytes, &d1));
+    if (cv->kind != 0) HZ_TRY(st.in(2, cv->src2, bytes, &d2));
+    HZ_TRY(st.out(1, cv->dst, bytes, &dd));
+    if (cv->kind == 0 && fft_lds_ok(cv->n)) {
+        EwProgram P{};
+        HZ_TRY(conv_blocks_device(ctx, HZSDR_FMT_C64, cv->n, d1, dd, cv->filt, 1, 1, 0, P));
+    } else {
+        HZ_TRY(conv_generic_device(ctx, dd, d1, cv->kind == 0 ? cv->filt : d2, cv->n, cv->kind));
+    }
+    return st.finish();
+}
+
+int hzsdr_conv_free(hzsdr_conv *cv) {
+    if (!cv) return HZSDR_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(cv->ctx->device);
+    (void)hipStreamSynchronize(cv->ctx->stream);
+    if (cv->filt) (void)hipFree(cv->filt);
+    delete cv;
+    return HZSDR_OK;
+}
+
+int hzsdr_convolution_blocks(hzsdr_ctx *ctx, void *out, size_t out_len, const void *in, size_t in_len,
+                             const void *filter_freq, size_t filter_len, size_t *n_out) {
+    using namespace hz;
+    if (n_out) *n_out = 0;
+    if (!ctx) return HZSDR_ERR_INVALID_ARGUMENT;
+    if (!fft_lds_ok(filter_len) || !filter_freq)
+        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "convolution: filter length must be a power of two in 4..8192");
+    const size_t nblocks = in_len / filter_len, n = nblocks * filter_len;
+    if (out_len < n) return fail(ctx, HZSDR_ERR_DST_TOO_SMALL, "convolution: output buffer too small");
+    if (n && (!in || !out)) return HZSDR_ERR_INVALID_ARGUMENT;
+    HZ_TRY(enter(ctx));
+    if (n == 0) return HZSDR_OK;
+    Stage st(ctx);
+    const void *din, *dfilt;
+    void *dout;
+    HZ_TRY(st.in(0, in, n * 8, &din));
+    HZ_TRY(st.in(2, filter_freq, filter_len * 8, &dfilt));
+    HZ_TRY(st.out(1, out, n * 8, &dout));
+    EwProgram P{};
+    HZ_TRY(conv_blocks_device(ctx, HZSDR_FMT_C64, filter_len, din, dout, dfilt, nblocks, 1, 0, P));
+    HZ_TRY(st.finish());
+    if (n_out) *n_out = n;
+    return HZSDR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,594 @@
+// hz_convert.hip -- format converters, lookup tables, Decimate, Downsample.
+//
+// All of these are HBM-bound byte/element maps: the kernels are grid-stride
+// loops whose wide side moves 16 B per lane per instruction (a wave covers
+// 1 KiB contiguous), with a scalar path for ragged heads/tails and for
+// pointers that are only sample-aligned (Go sub-slices).
+#include "hz_common.h"
+#include "hz_device.h"
+
+namespace hz {
+
+// ---- component maps ---------------------------------------------------------
+// Every converter is a per-component map over the flat array of 2n components.
+
+enum Conv {
+    U8_C64, U8_I8, U8_I16, I8_C64, I8_U8, I8_I16, I16_C64, I16_U8, I16_I8, C64_U8, C64_I16, C64_I8,
+    I16_SHL  // ShiftLSBToMSBBits
+};
+
+template <int C> struct ConvTraits;
+#define HZ_TRAITS(C, S, D) \
+    template <> struct ConvTraits<C> { using src_t = S; using dst_t = D; }
+HZ_TRAITS(U8_C64, uint8_t, float);
+HZ_TRAITS(U8_I8, uint8_t, int8_t);
+HZ_TRAITS(U8_I16, uint8_t, int16_t);
+HZ_TRAITS(I8_C64, int8_t, float);
+HZ_TRAITS(I8_U8, int8_t, uint8_t);
+HZ_TRAITS(I8_I16, int8_t, int16_t);
+HZ_TRAITS(I16_C64, int16_t, float);
+HZ_TRAITS(I16_U8, int16_t, uint8_t);
+HZ_TRAITS(I16_I8, int16_t, int8_t);
+HZ_TRAITS(C64_U8, float, uint8_t);
+HZ_TRAITS(C64_I16, float, int16_t);
+HZ_TRAITS(C64_I8, float, int8_t);
+HZ_TRAITS(I16_SHL, int16_t, int16_t);
+
+template <int C>
+__device__ __forceinline__ typename ConvTraits<C>::dst_t conv1(typename ConvTraits<C>::src_t v,
+                                                                int arg) {
+    if constexpr (C == U8_C64) return u8_to_f32(v);
+    if constexpr (C == U8_I8) return (int8_t)((int)v - 128);                       // iq_u8.go:93-96
+    if constexpr (C == U8_I16) return (int16_t)(((int)v << 8) - 32768);            // iq_u8.go:79-82
+    if constexpr (C == I8_C64) return i8_to_f32(v);
+    if constexpr (C == I8_U8) return (uint8_t)((int)v + 128);                      // iq_i8.go:89-92
+    if constexpr (C == I8_I16) return (int16_t)((uint32_t)(int)v << 8);            // iq_i8.go:75-78
+    if constexpr (C == I16_C64) return i16_to_f32(v);
+    if constexpr (C == I16_U8) return (uint8_t)((uint32_t)(((int)v + 32768) & 0xFFFF) >> 8);  // iq_i16.go:121-124
+    if constexpr (C == I16_I8) return (int8_t)((int)v >> 8);                       // iq_i16.go:155-158
+    if constexpr (C == C64_U8) return (uint8_t)f32_to_u8(v);
+    if constexpr (C == C64_I16) return (int16_t)f32_to_i16(v);
+    if constexpr (C == C64_I8) return (int8_t)f32_to_i8(v);
+    if constexpr (C == I16_SHL) return (int16_t)((uint32_t)(uint16_t)v << arg);    // iq_i16.go:106-109
+}
+
+template <class T, int N> struct alignas(sizeof(T) * N) Vec {
+    T v[N];
+};
+
+// K components per lane per step, chosen so the wider side is 16 B.
+template <int C> struct ConvGeom {
+    using S = typename ConvTraits<C>::src_t;
+    using D = typename ConvTraits<C>::dst_t;
+    static constexpr int wide = sizeof(S) > sizeof(D) ? sizeof(S) : sizeof(D);
+    static constexpr int K = 16 / wide;
+};
+
+template <int C>
+__global__ __launch_bounds__(kThreads) void convert_vec_kernel(
+    const typename ConvTraits<C>::src_t *__restrict__ src,
+    typename ConvTraits<C>::dst_t *__restrict__ dst, size_t nvec, int arg) {
+    using G = ConvGeom<C>;
+    using SV = Vec<typename G::S, G::K>;
+    using DV = Vec<typename G::D, G::K>;
+    const SV *s = reinterpret_cast<const SV *>(src);
+    DV *d = reinterpret_cast<DV *>(dst);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // 4 independent vectors in flight per lane
+    for (; i + 3 * stride < nvec; i += 4 * stride) {
+        SV a0 = s[i], a1 = s[i + stride], a2 = s[i + 2 * stride], a3 = s[i + 3 * stride];
+        DV r0, r1, r2, r3;
+#pragma unroll
+        for (int k = 0; k < G::K; k++) {
+            r0.v[k] = conv1<C>(a0.v[k], arg);
+            r1.v[k] = conv1<C>(a1.v[k], arg);
+            r2.v[k] = conv1<C>(a2.v[k], arg);
+            r3.v[k] = conv1<C>(a3.v[k], arg);
+        }
+        d[i] = r0;
+        d[i + stride] = r1;
+        d[i + 2 * stride] = r2;
+        d[i + 3 * stride] = r3;
+    }
+    for (; i < nvec; i += stride) {
+        SV a = s[i];
+        DV r;
+#pragma unroll
+        for (int k = 0; k < G::K; k++) r.v[k] = conv1<C>(a.v[k], arg);
+        d[i] = r;
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(kThreads) void convert_scalar_kernel(
+    const typename ConvTraits<C>::src_t *__restrict__ src,
+    typename ConvTraits<C>::dst_t *__restrict__ dst, size_t ncomp, int arg) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncomp; i += stride)
+        dst[i] = conv1<C>(src[i], arg);
+}
+
+// Launch one converter over ncomp components: vector body where both pointers
+// are 16 B / K-aligned, scalar kernel for the tail or for unaligned slices.
+template <int C>
+static void launch_convert(hzsdr_ctx *ctx, const void *src, void *dst, size_t ncomp, int arg = 0) {
+    using G = ConvGeom<C>;
+    using S = typename G::S;
+    using D = typename G::D;
+    if (ncomp == 0) return;
+    const S *s = (const S *)src;
+    D *d = (D *)dst;
+    const bool aligned = ((uintptr_t)s % (sizeof(S) * G::K) == 0) && ((uintptr_t)d % (sizeof(D) * G::K) == 0);
+    size_t nvec = aligned ? ncomp / G::K : 0;
+    if (nvec) {
+        hipLaunchKernelGGL(convert_vec_kernel<C>, dim3(blocks_for(ctx, (nvec + 3) / 4)), dim3(kThreads),
+                           0, ctx->stream, s, d, nvec, arg);
+    }
+    size_t done = nvec * G::K;
+    if (done < ncomp) {
+        hipLaunchKernelGGL(convert_scalar_kernel<C>, dim3(blocks_for(ctx, ncomp - done)),
+                           dim3(kThreads), 0, ctx->stream, s + done, d + done, ncomp - done, arg);
+    }
+}
+
+// Dispatch (src_format, dst_format) -> kernel; formats already validated.
+int convert_device(hzsdr_ctx *ctx, int dst_fmt, void *dst, int src_fmt, const void *src, size_t n) {
+    const size_t nc = 2 * n;
+    switch (src_fmt * 8 + dst_fmt) {
+    case HZSDR_FMT_U8 * 8 + HZSDR_FMT_C64: launch_convert<U8_C64>(ctx, src, dst, nc); break;
+    case HZSDR_FMT_U8 * 8 + HZSDR_FMT_I8: launch_convert<U8_I8>(ctx, src, dst, nc); break;
+    case HZSDR_FMT_U8 * 8 + HZSDR_FMT_I16: launch_convert<U8_I16>(ctx, src, dst, nc); break;
+    case HZSDR_FMT_I8 * 8 + HZSDR_FMT_C64: launch_convert<I8_C64>(ctx, src, dst, nc); break;
+    case HZSDR_FMT_I8 * 8 + HZSDR_FMT_U8: launch_convert<I8_U8>(ctx, src, dst, nc); break;
+    case HZSDR_FMT_I8 * 8 + HZSDR_FMT_I16: launch_convert<I8_I16>(ctx, src, dst, nc); break;
+    case HZSDR_FMT_I16 * 8 + HZSDR_FMT_C64: launch_convert<I16_C64>(ctx, src, dst, nc); break;
+    case HZSDR_FMT_I16 * 8 + HZSDR_FMT_U8: launch_convert<I16_U8>(ctx, src, dst, nc); break;
+    case HZSDR_FMT_I16 * 8 + HZSDR_FMT_I8: launch_convert<I16_I8>(ctx, src, dst, nc); break;
+    case HZSDR_FMT_C64 * 8 + HZSDR_FMT_U8: launch_convert<C64_U8>(ctx, src, dst, nc); break;
+    case HZSDR_FMT_C64 * 8 + HZSDR_FMT_I16: launch_convert<C64_I16>(ctx, src, dst, nc); break;
+    case HZSDR_FMT_C64 * 8 + HZSDR_FMT_I8: launch_convert<C64_I8>(ctx, src, dst, nc); break;
+    default: return HZSDR_ERR_CONVERSION_NOT_IMPLEMENTED;
+    }
+    return HZSDR_OK;
+}
+
+// ---- lookup-table gather ------------------------------------------------------
+
+// dst[i] = tab[idx(src[i])]; E = element type of one table entry / output sample.
+// UMUL255 selects stream.Multiply's private u8 index I*255 + Q
+// (stream/multiply.go:106-108) instead of the raw little-endian uint16.
+template <class E, bool UMUL255>
+__global__ __launch_bounds__(kThreads) void lut_kernel(const uint16_t *__restrict__ src,
+                                                       const E *__restrict__ tab, E *dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        uint32_t raw = src[i];
+        uint32_t idx = UMUL255 ? (raw & 0xFF) * 255u + (raw >> 8) : raw;
+        dst[i] = tab[idx];
+    }
+}
+
+// 4 samples per lane: one 8-byte source load, four gathers, vector store
+template <class E, bool UMUL255>
+__global__ __launch_bounds__(kThreads) void lut_kernel_x4(const uint2 *__restrict__ src,
+                                                          const E *__restrict__ tab,
+                                                          Vec<E, 4> *dst, size_t nvec) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        uint2 raw = src[i];
+        uint32_t r[4] = {raw.x & 0xFFFF, raw.x >> 16, raw.y & 0xFFFF, raw.y >> 16};
+        Vec<E, 4> o;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t idx = UMUL255 ? (r[k] & 0xFF) * 255u + (r[k] >> 8) : r[k];
+            o.v[k] = tab[idx];
+        }
+        dst[i] = o;
+    }
+}
+
+template <class E, bool UMUL255>
+static void launch_lut(hzsdr_ctx *ctx, const void *src, const void *tab, void *dst, size_t n) {
+    if (n == 0) return;
+    const bool aligned = ((uintptr_t)src % 8 == 0) && ((uintptr_t)dst % (sizeof(E) * 4) == 0);
+    size_t nvec = aligned ? n / 4 : 0;
+    if (nvec)
+        hipLaunchKernelGGL((lut_kernel_x4<E, UMUL255>), dim3(blocks_for(ctx, nvec)), dim3(kThreads), 0,
+                           ctx->stream, (const uint2 *)src, (const E *)tab, (Vec<E, 4> *)dst, nvec);
+    size_t done = nvec * 4;
+    if (done < n)
+        hipLaunchKernelGGL((lut_kernel<E, UMUL255>), dim3(blocks_for(ctx, n - done)), dim3(kThreads), 0,
+                           ctx->stream, (const uint16_t *)src + done, (const E *)tab, (E *)dst + done,
+                           n - done);
+}
+
+static void lut_device(hzsdr_ctx *ctx, int dst_fmt, const void *src, const void *tab, void *dst,
+                       size_t n) {
+    switch (format_size(dst_fmt)) {
+    case 2: launch_lut<uint16_t, false>(ctx, src, tab, dst, n); break;
+    case 4: launch_lut<uint32_t, false>(ctx, src, tab, dst, n); break;
+    default: launch_lut<uint2, false>(ctx, src, tab, dst, n); break;
+    }
+}
+
+// ---- Decimate -----------------------------------------------------------------
+
+// to[i] = from[factor * i]  (stream/decimate.go:84-98)
+template <class E>
+__global__ __launch_bounds__(kThreads) void decimate_kernel(const E *__restrict__ from, E *to,
+                                                            size_t count, size_t factor) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+        to[i] = from[i * factor];
+}
+
+void decimate_device(hzsdr_ctx *ctx, int fmt, const void *from, void *to, size_t count,
+                     size_t factor) {
+    if (count == 0) return;
+    dim3 g(blocks_for(ctx, count)), b(kThreads);
+    switch (format_size(fmt)) {
+    case 2: hipLaunchKernelGGL(decimate_kernel<uint16_t>, g, b, 0, ctx->stream, (const uint16_t *)from, (uint16_t *)to, count, factor); break;
+    case 4: hipLaunchKernelGGL(decimate_kernel<uint32_t>, g, b, 0, ctx->stream, (const uint32_t *)from, (uint32_t *)to, count, factor); break;
+    default: hipLaunchKernelGGL(decimate_kernel<uint2>, g, b, 0, ctx->stream, (const uint2 *)from, (uint2 *)to, count, factor); break;
+    }
+}
+
+// ---- Downsample -----------------------------------------------------------------
+
+template <int FMT> struct SrcSample;
+template <> struct SrcSample<HZSDR_FMT_U8> {
+    using raw_t = uint16_t;
+    static __device__ __forceinline__ float2 cvt(uint16_t r) { return make_float2(u8_to_f32(r & 0xFF), u8_to_f32(r >> 8)); }
+};
+template <> struct SrcSample<HZSDR_FMT_I8> {
+    using raw_t = uint16_t;
+    static __device__ __forceinline__ float2 cvt(uint16_t r) { return make_float2(i8_to_f32((int8_t)(r & 0xFF)), i8_to_f32((int8_t)(r >> 8))); }
+};
+template <> struct SrcSample<HZSDR_FMT_I16> {
+    using raw_t = uint32_t;
+    static __device__ __forceinline__ float2 cvt(uint32_t r) { return make_float2(i16_to_f32((int16_t)(r & 0xFFFF)), i16_to_f32((int16_t)(r >> 16))); }
+};
+template <> struct SrcSample<HZSDR_FMT_C64> {
+    using raw_t = float2;
+    static __device__ __forceinline__ float2 cvt(float2 r) { return r; }
+};
+
+// One output per lane: convert `factor` consecutive samples, accumulate in
+// order from +0, divide by float32(factor)  (stream/downsample.go:99-124).
+// W raw samples are fetched per vector load (W * sizeof(raw) = 16 B) when the
+// window geometry allows (factor % W == 0 and 16-B aligned source).
+template <int FMT, int W>
+__global__ __launch_bounds__(kThreads) void downsample_kernel(
+    const typename SrcSample<FMT>::raw_t *__restrict__ from, float2 *to, size_t count,
+    unsigned factor) {
+    using R = typename SrcSample<FMT>::raw_t;
+    const float div = (float)factor;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const R *w = from + i * factor;
+        float sr = 0.0f, si = 0.0f;
+        if constexpr (W > 1) {
+            const Vec<R, W> *wv = reinterpret_cast<const Vec<R, W> *>(w);
+            for (unsigned j = 0; j < factor / W; j++) {
+                Vec<R, W> v = wv[j];
+#pragma unroll
+                for (int k = 0; k < W; k++) {
+                    float2 c = SrcSample<FMT>::cvt(v.v[k]);
+                    sr = __fadd_rn(sr, c.x);
+                    si = __fadd_rn(si, c.y);
+                }
+            }
+        } else {
+            for (unsigned j = 0; j < factor; j++) {
+                float2 c = SrcSample<FMT>::cvt(w[j]);
+                sr = __fadd_rn(sr, c.x);
+                si = __fadd_rn(si, c.y);
+            }
+        }
+        to[i] = make_float2(__fdiv_rn(sr, div), __fdiv_rn(si, div));
+    }
+}
+
+template <int FMT>
+static void launch_downsample(hzsdr_ctx *ctx, const void *from, void *to, size_t count,
+                              unsigned factor) {
+    using R = typename SrcSample<FMT>::raw_t;
+    constexpr int W = 16 / sizeof(R);
+    if (count == 0) return;
+    dim3 g(blocks_for(ctx, count)), b(kThreads);
+    if (factor % W == 0 && (uintptr_t)from % 16 == 0)
+        hipLaunchKernelGGL((downsample_kernel<FMT, W>), g, b, 0, ctx->stream, (const R *)from, (float2 *)to, count, factor);
+    else
+        hipLaunchKernelGGL((downsample_kernel<FMT, 1>), g, b, 0, ctx->stream, (const R *)from, (float2 *)to, count, factor);
+}
+
+void downsample_device(hzsdr_ctx *ctx, int from_fmt, const void *from, void *to, size_t count,
+                       unsigned factor) {
+    switch (from_fmt) {
+    case HZSDR_FMT_U8: launch_downsample<HZSDR_FMT_U8>(ctx, from, to, count, factor); break;
+    case HZSDR_FMT_I16: launch_downsample<HZSDR_FMT_I16>(ctx, from, to, count, factor); break;
+    default: launch_downsample<HZSDR_FMT_C64>(ctx, from, to, count, factor); break;
+    }
+}
+
+// used by hz_vector.hip (rotate) -- declared there
+void rotate_device(hzsdr_ctx *ctx, void *buf, size_t n, float re, float im);
+
+}  // namespace hz
+
+// =============================================================================
+// C ABI
+// =============================================================================
+
+struct hzsdr_lut {
+    hzsdr_ctx *ctx;
+    int src_fmt, dst_fmt;
+    void *tab;  // device, 65536 entries
+};
+
+struct hzsdr_rotlut {
+    hzsdr_ctx *ctx;
+    int fmt;
+    void *tab;     // device: u8 -> 65535 entries (I*255+Q), i8 -> 65536 entries
+    float *cbuf;   // device scratch for the c64 round trip
+};
+
+extern "C" {
+
+int hzsdr_convert(hzsdr_ctx *ctx, int dst_format, void *dst, size_t dst_len, int src_format,
+                  const void *src, size_t src_len, size_t *n_out) {
+    using namespace hz;
+    if (n_out) *n_out = 0;
+    if (!ctx) return HZSDR_ERR_INVALID_ARGUMENT;
+    const int ss = format_size(src_format), ds = format_size(dst_format);
+    if (ss == 0 || ds == 0) return fail(ctx, HZSDR_ERR_FORMAT_UNKNOWN, "convert: unknown format");
+    size_t n = src_len;
+    if (src_format == dst_format) {
+        if (dst_len < n) n = dst_len;  // CopySamples -> copy(dst, src), copy.go:31-52
+    } else if (src_len > dst_len) {
+        return fail(ctx, HZSDR_ERR_DST_TOO_SMALL, "convert: dst shorter than src");  // conv.go:60-62
+    }
+    if (n && (!src || !dst)) return HZSDR_ERR_INVALID_ARGUMENT;
+    HZ_TRY(enter(ctx));
+    if (n == 0) return HZSDR_OK;
+    if (src_format == dst_format) {
+        hipMemcpyKind kind = ctx->memspace == HZSDR_MEM_HOST ? hipMemcpyHostToHost : hipMemcpyDeviceToDevice;
+        if (ctx->memspace == HZSDR_MEM_HOST) {
+            memmove(dst, src, n * ss);
+        } else {
+            HZ_HIP(ctx, hipMemcpyAsync(dst, src, n * ss, kind, ctx->stream));
+        }
+        if (n_out) *n_out = n;
+        return HZSDR_OK;
+    }
+    Stage st(ctx);
+    const void *dsrc;
+    void *ddst;
+    HZ_TRY(st.in(0, src, n * ss, &dsrc));
+    HZ_TRY(st.out(1, dst, n * ds, &ddst));
+    HZ_TRY(convert_device(ctx, dst_format, ddst, src_format, dsrc, n));
+    HZ_TRY(st.finish());
+    if (n_out) *n_out = n;
+    return HZSDR_OK;
+}
+
+int hzsdr_i16_shift_lsb_to_msb(hzsdr_ctx *ctx, void *buf, size_t n, int bits) {
+    using namespace hz;
+    if (!ctx || (n && !buf)) return HZSDR_ERR_INVALID_ARGUMENT;
+    if (bits < 0 || bits > 16) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "shift: bits outside 0..16");
+    HZ_TRY(enter(ctx));
+    if (n == 0) return HZSDR_OK;
+    Stage st(ctx);
+    void *d;
+    HZ_TRY(st.inout(0, buf, n * 4, &d));
+    launch_convert<I16_SHL>(ctx, d, d, 2 * n, 16 - bits);
+    return st.finish();
+}
+
+int hzsdr_lut_create(hzsdr_ctx *ctx, int src_format, int dst_format, const void *table,
+                     size_t table_len, hzsdr_lut **out) {
+    using namespace hz;
+    if (!ctx || !out) return HZSDR_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    const int ds = format_size(dst_format);
+    if (ds == 0) return fail(ctx, HZSDR_ERR_FORMAT_UNKNOWN, "lut: unknown table format");
+    if (table_len != 65536 || !table)  // iq_lookup_table.go:107-109
+        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "lut: table must be exactly 65536 samples");
+    if (src_format != HZSDR_FMT_U8 && src_format != HZSDR_FMT_I8)  // :111-116
+        return fail(ctx, HZSDR_ERR_FORMAT_UNKNOWN, "lut: input format must be u8 or i8");
+    HZ_TRY(enter(ctx));
+    void *tab = nullptr;
+    HZ_HIP(ctx, hipMalloc(&tab, (size_t)65536 * ds));
+    hipMemcpyKind kind = ctx->memspace == HZSDR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    hipError_t e = hipMemcpyAsync(tab, table, (size_t)65536 * ds, kind, ctx->stream);
+    if (e == hipSuccess && ctx->memspace == HZSDR_MEM_HOST) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(tab);
+        return hip_fail(ctx, e, "lut table upload", __FILE__, __LINE__);
+    }
+    *out = new hzsdr_lut{ctx, src_format, dst_format, tab};
+    return HZSDR_OK;
+}
+
+int hzsdr_lut_lookup(hzsdr_lut *lut, int dst_format, void *dst, size_t dst_len, int src_format,
+                     const void *src, size_t src_len, size_t *n_out) {
+    using namespace hz;
+    if (n_out) *n_out = 0;
+    if (!lut) return HZSDR_ERR_INVALID_ARGUMENT;
+    hzsdr_ctx *ctx = lut->ctx;
+    if (dst_format != lut->dst_fmt)  // iq_lookup_table.go:130-132
+        return fail(ctx, HZSDR_ERR_FORMAT_MISMATCH, "lut: dst format differs from the table's");
+    if (dst_len < src_len) return fail(ctx, HZSDR_ERR_DST_TOO_SMALL, "lut: dst shorter than src");  // :133-135
+    if (src_format != lut->src_fmt) return fail(ctx, HZSDR_ERR_FORMAT_MISMATCH, "lut: src format differs");
+    if (src_len && (!src || !dst)) return HZSDR_ERR_INVALID_ARGUMENT;
+    HZ_TRY(enter(ctx));
+    if (src_len == 0) return HZSDR_OK;
+    const int ds = format_size(dst_format);
+    Stage st(ctx);
+    const void *dsrc;
+    void *ddst;
+    HZ_TRY(st.in(0, src, src_len * 2, &dsrc));
+    HZ_TRY(st.out(1, dst, src_len * ds, &ddst));
+    lut_device(ctx, dst_format, dsrc, lut->tab, ddst, src_len);
+    HZ_TRY(st.finish());
+    if (n_out) *n_out = src_len;
+    return HZSDR_OK;
+}
+
+int hzsdr_lut_free(hzsdr_lut *lut) {
+    if (!lut) return HZSDR_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(lut->ctx->device);
+    (void)hipStreamSynchronize(lut->ctx->stream);
+    (void)hipFree(lut->tab);
+    delete lut;
+    return HZSDR_OK;
+}
+
+// ---- stream.Multiply for u8 / i8 ---------------------------------------------
+
+int hzsdr_rotlut_set_multiplier(hzsdr_rotlut *t, float re, float im) {
+    using namespace hz;
+    if (!t) return HZSDR_ERR_INVALID_ARGUMENT;
+    hzsdr_ctx *ctx = t->ctx;
+    HZ_TRY(enter(ctx));
+    // Host builds only the KEY table (which samples sit at which index, with the
+    // reference's fill order); the arithmetic runs through the same GPU
+    // converter / rotate kernels a caller would use (stream/multiply.go:165-171).
+    const size_t entries = t->fmt == HZSDR_FMT_U8 ? 65535 : 65536;
+    HZ_TRY(ensure_pinned(ctx, entries * 2));
+    uint8_t *keys = (uint8_t *)ctx->pinned;
+    if (t->fmt == HZSDR_FMT_U8) {
+        memset(keys, 0, entries * 2);
+        for (uint32_t realv = 0; realv < 256; realv++)        // stream/multiply.go:156-163
+            for (uint32_t imagv = 0; imagv <= 256; imagv++) {
+                uint8_t i8 = (uint8_t)realv, q8 = (uint8_t)imagv;
+                uint32_t idx = (uint32_t)i8 * 255 + q8;        // :106-108
+                keys[2 * idx] = i8;
+                keys[2 * idx + 1] = q8;
+            }
+    } else {
+        hzsdr_lut_identity(keys);                              // :222
+    }
+    HZ_HIP(ctx, hipMemcpyAsync(t->tab, keys, entries * 2, hipMemcpyHostToDevice, ctx->stream));
+    HZ_TRY(convert_device(ctx, HZSDR_FMT_C64, t->cbuf, t->fmt, t->tab, entries));
+    rotate_device(ctx, t->cbuf, entries, re, im);
+    HZ_TRY(convert_device(ctx, t->fmt, t->tab, HZSDR_FMT_C64, t->cbuf, entries));
+    HZ_HIP(ctx, hipGetLastError());
+    // the pinned key buffer is reused by later calls: wait for the upload
+    HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HZSDR_OK;
+}
+
+int hzsdr_rotlut_create(hzsdr_ctx *ctx, int format, float re, float im, hzsdr_rotlut **out) {
+    using namespace hz;
+    if (!ctx || !out) return HZSDR_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (format != HZSDR_FMT_U8 && format != HZSDR_FMT_I8)
+        return fail(ctx, HZSDR_ERR_FORMAT_UNKNOWN, "rotlut: format must be u8 or i8");
+    HZ_TRY(enter(ctx));
+    hzsdr_rotlut *t = new hzsdr_rotlut{ctx, format, nullptr, nullptr};
+    hipError_t e = hipMalloc(&t->tab, 65536 * 2);
+    if (e == hipSuccess) e = hipMalloc((void **)&t->cbuf, 65536 * 8);
+    if (e != hipSuccess) {
+        if (t->tab) (void)hipFree(t->tab);
+        delete t;
+        return hip_fail(ctx, e, "rotlut alloc", __FILE__, __LINE__);
+    }
+    int rc = hzsdr_rotlut_set_multiplier(t, re, im);
+    if (rc != HZSDR_OK) {
+        hzsdr_rotlut_free(t);
+        return rc;
+    }
+    *out = t;
+    return HZSDR_OK;
+}
+
+int hzsdr_rotlut_apply(hzsdr_rotlut *t, void *buf, size_t n) {
+    using namespace hz;
+    if (!t || (n && !buf)) return HZSDR_ERR_INVALID_ARGUMENT;
+    hzsdr_ctx *ctx = t->ctx;
+    HZ_TRY(enter(ctx));
+    if (n == 0) return HZSDR_OK;
+    Stage st(ctx);
+    void *d;
+    HZ_TRY(st.inout(0, buf, n * 2, &d));
+    if (t->fmt == HZSDR_FMT_U8)
+        launch_lut<uint16_t, true>(ctx, d, t->tab, d, n);
+    else
+        launch_lut<uint16_t, false>(ctx, d, t->tab, d, n);
+    return st.finish();
+}
+
+int hzsdr_rotlut_free(hzsdr_rotlut *t) {
+    if (!t) return HZSDR_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipStreamSynchronize(t->ctx->stream);
+    if (t->tab) (void)hipFree(t->tab);
+    if (t->cbuf) (void)hipFree(t->cbuf);
+    delete t;
+    return HZSDR_OK;
+}
+
+// ---- Decimate / Downsample -----------------------------------------------------
+
+int hzsdr_decimate(hzsdr_ctx *ctx, int to_format, void *to, size_t to_len, int from_format,
+                   const void *from, size_t from_len, unsigned factor, int64_t offset,
+                   size_t *n_out) {
+    using namespace hz;
+    (void)offset;  // accepted and ignored, as stream/decimate.go:59-101 does
+    if (n_out) *n_out = 0;
+    if (!ctx) return HZSDR_ERR_INVALID_ARGUMENT;
+    if (from_format != to_format)  // :60-62
+        return fail(ctx, HZSDR_ERR_FORMAT_MISMATCH, "decimate: formats differ");
+    if (factor == 0) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "decimate: factor 0");
+    const size_t count = from_len / factor;
+    if (to_len < count) return fail(ctx, HZSDR_ERR_DST_TOO_SMALL, "decimate: dst too small");  // :68-70
+    if (count > 0 && from_format != HZSDR_FMT_U8 && from_format != HZSDR_FMT_I16 &&
+        from_format != HZSDR_FMT_C64)  // :85-97 (i8 is not in the type switch)
+        return fail(ctx, HZSDR_ERR_FORMAT_UNKNOWN, "decimate: format not handled");
+    if (count && (!to || !from)) return HZSDR_ERR_INVALID_ARGUMENT;
+    HZ_TRY(enter(ctx));
+    if (count == 0) return HZSDR_OK;
+    const int sz = format_size(from_format);
+    Stage st(ctx);
+    const void *dfrom;
+    void *dto;
+    HZ_TRY(st.in(0, from, ((count - 1) * factor + 1) * sz, &dfrom));
+    HZ_TRY(st.out(1, to, count * sz, &dto));
+    decimate_device(ctx, from_format, dfrom, dto, count, factor);
+    HZ_TRY(st.finish());
+    if (n_out) *n_out = count;
+    return HZSDR_OK;
+}
+
+int hzsdr_downsample(hzsdr_ctx *ctx, int to_format, void *to, size_t to_len, int from_format,
+                     const void *from, size_t from_len, unsigned factor, int64_t offset,
+                     size_t *n_out) {
+    using namespace hz;
+    (void)offset;
+    if (n_out) *n_out = 0;
+    if (!ctx) return HZSDR_ERR_INVALID_ARGUMENT;
+    if (to_format != HZSDR_FMT_C64)  // stream/downsample.go:69-71
+        return fail(ctx, HZSDR_ERR_FORMAT_MISMATCH, "downsample: dst must be c64");
+    if (factor == 0) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "downsample: factor 0");
+    const size_t count = from_len / factor;
+    if (to_len < count) return fail(ctx, HZSDR_ERR_DST_TOO_SMALL, "downsample: dst too small");  // :77-79
+    if (count > 0 && from_format != HZSDR_FMT_U8 && from_format != HZSDR_FMT_I16 &&
+        from_format != HZSDR_FMT_C64)  // :104-114
+        return fail(ctx, HZSDR_ERR_FORMAT_UNKNOWN, "downsample: format not handled");
+    if (count && (!to || !from)) return HZSDR_ERR_INVALID_ARGUMENT;
+    HZ_TRY(enter(ctx));
+    if (count == 0) return HZSDR_OK;
+    Stage st(ctx);
+    const void *dfrom;
+    void *dto;
+    HZ_TRY(st.in(0, from, count * factor * format_size(from_format), &dfrom));
+    HZ_TRY(st.out(1, to, count * 8, &dto));
+    downsample_device(ctx, from_format, dfrom, dto, count, factor);
+    HZ_TRY(st.finish());
+    if (n_out) *n_out = count;
+    return HZSDR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,202 @@
+// hz_ctx.hip -- context lifecycle, memory, staging (C-ABI: library / context section).
+#include "hz_common.h"
+
+namespace hz {
+
+int ensure_slot(hzsdr_ctx *ctx, int slot, size_t bytes) {
+    auto &s = ctx->slots[slot];
+    if (bytes <= s.cap) return HZSDR_OK;
+    if (s.ptr) {
+        // the old buffer may still be in use by enqueued work
+        HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        HZ_HIP(ctx, hipFree(s.ptr));
+        s.ptr = nullptr;
+        s.cap = 0;
+    }
+    size_t cap = (bytes + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
+    HZ_HIP(ctx, hipMalloc(&s.ptr, cap));
+    s.cap = cap;
+    return HZSDR_OK;
+}
+
+int ensure_pinned(hzsdr_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->pinned_cap) return HZSDR_OK;
+    if (ctx->pinned) {
+        HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        HZ_HIP(ctx, hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_cap = 0;
+    }
+    size_t cap = bytes < 4096 ? 4096 : bytes;
+    HZ_HIP(ctx, hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault));
+    ctx->pinned_cap = cap;
+    return HZSDR_OK;
+}
+
+int Stage::in(int slot, const void *p, size_t bytes, const void **dev) {
+    if (!host() || bytes == 0) {
+        *dev = p;
+        return HZSDR_OK;
+    }
+    HZ_TRY(ensure_slot(ctx, slot, bytes));
+    HZ_HIP(ctx, hipMemcpyAsync(ctx->slots[slot].ptr, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dev = ctx->slots[slot].ptr;
+    return HZSDR_OK;
+}
+
+int Stage::out(int slot, void *p, size_t bytes, void **dev) {
+    if (!host() || bytes == 0) {
+        *dev = p;
+        return HZSDR_OK;
+    }
+    HZ_TRY(ensure_slot(ctx, slot, bytes));
+    *dev = ctx->slots[slot].ptr;
+    backs.push_back({p, *dev, bytes});
+    return HZSDR_OK;
+}
+
+int Stage::inout(int slot, void *p, size_t bytes, void **dev) {
+    if (!host() || bytes == 0) {
+        *dev = p;
+        return HZSDR_OK;
+    }
+    HZ_TRY(ensure_slot(ctx, slot, bytes));
+    HZ_HIP(ctx, hipMemcpyAsync(ctx->slots[slot].ptr, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dev = ctx->slots[slot].ptr;
+    backs.push_back({p, *dev, bytes});
+    return HZSDR_OK;
+}
+
+int Stage::finish() {
+    HZ_HIP(ctx, hipGetLastError());
+    if (!host()) return HZSDR_OK;
+    for (auto &b : backs)
+        HZ_HIP(ctx, hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HZSDR_OK;
+}
+
+static bool device_is_gfx950(int dev) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
+    return strncmp(p.gcnArchName, "gfx950", 6) == 0;
+}
+
+}  // namespace hz
+
+extern "C" {
+
+int hzsdr_device_count(int *count) {
+    if (!count) return HZSDR_ERR_INVALID_ARGUMENT;
+    *count = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return HZSDR_ERR_NO_DEVICE;
+    }
+    int ok = 0;
+    for (int i = 0; i < n; i++)
+        if (hz::device_is_gfx950(i)) ok++;
+    *count = ok;
+    return ok > 0 ? HZSDR_OK : HZSDR_ERR_NO_DEVICE;
+}
+
+int hzsdr_open(int device, int memspace, hzsdr_ctx **out) {
+    if (!out) return HZSDR_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (memspace != HZSDR_MEM_HOST && memspace != HZSDR_MEM_DEVICE) return HZSDR_ERR_INVALID_ARGUMENT;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return HZSDR_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) return HZSDR_ERR_INVALID_ARGUMENT;
+    // This library carries gfx950 code objects only: fail loudly elsewhere.
+    if (!hz::device_is_gfx950(device)) return HZSDR_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return HZSDR_ERR_NO_DEVICE;
+    hzsdr_ctx *ctx = new hzsdr_ctx();
+    ctx->device = device;
+    ctx->memspace = memspace;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) == hipSuccess && p.multiProcessorCount > 0)
+        ctx->num_cus = p.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return HZSDR_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return HZSDR_OK;
+}
+
+int hzsdr_close(hzsdr_ctx *ctx) {
+    if (!ctx) return HZSDR_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &s : ctx->slots)
+        if (s.ptr) (void)hipFree(s.ptr);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (auto &kv : ctx->twiddles) (void)hipFree(kv.second);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return HZSDR_OK;
+}
+
+const char *hzsdr_last_error(const hzsdr_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int hzsdr_memspace(const hzsdr_ctx *ctx) { return ctx ? ctx->memspace : -1; }
+
+int hzsdr_set_stream(hzsdr_ctx *ctx, void *hip_stream) {
+    HZ_TRY(hz::enter(ctx));
+    HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return HZSDR_OK;
+}
+
+void *hzsdr_get_stream(const hzsdr_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int hzsdr_synchronize(hzsdr_ctx *ctx) {
+    HZ_TRY(hz::enter(ctx));
+    HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HZSDR_OK;
+}
+
+int hzsdr_malloc_device(hzsdr_ctx *ctx, size_t bytes, void **out) {
+    HZ_TRY(hz::enter(ctx));
+    if (!out) return HZSDR_ERR_INVALID_ARGUMENT;
+    HZ_HIP(ctx, hipMalloc(out, bytes ? bytes : 1));
+    return HZSDR_OK;
+}
+
+int hzsdr_free_device(hzsdr_ctx *ctx, void *ptr) {
+    HZ_TRY(hz::enter(ctx));
+    HZ_HIP(ctx, hipFree(ptr));
+    return HZSDR_OK;
+}
+
+int hzsdr_malloc_pinned(hzsdr_ctx *ctx, size_t bytes, void **out) {
+    HZ_TRY(hz::enter(ctx));
+    if (!out) return HZSDR_ERR_INVALID_ARGUMENT;
+    HZ_HIP(ctx, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return HZSDR_OK;
+}
+
+int hzsdr_free_pinned(hzsdr_ctx *ctx, void *ptr) {
+    HZ_TRY(hz::enter(ctx));
+    HZ_HIP(ctx, hipHostFree(ptr));
+    return HZSDR_OK;
+}
+
+int hzsdr_memcpy_h2d(hzsdr_ctx *ctx, void *dst_device, const void *src_host, size_t bytes) {
+    HZ_TRY(hz::enter(ctx));
+    HZ_HIP(ctx, hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return HZSDR_OK;
+}
+
+int hzsdr_memcpy_d2h(hzsdr_ctx *ctx, void *dst_host, const void *src_device, size_t bytes) {
+    HZ_TRY(hz::enter(ctx));
+    HZ_HIP(ctx, hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return HZSDR_OK;
+}
+
+}  // extern "C"

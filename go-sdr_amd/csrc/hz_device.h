@@ -1,0 +1,180 @@
+// hz_device.h -- device-side arithmetic shared by every kernel.
+//
+// The arithmetic contracts (what "bit-exact with the reference" means here)
+// are the Go/amd64 ones: float32/float64 real ops round once and are never
+// fused (the translation units are built with -ffp-contract=off and anything
+// that must not fuse is written with explicit operations), complex64 products
+// are formed in float64 and narrowed once, float->narrow-int conversions go
+// through a truncating float->int32 conversion.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hz {
+
+// Go complex64 * complex64: cmd/compile widens to float64 ("Compute in
+// Float64 to minimize cancellation error"), forms ar*br - ai*bi and
+// ar*bi + ai*br, narrows each once.  Products of two float32 values are exact
+// in float64, so fma(a, c, -(b*d)) rounds the same exact value once and is
+// bit-identical to the un-fused form while costing half the f64 issue slots.
+// Call sites: internal/simd/mult.go:29-33, stream/shifter.go:82,
+// fft/convolution.go:107-109,129-134,187-189.
+__device__ __forceinline__ float2 go_cmul(float2 a, float2 b) {
+    double ar = a.x, ai = a.y, br = b.x, bi = b.y;
+    double re = __fma_rn(ar, br, -(ai * bi));
+    double im = __fma_rn(ar, bi, ai * br);
+    return make_float2((float)re, (float)im);
+}
+
+// Go float32 -> int32 on amd64 (CVTTSS2SL): truncation; NaN and out-of-range
+// give 0x80000000 ("integer indefinite"), unlike v_cvt_i32_f32 which saturates.
+__device__ __forceinline__ int32_t go_f32_to_i32(float x) {
+    int32_t r = (int32_t)x;  // v_cvt_i32_f32: truncates, saturates, NaN -> 0
+    bool in_range = (x > -2147483904.0f) && (x < 2147483648.0f);
+    return in_range ? r : INT32_MIN;
+}
+
+// ---- per-component converters (one float / integer component each) --------
+
+// iq_u8.go:111-121 / iq_u8_amd64.s:71-89: (float32(b) - 127.5) / 127.5
+__device__ __forceinline__ float u8_to_f32(uint32_t b) {
+    return __fdiv_rn(__fsub_rn((float)b, 127.5f), 127.5f);
+}
+// iq_i8.go:109-119: float32(b) / 128 (exact)
+__device__ __forceinline__ float i8_to_f32(int32_t b) { return __fdiv_rn((float)b, 128.0f); }
+// iq_i16.go:137-147: float32(v) / 32767
+__device__ __forceinline__ float i16_to_f32(int32_t v) { return __fdiv_rn((float)v, 32767.0f); }
+// iq_c64.go:77-89: uint8(x*127.5 + 127.5), un-fused
+__device__ __forceinline__ uint32_t f32_to_u8(float x) {
+    float v = __fadd_rn(__fmul_rn(x, 127.5f), 127.5f);
+    return (uint32_t)go_f32_to_i32(v) & 0xFFu;
+}
+// iq_c64.go:92-103: int16(x * 32767)
+__device__ __forceinline__ uint32_t f32_to_i16(float x) {
+    return (uint32_t)go_f32_to_i32(__fmul_rn(x, 32767.0f)) & 0xFFFFu;
+}
+// iq_c64.go:106-117: int8(x * 127)
+__device__ __forceinline__ uint32_t f32_to_i8(float x) {
+    return (uint32_t)go_f32_to_i32(__fmul_rn(x, 127.0f)) & 0xFFu;
+}
+
+// ---- math.Sincos (Go standard library) restated for the device -------------
+// src/math/sin.go coefficients (Cephes), src/math/sincos.go Cody-Waite
+// reduction for x < 2^29, src/math/trig_reduce.go Payne-Hanek above.  Every
+// operation is an explicit un-fused IEEE double op so the result equals the
+// host restatement in oracle/hzsdr_oracle.c bit for bit.
+
+__device__ __constant__ static const uint64_t kMPi4[20] = {
+    0x0000000000000001ULL, 0x45f306dc9c882a53ULL, 0xf84eafa3ea69bb81ULL, 0xb6c52b3278872083ULL,
+    0xfca2c757bd778ac3ULL, 0x6e48dc74849ba5c0ULL, 0x0c925dd413a32439ULL, 0xfc3bd63962534e7dULL,
+    0xd1046bea5d768909ULL, 0xd338e04d68befc82ULL, 0x7323ac7306a673e9ULL, 0x3908bf177bf25076ULL,
+    0x3ff12fffbc0b301fULL, 0xde5e2316b414da3eULL, 0xda6cfd9e4f96136eULL, 0x9e8c7ecd3cbfd45aULL,
+    0xea4f758fd7cbe2f6ULL, 0x7a0e73ef14a525d4ULL, 0xd7f6bf623f1aba10ULL, 0xac06608df8f6d757ULL,
+};
+
+__device__ __forceinline__ uint64_t shr64(uint64_t v, unsigned s) { return s >= 64 ? 0 : v >> s; }
+__device__ __forceinline__ uint64_t shl64(uint64_t v, unsigned s) { return s >= 64 ? 0 : v << s; }
+
+// trigReduce(x) for x >= 2^29 (never reached below pi/4 from Sincos)
+__device__ __noinline__ void go_trig_reduce(double x, uint32_t &j_out, double &z_out) {
+    uint64_t ix = (uint64_t)__double_as_longlong(x);
+    int exp = (int)((ix >> 52) & 0x7FF) - 1023 - 52;
+    ix &= ~(0x7FFULL << 52);
+    ix |= 1ULL << 52;
+    unsigned digit = (unsigned)(exp + 61) / 64, bitshift = (unsigned)(exp + 61) % 64;
+    uint64_t d0 = kMPi4[digit], d1 = kMPi4[digit + 1], d2 = kMPi4[digit + 2], d3 = kMPi4[digit + 3];
+    uint64_t z0 = (d0 << bitshift) | shr64(d1, 64 - bitshift);
+    uint64_t z1 = (d1 << bitshift) | shr64(d2, 64 - bitshift);
+    uint64_t z2 = (d2 << bitshift) | shr64(d3, 64 - bitshift);
+    uint64_t z2hi = __umul64hi(z2, ix);
+    uint64_t z1hi = __umul64hi(z1, ix), z1lo = z1 * ix;
+    uint64_t z0lo = z0 * ix;
+    uint64_t lo = z1lo + z2hi;
+    uint64_t c = lo < z1lo ? 1 : 0;
+    uint64_t hi = z0lo + z1hi + c;
+    uint32_t j = (uint32_t)(hi >> 61);
+    hi = (hi << 3) | (lo >> 61);
+    unsigned lz = hi == 0 ? 64u : (unsigned)__clzll((long long)hi);
+    uint64_t e = (uint64_t)(1023 - (lz + 1));
+    hi = shl64(hi, lz + 1) | shr64(lo, 64 - (lz + 1));
+    hi >>= 64 - 52;
+    hi |= e << 52;
+    double z = __longlong_as_double((long long)hi);
+    if (j & 1) {
+        j++;
+        j &= 7;
+        z = __dsub_rn(z, 1.0);
+    }
+    j_out = j;
+    z_out = __dmul_rn(z, 0.78539816339744830961566084581987572);
+}
+
+// math.Sincos(x) -> (sin, cos)
+__device__ __forceinline__ void go_sincos(double x, double &sn, double &cs) {
+    const double PI4A = 7.85398125648498535156e-1;
+    const double PI4B = 3.77489470793079817668e-8;
+    const double PI4C = 2.69515142907905952645e-15;
+    const double M4PI = 1.27323954473516268615107010698;
+    if (x == 0.0) {
+        sn = x;
+        cs = 1.0;
+        return;
+    }
+    if (!(fabs(x) <= 1.7976931348623157e308)) {  // NaN or Inf
+        sn = __longlong_as_double(0x7FF8000000000001LL);
+        cs = sn;
+        return;
+    }
+    bool sin_sign = false, cos_sign = false;
+    if (x < 0) {
+        x = -x;
+        sin_sign = true;
+    }
+    uint32_t j;
+    double z;
+    if (x >= 536870912.0) {
+        go_trig_reduce(x, j, z);
+    } else {
+        uint64_t jj = (uint64_t)__dmul_rn(x, M4PI);
+        double y = (double)jj;
+        if (jj & 1) {
+            jj++;
+            y = __dadd_rn(y, 1.0);
+        }
+        j = (uint32_t)(jj & 7);
+        z = __dsub_rn(__dsub_rn(__dsub_rn(x, __dmul_rn(y, PI4A)), __dmul_rn(y, PI4B)),
+                      __dmul_rn(y, PI4C));
+    }
+    if (j > 3) {
+        j -= 4;
+        sin_sign = !sin_sign;
+        cos_sign = !cos_sign;
+    }
+    if (j > 1) cos_sign = !cos_sign;
+    double zz = __dmul_rn(z, z);
+    // cos = 1.0 - 0.5*zz + zz*zz*((((((c0*zz)+c1)*zz+c2)*zz+c3)*zz+c4)*zz+c5)
+    double pc = __dmul_rn(-1.13585365213876817300e-11, zz);
+    pc = __dmul_rn(__dadd_rn(pc, 2.08757008419747316778e-9), zz);
+    pc = __dmul_rn(__dadd_rn(pc, -2.75573141792967388112e-7), zz);
+    pc = __dmul_rn(__dadd_rn(pc, 2.48015872888517045348e-5), zz);
+    pc = __dmul_rn(__dadd_rn(pc, -1.38888888888730564116e-3), zz);
+    pc = __dadd_rn(pc, 4.16666666666665929218e-2);
+    double c = __dadd_rn(__dsub_rn(1.0, __dmul_rn(0.5, zz)), __dmul_rn(__dmul_rn(zz, zz), pc));
+    // sin = z + z*zz*((((((s0*zz)+s1)*zz+s2)*zz+s3)*zz+s4)*zz+s5)
+    double ps = __dmul_rn(1.58962301576546568060e-10, zz);
+    ps = __dmul_rn(__dadd_rn(ps, -2.50507477628578072866e-8), zz);
+    ps = __dmul_rn(__dadd_rn(ps, 2.75573136213857245213e-6), zz);
+    ps = __dmul_rn(__dadd_rn(ps, -1.98412698295895385996e-4), zz);
+    ps = __dmul_rn(__dadd_rn(ps, 8.33333333332211858878e-3), zz);
+    ps = __dadd_rn(ps, -1.66666666666666307295e-1);
+    double s = __dadd_rn(z, __dmul_rn(__dmul_rn(z, zz), ps));
+    if (j == 1 || j == 2) {
+        double t = s;
+        s = c;
+        c = t;
+    }
+    sn = sin_sign ? -s : s;
+    cs = cos_sign ? -c : c;
+}
+
+}  // namespace hz

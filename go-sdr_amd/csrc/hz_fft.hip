@@ -1,0 +1,250 @@
+// hz_fft.hip -- fft.Planner / fft.Plan (fft/fft.go:45-59) and the two-input
+// fft.Convolve / fft.CrossCorrelate closures (fft/convolution.go:30-138).
+//
+// N in [4, 8192]: one LDS-resident kernel per Transform (hz_fft.h).  Other
+// powers of two (1, 2, > 8192) take a plain global-memory Stockham radix-2 path:
+// correct, unoptimised (the 64 Ki-point kerberos sizes are a "next" row).
+#include "hz_fft.h"
+
+#include <math.h>
+
+#include "hz_common.h"
+#include "hz_device.h"
+#include "hz_fft_api.h"
+
+namespace hz {
+
+// ---- twiddle tables ---------------------------------------------------------------
+
+int get_twiddles(hzsdr_ctx *ctx, size_t n, const float2 **out) {
+    auto it = ctx->twiddles.find(n);
+    if (it != ctx->twiddles.end()) {
+        *out = (const float2 *)it->second;
+        return HZSDR_OK;
+    }
+    std::vector<float2> h(n);
+    for (size_t m = 0; m < n; m++) {
+        double a = -2.0 * M_PI * (double)m / (double)n;
+        h[m] = make_float2((float)cos(a), (float)sin(a));
+    }
+    void *d = nullptr;
+    HZ_HIP(ctx, hipMalloc(&d, n * sizeof(float2)));
+    hipError_t e = hipMemcpy(d, h.data(), n * sizeof(float2), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return hip_fail(ctx, e, "twiddle upload", __FILE__, __LINE__);
+    }
+    ctx->twiddles[n] = d;
+    *out = (const float2 *)d;
+    return HZSDR_OK;
+}
+
+// ---- LDS kernels ---------------------------------------------------------------------
+
+template <int N, bool FWD>
+__global__ __launch_bounds__(fft_block(N)) void fft_plan_kernel(const float2 *__restrict__ in,
+                                                                float2 *__restrict__ out,
+                                                                const float2 *__restrict__ tw,
+                                                                size_t batch) {
+    constexpr int TPT = fft_tpt(N), XPB = fft_xpb(N), CNT = N / TPT;
+    __shared__ float2 lds_all[XPB * N];
+    const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
+    float2 *lds = lds_all + sub * N;
+    for (size_t t0 = (size_t)blockIdx.x * XPB; t0 < batch; t0 += (size_t)gridDim.x * XPB) {
+        const size_t t = t0 + sub;
+        const bool live = t < batch;
+        const float2 *src = in + t * N;
+        float2 *dst = out + t * N;
+        FftRegs<N> R;
+        __syncthreads();  // previous iteration's LDS reads are done
+        if constexpr (FWD) {
+#pragma unroll
+            for (int q = 0; q < CNT; q++) {
+                const int idx = fft_odd(N) ? edge2_index<N>(q, lane) : edge4_index<N>(q, lane);
+                R.v[q] = live ? src[idx] : make_float2(0.f, 0.f);
+            }
+            fft_forward_regs<N>(R, lds, tw, lane);
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < CNT; q++) dst[edge4_index<N>(q, lane)] = R.v[q];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < CNT; q++) R.v[q] = live ? src[edge4_index<N>(q, lane)] : make_float2(0.f, 0.f);
+            fft_backward_regs<N>(R, lds, tw, lane);
+            if (live) {
+#pragma unroll
+                for (int q = 0; q < CNT; q++) {
+                    const int idx = fft_odd(N) ? edge2_index<N>(q, lane) : edge4_index<N>(q, lane);
+                    dst[idx] = R.v[q];
+                }
+            }
+        }
+    }
+}
+
+template <int N>
+static void launch_plan_n(hzsdr_ctx *ctx, const float2 *in, float2 *out, const float2 *tw, size_t batch,
+                          bool fwd) {
+    constexpr int XPB = fft_xpb(N);
+    size_t groups = (batch + XPB - 1) / XPB;
+    size_t cap = (size_t)ctx->num_cus * 16;
+    unsigned grid = (unsigned)(groups < cap ? groups : cap);
+    if (fwd)
+        hipLaunchKernelGGL((fft_plan_kernel<N, true>), dim3(grid), dim3(fft_block(N)), 0, ctx->stream, in, out, tw, batch);
+    else
+        hipLaunchKernelGGL((fft_plan_kernel<N, false>), dim3(grid), dim3(fft_block(N)), 0, ctx->stream, in, out, tw, batch);
+}
+
+// ---- generic global-memory path ---------------------------------------------------------
+
+__global__ void fft_global_r2_pass(const float2 *__restrict__ in, float2 *__restrict__ out,
+                                   const float2 *__restrict__ tw, size_t n, size_t ns, size_t batch,
+                                   bool inv) {
+    const size_t half = n / 2, total = half * batch;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const size_t t = g / half, j = g % half;
+        const size_t k = j & (ns - 1);
+        float2 a = in[t * n + j], b = in[t * n + j + half];
+        if (ns > 1) {
+            float2 w = tw[k * (n / (2 * ns))];
+            if (inv) w.y = -w.y;
+            b = cmulf(b, w);
+        }
+        const size_t j0 = ((j - k) << 1) + k;
+        out[t * n + j0] = cadd(a, b);
+        out[t * n + j0 + ns] = csub(a, b);
+    }
+}
+
+static int fft_global(hzsdr_ctx *ctx, const float2 *in, float2 *out, size_t n, size_t batch, bool fwd) {
+    const size_t bytes = n * batch * sizeof(float2);
+    if (n == 1) {
+        if (in != out) HZ_HIP(ctx, hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        return HZSDR_OK;
+    }
+    const float2 *tw;
+    HZ_TRY(get_twiddles(ctx, n, &tw));
+    HZ_TRY(ensure_slot(ctx, 10, bytes));
+    HZ_TRY(ensure_slot(ctx, 11, bytes));
+    float2 *ta = (float2 *)ctx->slots[10].ptr, *tb = (float2 *)ctx->slots[11].ptr;
+    int passes = 0;
+    for (size_t s = 1; s < n; s <<= 1) passes++;
+    const float2 *src = in;
+    size_t ns = 1;
+    for (int p = 0; p < passes; p++, ns <<= 1) {
+        float2 *dst = (p == passes - 1) ? out : ((p & 1) ? tb : ta);
+        hipLaunchKernelGGL(fft_global_r2_pass, dim3(blocks_for(ctx, n / 2 * batch)), dim3(kThreads), 0,
+                           ctx->stream, src, dst, tw, n, ns, batch, !fwd);
+        src = dst;
+    }
+    return HZSDR_OK;
+}
+
+// Transform `batch` consecutive length-n blocks of device memory.
+int fft_device(hzsdr_ctx *ctx, const void *in, void *out, size_t n, size_t batch, bool fwd) {
+    if (batch == 0 || n == 0) return HZSDR_OK;
+    const float2 *i = (const float2 *)in;
+    float2 *o = (float2 *)out;
+    if (!fft_lds_ok(n)) return fft_global(ctx, i, o, n, batch, fwd);
+    const float2 *tw;
+    HZ_TRY(get_twiddles(ctx, n, &tw));
+    switch (n) {
+    case 4: launch_plan_n<4>(ctx, i, o, tw, batch, fwd); break;
+    case 8: launch_plan_n<8>(ctx, i, o, tw, batch, fwd); break;
+    case 16: launch_plan_n<16>(ctx, i, o, tw, batch, fwd); break;
+    case 32: launch_plan_n<32>(ctx, i, o, tw, batch, fwd); break;
+    case 64: launch_plan_n<64>(ctx, i, o, tw, batch, fwd); break;
+    case 128: launch_plan_n<128>(ctx, i, o, tw, batch, fwd); break;
+    case 256: launch_plan_n<256>(ctx, i, o, tw, batch, fwd); break;
+    case 512: launch_plan_n<512>(ctx, i, o, tw, batch, fwd); break;
+    case 1024: launch_plan_n<1024>(ctx, i, o, tw, batch, fwd); break;
+    case 2048: launch_plan_n<2048>(ctx, i, o, tw, batch, fwd); break;
+    case 4096: launch_plan_n<4096>(ctx, i, o, tw, batch, fwd); break;
+    case 8192: launch_plan_n<8192>(ctx, i, o, tw, batch, fwd); break;
+    default: return HZSDR_ERR_INVALID_ARGUMENT;
+    }
+    return HZSDR_OK;
+}
+
+// f1[i] = f1[i] * f2[i] or f1[i] * conj(f2[i]) with Go complex64 semantics
+// (fft/convolution.go:107-109, :129-134).
+__global__ void pointwise_mul_kernel(float2 *f1, const float2 *__restrict__ f2, size_t n, bool conj) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float2 b = f2[i];
+        if (conj) b.y = -b.y;
+        f1[i] = go_cmul(f1[i], b);
+    }
+}
+
+void pointwise_mul_device(hzsdr_ctx *ctx, void *f1, const void *f2, size_t n, bool conj) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(pointwise_mul_kernel, dim3(blocks_for(ctx, n)), dim3(kThreads), 0, ctx->stream,
+                       (float2 *)f1, (const float2 *)f2, n, conj);
+}
+
+}  // namespace hz
+
+struct hzsdr_fft {
+    hzsdr_ctx *ctx;
+    void *iq, *freq;
+    size_t n, batch;
+    bool fwd;
+};
+
+extern "C" {
+
+int hzsdr_fft_plan_batch(hzsdr_ctx *ctx, void *iq, void *freq, size_t n, size_t batch, int direction,
+                         hzsdr_fft **out) {
+    using namespace hz;
+    if (!ctx || !out) return HZSDR_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (n == 0 || (n & (n - 1)) != 0 || n > ((size_t)1 << 24))
+        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "fft: length must be a power of two <= 2^24");
+    if (batch == 0 || !iq || !freq) return HZSDR_ERR_INVALID_ARGUMENT;
+    if (direction != HZSDR_FFT_FORWARD && direction != HZSDR_FFT_BACKWARD) return HZSDR_ERR_INVALID_ARGUMENT;
+    HZ_TRY(enter(ctx));
+    const float2 *tw;
+    if (n > 1) HZ_TRY(get_twiddles(ctx, n, &tw));  // plan-time cost, like any planner
+    *out = new hzsdr_fft{ctx, iq, freq, n, batch, direction == HZSDR_FFT_FORWARD};
+    return HZSDR_OK;
+}
+
+int hzsdr_fft_plan(hzsdr_ctx *ctx, void *iq, size_t iq_len, void *freq, size_t freq_len, int direction,
+                   hzsdr_fft **out) {
+    if (!ctx || !out) return HZSDR_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (iq_len != freq_len)  // testutils/fft.go:127-137
+        return hz::fail(ctx, HZSDR_ERR_DST_TOO_SMALL, "fft: iq and frequency lengths differ");
+    return hzsdr_fft_plan_batch(ctx, iq, freq, iq_len, 1, direction, out);
+}
+
+int hzsdr_fft_transform(hzsdr_fft *p) {
+    using namespace hz;
+    if (!p) return HZSDR_ERR_INVALID_ARGUMENT;
+    hzsdr_ctx *ctx = p->ctx;
+    HZ_TRY(enter(ctx));
+    const size_t bytes = p->n * p->batch * 8;
+    Stage st(ctx);
+    const void *din;
+    void *dout;
+    if (p->fwd) {
+        HZ_TRY(st.in(0, p->iq, bytes, &din));
+        HZ_TRY(st.out(1, p->freq, bytes, &dout));
+    } else {
+        HZ_TRY(st.in(0, p->freq, bytes, &din));
+        HZ_TRY(st.out(1, p->iq, bytes, &dout));
+    }
+    HZ_TRY(fft_device(ctx, din, dout, p->n, p->batch, p->fwd));
+    return st.finish();
+}
+
+int hzsdr_fft_free(hzsdr_fft *p) {
+    if (!p) return HZSDR_ERR_INVALID_ARGUMENT;
+    delete p;
+    return HZSDR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// hz_nco.h -- NCO clock tables shared by hz_nco.hip and hz_chain.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/hzsdr.h"
+
+struct hzsdr_ctx;
+
+namespace hz {
+
+constexpr int kNcoMaxSegs = 32;
+
+// The exactly-linear runs of the NCO clock for one buffer (see
+// hzsdr_nco_segments).  Up to kNcoMaxSegs runs travel by value in the kernel
+// arguments (scalar loads, uniform scan); longer tables (tiny sample rates,
+// tie binades) are read from device memory with a binary search.
+struct NcoSegs {
+    int n;      // runs held inline (0 when `big` is used)
+    int big_n;  // runs in `big`
+    const hzsdr_nco_segment *big;
+    uint64_t first[kNcoMaxSegs];
+    double t0[kNcoMaxSegs];
+    double step[kNcoMaxSegs];
+};
+
+// ts for sample j of the buffer the table was planned for
+__device__ __forceinline__ double nco_ts(const NcoSegs &sg, uint64_t j) {
+    uint64_t first;
+    double t0, step;
+    if (sg.big_n == 0) {
+        first = sg.first[0];
+        t0 = sg.t0[0];
+        step = sg.step[0];
+        for (int s = 1; s < sg.n; s++) {
+            if (j >= sg.first[s]) {
+                first = sg.first[s];
+                t0 = sg.t0[s];
+                step = sg.step[s];
+            }
+        }
+    } else {
+        int lo = 0, hi = sg.big_n - 1;  // last run with first <= j
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (sg.big[mid].first <= j) lo = mid; else hi = mid - 1;
+        }
+        first = sg.big[lo].first;
+        t0 = sg.big[lo].t0;
+        step = sg.big[lo].step;
+    }
+    return __fma_rn((double)(j - first), step, t0);  // exact: the value is representable
+}
+
+// Plans the next n clock values from *ts (advancing it) into `sg`; a table too
+// long for the inline form is uploaded to a context scratch slot.
+int nco_plan(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, size_t n, NcoSegs *sg);
+// In-place shift of n samples at device pointer buf, advancing *ts.
+int nco_shift_device(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, double shift_hz, void *buf,
+                     size_t n);
+
+}  // namespace hz

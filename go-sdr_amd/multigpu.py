@@ -1,0 +1,117 @@
+"""Beamform sharded over GPUs: one process per GPU, channels
+split contiguously over ranks, each rank runs its channels' weighted partial sum
+locally (hzsdr_beamform_partial) and ONE exchange step combines them.
+
+Two exchanges, both plain torch.distributed (backend "nccl" = RCCL over xGMI on
+the GPU box, "gloo" in the CPU tests):
+
+  reduce_fast      dist.reduce(SUM) of the per-rank partial sums onto rank 0.
+                   Fast path; the summation order is RCCL's, so the result is
+                   within a few ULP of the reference, not bit-identical.
+  ordered_pipeline rank r receives the running sum from rank r-1, continues the
+                   reference's left-to-right accumulation with its own channels
+                   (stream/add.go:115-119 order) and forwards it; sliced so hops
+                   overlap.  Bit-identical to the single-GPU / reference result;
+                   the final sum lands on the LAST rank.
+
+Nothing here touches sample values on the host; `partial_fn` is the only thing
+that computes, and on the GPU box it is the HIP kernel.
+"""
+import time
+
+import numpy as np
+
+
+def shard_channels(n_channels, world, rank):
+    """Contiguous channel range [lo, hi) owned by `rank` (order-preserving)."""
+    lo = n_channels * rank // world
+    hi = n_channels * (rank + 1) // world
+    return lo, hi
+
+
+def reduce_fast(dist, torch, partial, dst=0):
+    """Sum complex64 partials elementwise onto rank `dst` (float32 lanes)."""
+    dist.reduce(torch.view_as_real(partial), dst=dst, op=dist.ReduceOp.SUM)
+    return partial
+
+
+def ordered_pipeline(dist, rank, world, out, partial_fn, n_slices=8):
+    """Fixed-order accumulation across ranks.  partial_fn(lo, hi, accumulate)
+    must do out[lo:hi] = (out[lo:hi] if accumulate else 0) + sum of this rank's
+    weighted channels over samples [lo, hi), left to right."""
+    import torch
+    n = out.shape[0]
+    bounds = [n * s // n_slices for s in range(n_slices + 1)]
+    reqs = []
+    for s in range(n_slices):
+        lo, hi = bounds[s], bounds[s + 1]
+        if hi == lo:
+            continue
+        view = torch.view_as_real(out[lo:hi])
+        if rank > 0:
+            dist.recv(view, src=rank - 1)
+        partial_fn(lo, hi, rank > 0)
+        if rank < world - 1:
+            reqs.append(dist.isend(view, dst=rank + 1))
+    for r in reqs:
+        r.wait()
+    return out
+
+
+def bench_beamform(hz, ctx, torch, dist, rank, world, n, steps, warmup, synth):
+    """4-channel (or `world`-channel when world > 4) coherent c64 beamform, one
+    exchange per buffer.  Returns the JSON sub-object bench.py attaches."""
+    k = max(4, world)
+    lo, hi = shard_channels(k, world, rank)
+    chans = [torch.from_numpy(synth(5 + c, n)).cuda() for c in range(lo, hi)]
+    dists = [0.1 * c for c in range(k)]
+    weights = hz.beamform_angles(433e6, 30.0, dists)
+    my_w = weights[lo:hi]
+    out = torch.zeros(n, dtype=torch.complex64, device="cuda")
+
+    def fast():
+        if chans:
+            ctx.beamform(out, chans, my_w)
+        else:
+            out.zero_()
+        reduce_fast(dist, torch, out, dst=0)
+
+    def ordered():
+        def part(a, b, acc):
+            if chans:
+                ctx.beamform(out[a:b], [c[a:b] for c in chans], my_w, accumulate=acc)
+            elif not acc:
+                out[a:b].zero_()
+        ordered_pipeline(dist, rank, world, out, part)
+
+    res = {"channels": k, "samples_per_channel": n, "channels_per_gpu": hi - lo}
+    for name, fn in (("rccl_reduce", fast), ("ordered_pipeline", ordered)):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        ms = float(el.item()) / steps * 1e3
+        res[name] = {"ms_per_buffer": round(ms, 4),
+                     "Msamples_per_s": round(k * n / (ms * 1e-3) / 1e6, 1),
+                     "unit_note": "input samples over all channels per second"}
+    # local compute alone (no exchange), to show the exchange cost separately
+    for _ in range(warmup):
+        if chans:
+            ctx.beamform(out, chans, my_w)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if chans:
+            ctx.beamform(out, chans, my_w)
+    torch.cuda.synchronize()
+    res["local_partial_ms"] = round((time.perf_counter() - t0) / steps * 1e3, 4)
+    return res

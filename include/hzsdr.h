@@ -1,0 +1,310 @@
+/*
+ * hzsdr.h -- C ABI of libhzsdr_hip: the MI355X (gfx950) backend for the
+ * hz.tools/sdr sample-processing hot path.
+ *
+ * This is the boundary a cgo package binds (INTEGRATION.md shows the Go side).
+ * Plain C: pointers, sizes, ints.  Every entry point returns an hzsdr_status
+ * (0 = OK) unless it says otherwise.  Each declaration cites the reference
+ * interface (file:line under the go-sdr checkout) it replaces.
+ *
+ * Conventions
+ *   - Lengths and counts are in IQ SAMPLES, never bytes (reader.go:40-43).
+ *   - Sample memory layouts are the reference's: u8/i8 = interleaved I,Q bytes
+ *     (iq_u8.go:35, iq_i8.go:31); i16 = native-endian int16 pairs (iq_i16.go:50);
+ *     c64 = interleaved float32 re,im (iq_c64.go:38).
+ *   - A context is bound to one GPU and one hipStream.  Its memory space says
+ *     what the sample pointers passed through it are: HZSDR_MEM_HOST (ordinary
+ *     process memory, e.g. Go slices: the call stages H2D, runs the kernel,
+ *     stages D2H and returns when the result is in `dst`; the library keeps no
+ *     pointer after return, as cgo requires) or HZSDR_MEM_DEVICE (HIP device
+ *     pointers: the call only enqueues on the context's stream).
+ *   - Arguments are validated on the host before the GPU is touched, so the
+ *     reference's error known-answer tests hold without running a kernel.
+ *   - Entry points may be called from any OS thread (the device is re-selected
+ *     inside every call); one context must not be used by two threads at once,
+ *     matching the reference's single-consumer Readers (pipe.go:112).
+ *   - There is no CPU fallback: without a gfx950 device hzsdr_open fails with
+ *     HZSDR_ERR_NO_DEVICE.
+ */
+#ifndef HZSDR_H
+#define HZSDR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* sdr.SampleFormat values, iq.go:110-126 */
+#define HZSDR_FMT_C64 1
+#define HZSDR_FMT_U8 2
+#define HZSDR_FMT_I16 3
+#define HZSDR_FMT_I8 4
+
+/* Status codes.  The first four map 1:1 onto the reference's sentinel errors. */
+#define HZSDR_OK 0
+#define HZSDR_ERR_FORMAT_MISMATCH 1          /* sdr.ErrSampleFormatMismatch, iq.go:30 */
+#define HZSDR_ERR_FORMAT_UNKNOWN 2           /* sdr.ErrSampleFormatUnknown,  iq.go:34 */
+#define HZSDR_ERR_DST_TOO_SMALL 3            /* sdr.ErrDstTooSmall,          iq.go:38 */
+#define HZSDR_ERR_CONVERSION_NOT_IMPLEMENTED 4 /* sdr.ErrConversionNotImplemented, conv.go:30 */
+#define HZSDR_ERR_LENGTH_MISMATCH 5          /* the fmt.Errorf length errors: add.go:34, fft/convolution.go:38,157 */
+#define HZSDR_ERR_INVALID_ARGUMENT 6
+#define HZSDR_ERR_NO_DEVICE 7                /* no gfx950 GPU / HIP runtime unusable */
+#define HZSDR_ERR_HIP 8                      /* a HIP call failed; see hzsdr_last_error */
+#define HZSDR_ERR_OUT_OF_MEMORY 9
+
+#define HZSDR_MEM_HOST 0
+#define HZSDR_MEM_DEVICE 1
+
+typedef struct hzsdr_ctx hzsdr_ctx;
+typedef struct hzsdr_lut hzsdr_lut;
+typedef struct hzsdr_rotlut hzsdr_rotlut;
+typedef struct hzsdr_nco hzsdr_nco;
+typedef struct hzsdr_fft hzsdr_fft;
+typedef struct hzsdr_conv hzsdr_conv;
+typedef struct hzsdr_chain hzsdr_chain;
+
+/* ---- library / context -------------------------------------------------- */
+
+/* "hip:gfx950": the string a simd.Backends-style report lists
+ * (internal/simd/simd.go:29, debug/build.go:69-72).  Returns a static string. */
+const char *hzsdr_backend(void);
+const char *hzsdr_version(void);
+/* Static text for a status code (rtl/error.go:29-36 rvToErr analogue). */
+const char *hzsdr_strerror(int status);
+/* SampleFormat.Size(), iq.go:93-106: bytes per IQ sample, 0 if unknown. */
+int hzsdr_format_size(int format);
+/* Number of usable gfx950 devices (the CPUID gate of
+ * internal/simd/enabled_amd64.go:35-55 becomes an arch check). */
+int hzsdr_device_count(int *count);
+
+int hzsdr_open(int device, int memspace, hzsdr_ctx **out);
+int hzsdr_close(hzsdr_ctx *ctx);
+/* Detail of the last failure on this context ("" if none). */
+const char *hzsdr_last_error(const hzsdr_ctx *ctx);
+int hzsdr_memspace(const hzsdr_ctx *ctx);
+/* Adopt the caller's hipStream_t (e.g. the stream a host framework already
+ * orders its work on); NULL restores the context's own stream. */
+int hzsdr_set_stream(hzsdr_ctx *ctx, void *hip_stream);
+void *hzsdr_get_stream(const hzsdr_ctx *ctx);
+/* Block until everything enqueued on the context's stream has finished. */
+int hzsdr_synchronize(hzsdr_ctx *ctx);
+
+/* C-owned buffers for Go to wrap with yikes.Samples (yikes/bytes.go:50-71) or
+ * to hand out from RingBufferOptions.IQBufferAllocator (stream/ring.go:60-68). */
+int hzsdr_malloc_device(hzsdr_ctx *ctx, size_t bytes, void **out);
+int hzsdr_free_device(hzsdr_ctx *ctx, void *ptr);
+int hzsdr_malloc_pinned(hzsdr_ctx *ctx, size_t bytes, void **out);
+int hzsdr_free_pinned(hzsdr_ctx *ctx, void *ptr);
+/* Stream-ordered copies between host and device memory. */
+int hzsdr_memcpy_h2d(hzsdr_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
+int hzsdr_memcpy_d2h(hzsdr_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+
+/* ---- format converters ---------------------------------- */
+
+/* sdr.ConvertBuffer(dst, src), conv.go:55-93; the twelve converters
+ * iq_u8.go:75-121, iq_i8.go:71-119, iq_i16.go:116-162, iq_c64.go:77-117 and
+ * the native kernels iq_u8_amd64.s:27-90 / iq_u8_amd64.go:26-38.  Equal
+ * formats copy min(dst_len, src_len) samples (CopySamples, copy.go:31-52).
+ * *n_out = samples written.  Errors: DST_TOO_SMALL, FORMAT_UNKNOWN. */
+int hzsdr_convert(hzsdr_ctx *ctx, int dst_format, void *dst, size_t dst_len, int src_format,
+                  const void *src, size_t src_len, size_t *n_out);
+/* SamplesI16.ShiftLSBToMSBBits(bits), iq_i16.go:103-111; in place. */
+int hzsdr_i16_shift_lsb_to_msb(hzsdr_ctx *ctx, void *buf_i16, size_t n, int bits);
+
+/* ---- LookupTable -------------------------------------------- */
+
+/* sdr.NewLookupTable(inputFormat, lookup), iq_lookup_table.go:98-123.  `table`
+ * holds exactly 65536 samples of dst_format, indexed by the raw little-endian
+ * uint16 of the two source bytes (iq_lookup_table.go:56-64); it is copied. */
+int hzsdr_lut_create(hzsdr_ctx *ctx, int src_format, int dst_format, const void *table,
+                     size_t table_len, hzsdr_lut **out);
+/* LookupTable.Lookup(dst, src), iq_lookup_table.go:129-150 and the gather
+ * loops :177-251.  src may alias dst when the formats have equal size. */
+int hzsdr_lut_lookup(hzsdr_lut *lut, int dst_format, void *dst, size_t dst_len, int src_format,
+                     const void *src, size_t src_len, size_t *n_out);
+int hzsdr_lut_free(hzsdr_lut *lut);
+/* LookupTableIdentityU8 / I8, iq_lookup_table.go:69-90: fills 65536 samples
+ * (2 bytes each) of HOST memory; pure host helper. */
+int hzsdr_lut_identity(void *table_host_131072_bytes);
+
+/* ---- c64 vector ops -------------------------------- */
+
+/* simd.ScaleComplex / SamplesC64.Scale / stream.Gain.Scale:
+ * internal/simd/mult.go:40, mult_simd_amd64.s:27-55, iq_c64.go:122,
+ * stream/gain.go:39-48.  In place. */
+int hzsdr_scale(hzsdr_ctx *ctx, void *buf_c64, size_t n, float r);
+/* simd.RotateComplex / SamplesC64.Multiply: internal/simd/mult.go:29-33,45,
+ * iq_c64.go:128.  In place; Go complex64 multiply semantics. */
+int hzsdr_rotate(hzsdr_ctx *ctx, void *buf_c64, size_t n, float re, float im);
+/* simd.AddComplex(a, b, c), internal/simd/add.go:33, add_simd_amd64.s:27-71,
+ * iq_c64.go:134.  c may alias a or b.  LENGTH_MISMATCH unless na == nb == nc. */
+int hzsdr_add(hzsdr_ctx *ctx, const void *a, size_t na, const void *b, size_t nb, void *c,
+              size_t nc);
+/* The data path of addReader.Read, stream/add.go:121-185: out = 0, then
+ * out += bufs[k] for k = 0..count-1 in that order (c64 float adds; i16 / i8
+ * wrapping adds, stream/add.go:95-119).  u8 -> FORMAT_UNKNOWN (stream/add.go:55-61). */
+int hzsdr_sum(hzsdr_ctx *ctx, int format, void *out, const void *const *bufs, int count, size_t n);
+
+/* ---- stream.Multiply on u8 / i8 ---------------------------- */
+
+/* uint8MultiplyReader / int8MultiplyReader, stream/multiply.go:91-238: a
+ * table built by identity -> c64 -> Multiply(m) -> back, rebuilt by
+ * SetMultiplier; the u8 variant keeps the reference's private I*255+Q index
+ * (stream/multiply.go:106-108) including its aliasing.  format = U8 or I8. */
+int hzsdr_rotlut_create(hzsdr_ctx *ctx, int format, float re, float im, hzsdr_rotlut **out);
+int hzsdr_rotlut_set_multiplier(hzsdr_rotlut *t, float re, float im);
+/* In place over n samples (stream/multiply.go:118-140, :186-205). */
+int hzsdr_rotlut_apply(hzsdr_rotlut *t, void *buf, size_t n);
+int hzsdr_rotlut_free(hzsdr_rotlut *t);
+
+/* ---- stream.ShiftBuffer NCO -------------------------------- */
+
+/* stream.ShiftBuffer(sampleRate), stream/shifter.go:66-85: the returned
+ * closure becomes an object whose float64 time `ts` persists across buffers. */
+int hzsdr_nco_create(hzsdr_ctx *ctx, uint64_t sample_rate, hzsdr_nco **out);
+/* The closure call fn(freq, buf): buf[j] *= exp(i * (2*pi*freq) * ts_j), in
+ * place, advancing ts by n samples. */
+int hzsdr_nco_shift(hzsdr_nco *nco, double shift_hz, void *buf_c64, size_t n);
+int hzsdr_nco_get_time(const hzsdr_nco *nco, double *ts);
+int hzsdr_nco_set_time(hzsdr_nco *nco, double ts);
+int hzsdr_nco_free(hzsdr_nco *nco);
+
+/* One run of the NCO time sequence that is exactly linear:
+ * ts[first + i] = t0 + i * step for 0 <= i < count (float64, exact). */
+typedef struct hzsdr_nco_segment {
+    uint64_t first;
+    uint64_t count;
+    double t0;
+    double step;
+} hzsdr_nco_segment;
+/* Pure host helper (no GPU): the piecewise-linear description of the next n
+ * values of `ts += 1/rate; if ts > 2pi { ts -= 2pi }` (stream/shifter.go:76-79)
+ * starting from ts_start.  Writes at most cap segments; *n_segments is the
+ * number needed; *ts_end the state after n samples. */
+int hzsdr_nco_segments(uint64_t sample_rate, double ts_start, uint64_t n,
+                       hzsdr_nco_segment *segments, size_t cap, size_t *n_segments,
+                       double *ts_end);
+
+/* ---- Decimate / Downsample ---------------------------- */
+
+/* stream.DecimateBuffer(to, from, factor, offset), stream/decimate.go:59-101:
+ * to[i] = from[factor*i]; u8 / i16 / c64 only; `offset` is accepted and
+ * ignored exactly as the reference does. */
+int hzsdr_decimate(hzsdr_ctx *ctx, int to_format, void *to, size_t to_len, int from_format,
+                   const void *from, size_t from_len, unsigned factor, int64_t offset,
+                   size_t *n_out);
+/* stream.DownsampleBuffer(to, from, factor, offset), stream/downsample.go:68-127:
+ * boxcar mean of `factor` samples converted to c64, accumulated in order. */
+int hzsdr_downsample(hzsdr_ctx *ctx, int to_format, void *to, size_t to_len, int from_format,
+                     const void *from, size_t from_len, unsigned factor, int64_t offset,
+                     size_t *n_out);
+
+/* ---- fft.Planner / fft.Plan and the convolve helpers --- */
+
+#define HZSDR_FFT_BACKWARD 0 /* fft.Backward = false, fft/fft.go:36 */
+#define HZSDR_FFT_FORWARD 1  /* fft.Forward  = true,  fft/fft.go:33 */
+
+/* fft.Planner(iq, frequency, direction), fft/fft.go:45-48: binds the two
+ * buffers for the life of the plan.  iq_len != freq_len -> DST_TOO_SMALL
+ * (testutils/fft.go:127-137).  Forward = exp(-j 2 pi k n / N), natural bin
+ * order, backward unnormalised.  Lengths must be a power of two. */
+int hzsdr_fft_plan(hzsdr_ctx *ctx, void *iq_c64, size_t iq_len, void *freq_c64, size_t freq_len,
+                   int direction, hzsdr_fft **out);
+/* `batch` independent transforms over consecutive length-n blocks of both buffers. */
+int hzsdr_fft_plan_batch(hzsdr_ctx *ctx, void *iq_c64, void *freq_c64, size_t n, size_t batch,
+                         int direction, hzsdr_fft **out);
+/* Plan.Transform(), fft/fft.go:52-55. */
+int hzsdr_fft_transform(hzsdr_fft *plan);
+/* Plan.Close(), fft/fft.go:57-58. */
+int hzsdr_fft_free(hzsdr_fft *plan);
+
+#define HZSDR_CONV_CONVOLVE 0        /* fft.Convolve,       fft/convolution.go:97-113 */
+#define HZSDR_CONV_CROSS_CORRELATE 1 /* fft.CrossCorrelate, fft/convolution.go:119-138 */
+/* fft.Convolve / fft.CrossCorrelate: returns the "func() error" closure as an
+ * object.  dst may alias iq1 / iq2.  LENGTH_MISMATCH unless all equal. */
+int hzsdr_convolve_create(hzsdr_ctx *ctx, void *dst, size_t dst_len, const void *iq1,
+                          size_t iq1_len, const void *iq2, size_t iq2_len, int mode,
+                          hzsdr_conv **out);
+/* fft.ConvolveFreq(planner, dst, src, freq), fft/convolution.go:150-192; `freq`
+ * (frequency-domain filter, n bins) is copied at creation. */
+int hzsdr_convolve_freq_create(hzsdr_ctx *ctx, void *dst, size_t dst_len, const void *src,
+                               size_t src_len, const void *freq, size_t freq_len,
+                               hzsdr_conv **out);
+/* Calls the closure once: forward transform(s), pointwise multiply with Go
+ * complex64 semantics (fft/convolution.go:107-109, :187-189), backward. */
+int hzsdr_conv_exec(hzsdr_conv *conv);
+int hzsdr_conv_free(hzsdr_conv *conv);
+/* The whole-buffer form of stream.ConvolutionReader, stream/convolution.go:36-82:
+ * block-circular filtering of consecutive len(filter)-sample blocks; a
+ * trailing partial block is not produced.  *n_out = blocks * filter_len. */
+int hzsdr_convolution_blocks(hzsdr_ctx *ctx, void *out, size_t out_len, const void *in,
+                             size_t in_len, const void *filter_freq, size_t filter_len,
+                             size_t *n_out);
+
+/* ---- Beamform ---------------------------------------------- */
+
+/* stream.BeamformAngles2D / BeamformAngles, stream/beamform.go:57-128.  Pure
+ * host float64 math; writes n complex64 values (re, im pairs). */
+int hzsdr_beamform_angles_2d(double frequency_hz, double angle_deg, const double center[2],
+                             const double *antennas_xy, int n, float *out_c64);
+int hzsdr_beamform_angles(double frequency_hz, double angle_deg, const double *distances, int n,
+                          float *out_c64);
+/* The data path of stream.ReadBeamform, stream/beamform.go:148-171:
+ * out = ((0 + w0*x0) + w1*x1) + ...; per channel ConvertReader -> c64
+ * (`format` is the channels' format), multiplyReader (skipped when w == 1,
+ * stream/multiply.go:59-62), then the ordered sum of stream/add.go:115-119.
+ * weights: count complex64 values in HOST memory, passed by value per call
+ * (Beamform.SetPhaseAngles, stream/beamform.go:131-139, applies between reads). */
+int hzsdr_beamform(hzsdr_ctx *ctx, void *out_c64, int format, const void *const *channels,
+                   const float *weights_c64, int count, size_t n);
+/* Partial sum for sharding channels over GPUs: as hzsdr_beamform
+ * but accumulating onto the current contents of out_c64 when accumulate != 0,
+ * so rank r continues the ordered sum that ranks < r started. */
+int hzsdr_beamform_partial(hzsdr_ctx *ctx, void *out_c64, int format,
+                           const void *const *channels, const float *weights_c64, int count,
+                           size_t n, int accumulate);
+
+/* ---- fused operator chains (north_star: one kernel per buffer) ----------- */
+
+/* A chain is the GPU form of nested stream.* Readers over one source
+ * (stream/read_transformer.go:92-116 Proc is the per-buffer hook it plugs in
+ * at).  Stages are pushed in data-flow order; elementwise stages (convert to
+ * c64, shift, gain, rotate) and at most one terminal stage fuse into a single
+ * kernel launch per hzsdr_chain_run. */
+int hzsdr_chain_create(hzsdr_ctx *ctx, int src_format, uint64_t sample_rate, hzsdr_chain **out);
+/* stream.ShiftReader(r, shift), stream/shifter.go:89-102 (stateful NCO). */
+int hzsdr_chain_shift(hzsdr_chain *c, double shift_hz);
+/* stream.Gain(r, v), stream/gain.go:30-57. */
+int hzsdr_chain_gain(hzsdr_chain *c, float r);
+/* stream.Multiply(r, m) on c64, stream/multiply.go:27-89 (skipped when m == 1). */
+int hzsdr_chain_rotate(hzsdr_chain *c, float re, float im);
+/* Terminal: stream.DecimateReader(r, factor), stream/decimate.go:34-55
+ * (32 Ki-sample blocks, phase restarts per block as in the reference). */
+int hzsdr_chain_decimate(hzsdr_chain *c, unsigned factor);
+/* Terminal: stream.DownsampleReader(r, factor), stream/downsample.go:47-64. */
+int hzsdr_chain_downsample(hzsdr_chain *c, unsigned factor);
+/* Terminal: stream.ConvolutionReader(r, planner, filter), stream/convolution.go:36-82,
+ * optionally followed by DecimateReader(factor) (factor 1 = none). */
+int hzsdr_chain_convolution(hzsdr_chain *c, const void *filter_freq, size_t filter_len,
+                            unsigned decimate_factor);
+/* Terminal: the north-star FIR-decimate (BASELINE.json north_star; not a
+ * reference function): y[m] = sum_k taps[k] * x[factor*m - k] by overlap-save,
+ * history carried across runs.  taps: n_taps complex64 in HOST memory. */
+int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps_c64, size_t n_taps,
+                             unsigned factor);
+/* Samples the chain would produce for n_in input samples, and how many input
+ * samples it consumes (whole blocks only for block-structured terminals). */
+int hzsdr_chain_plan(const hzsdr_chain *c, size_t n_in, size_t *n_consumed, size_t *n_out);
+/* One buffer through the chain.  out format: c64. */
+int hzsdr_chain_run(hzsdr_chain *c, const void *in, size_t n_in, void *out, size_t out_cap,
+                    size_t *n_consumed, size_t *n_out);
+/* Forget stream state (NCO time, FIR history). */
+int hzsdr_chain_reset(hzsdr_chain *c);
+int hzsdr_chain_free(hzsdr_chain *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HZSDR_H */

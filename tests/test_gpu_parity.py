@@ -1,0 +1,696 @@
+"""GPU parity: every entry point of the C ABI against the CPU oracle on the same
+seeded inputs, in both memory spaces (HOST = numpy through staging, DEVICE =
+torch CUDA tensors on torch's current stream).
+
+Bars (BASELINE.json north_star): bit-exact for integer / LUT / single-rounding
+float paths; <= 1 ULP for complex64 ops whose only freedom is float64 sincos
+(here the GPU runs the same restated math.Sincos as the oracle, so those are
+checked bit-exact too); FFT-based ops against an error bound, written in each
+test, because the reference has no FFT of its own to be identical to."""
+import importlib
+import math
+
+import numpy as np
+import pytest
+
+from util import (bits_equal, filled, in_epsilon, rand_c64, rand_i16, rand_i8, rand_u8, samples,
+                  ulp_diff, zeros)
+
+pytestmark = pytest.mark.gpu
+
+FMTS = {"c64": 1, "u8": 2, "i16": 3, "i8": 4}
+
+
+@pytest.fixture(scope="module")
+def hz():
+    return importlib.import_module("go-sdr_amd")
+
+
+class Env:
+    """One memory space: moves numpy buffers in and out of it."""
+
+    def __init__(self, hz, kind):
+        import torch
+        self.hz, self.kind, self.torch = hz, kind, torch
+        if kind == "host":
+            self.ctx = hz.Context(0, hz.MEM_HOST)
+        else:
+            self.ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+
+    def put(self, a):
+        if self.kind == "host":
+            return np.ascontiguousarray(a).copy()
+        return self.torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def get(self, x):
+        if self.kind == "host":
+            return x
+        self.ctx.synchronize()
+        return x.cpu().numpy()
+
+    def zeros(self, fmt, n):
+        return self.put(zeros(fmt, n))
+
+
+@pytest.fixture(scope="module", params=["host", "device"])
+def env(request, hz):
+    e = Env(hz, request.param)
+    yield e
+    e.ctx.close()
+
+
+def c(pair):
+    return np.complex64(complex(pair[0], pair[1]))
+
+
+# ---- converters ----------------------------------------------------------------------
+
+ALL_PAIRS = [(s, d) for s in FMTS for d in FMTS if s != d]
+
+
+def _exhaustive(fmt):
+    allb = np.arange(65536, dtype=np.uint32)
+    if fmt == "u8":
+        return np.stack([(allb & 255), (allb >> 8)], 1).astype(np.uint8)
+    if fmt == "i8":
+        return np.stack([(allb & 255), (allb >> 8)], 1).astype(np.uint8).view(np.int8)
+    if fmt == "i16":
+        v = allb.astype(np.uint16).view(np.int16)
+        return np.stack([v, v[::-1]], 1).copy()
+    x = rand_c64(11, 65536)
+    x[:8] = samples("c64", [[1, -1], [0, 0], [-0.0, 0.5], [1e12, -1e12], [float("nan"), float("inf")],
+                             [-3, 3], [0.999999, -0.999999], [2.0, -2.0]])
+    return x
+
+
+@pytest.mark.parametrize("src_fmt,dst_fmt", ALL_PAIRS)
+def test_convert_exhaustive_bit_exact(env, orc, src_fmt, dst_fmt):
+    """All 65 536 (I,Q) byte pairs / all int16 values / float edge cases."""
+    src = _exhaustive(src_fmt)
+    want = zeros(dst_fmt, len(src))
+    assert orc.convert(want, src) == len(src)
+    dst = env.zeros(dst_fmt, len(src))
+    assert env.ctx.convert(dst, env.put(src)) == len(src)
+    assert bits_equal(env.get(dst), want)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 8, 9, 31, 255, 1000, 4097, 70001])
+def test_convert_ragged_lengths(env, orc, n):
+    src = rand_u8(n + 1, n)
+    want, dst = zeros("c64", n), env.zeros("c64", n)
+    orc.convert(want, src)
+    assert env.ctx.convert(dst, env.put(src)) == n
+    assert bits_equal(env.get(dst), want)
+    src = rand_c64(n + 2, n)
+    want, dst = zeros("i16", n), env.zeros("i16", n)
+    orc.convert(want, src)
+    assert env.ctx.convert(dst, env.put(src)) == n
+    assert bits_equal(env.get(dst), want)
+
+
+def test_convert_kats(env, kats):
+    for k in kats["convert"]:
+        src = samples(k["src_fmt"], k["src"])
+        dst = env.zeros(k["dst_fmt"], len(src))
+        assert env.ctx.convert(dst, env.put(src)) == len(src)
+        got, exp = env.get(dst), samples(k["dst_fmt"], k["dst"])
+        if "eps" in k:
+            g, w = got.view(np.float32).astype(np.float64), exp.view(np.float32).astype(np.float64)
+            if k.get("plus_one"):
+                g, w = g + 1, w + 1
+            assert in_epsilon(w, g, k["eps"]), k["cite"]
+        else:
+            assert bits_equal(got, exp), k["cite"]
+
+
+def test_convert_subslice_guard(env, kats):
+    """iq_u8_test.go:65-85: converting [32:69] must leave the guards untouched."""
+    k = kats["convert_subslice_guard"]
+    lo, hi = k["lo"], k["hi"]
+    src, dst = env.put(filled("u8", k["n"], k["fill"])), env.zeros("c64", k["n"])
+    assert env.ctx.convert(dst[lo:hi], src[lo:hi]) == hi - lo
+    got = env.get(dst)
+    assert np.all(got[:lo] == 0) and np.all(got[hi:] == 0)
+    assert in_epsilon(1.0, got[lo:hi].real, k["eps"]) and in_epsilon(1.0, got[lo:hi].imag, k["eps"])
+    # odd offsets: only sample-aligned pointers
+    for lo, hi in ((1, 1000), (3, 4), (5, 5), (7, 1024)):
+        dst = env.zeros("c64", k["n"])
+        env.ctx.convert(dst[lo:hi], src[lo:hi])
+        got = env.get(dst)
+        assert np.all(got[:lo] == 0) and np.all(got[hi:] == 0) and np.all(got[lo:hi] == got[lo:lo + 1])
+
+
+def test_convert_errors(env):
+    hz = env.hz
+    with pytest.raises(hz.ErrDstTooSmall):  # iq_u8.go:104-106
+        env.ctx.convert(env.zeros("c64", 4), env.zeros("u8", 8))
+    with pytest.raises(hz.ErrSampleFormatUnknown):
+        env.ctx.convert_raw(9, env.zeros("c64", 8), 8, hz.FMT_U8, env.zeros("u8", 8), 8)
+    # same format: CopySamples copies min(len) (copy.go:31-52)
+    src = env.put(rand_u8(1, 8))
+    d = env.zeros("u8", 4)
+    assert env.ctx.convert(d, src) == 4 and bits_equal(env.get(d), rand_u8(1, 8)[:4])
+    d = env.zeros("u8", 16)
+    assert env.ctx.convert(d, src) == 8 and bits_equal(env.get(d)[:8], rand_u8(1, 8))
+
+
+def test_i16_shift_lsb_to_msb(env, orc):
+    a = rand_i16(5, 1001)
+    want = a.copy()
+    orc.i16_shift_lsb_to_msb(want, 12)
+    d = env.put(a)
+    env.ctx.i16_shift_lsb_to_msb(d, 12)
+    assert bits_equal(env.get(d), want)
+
+
+# ---- c64 vector ops --------------------------------------------------------------------
+
+def test_scale_rotate_add_kats(env, kats):
+    k = kats["scale"]
+    b = env.put(filled("c64", k["n"], k["fill"]))
+    env.ctx.scale(b, k["r"])
+    assert np.all(env.get(b) == c(k["value"]))
+    k = kats["multiply"]
+    b = env.put(filled("c64", k["n"], k["fill"]))
+    env.ctx.rotate(b, c(k["m"]))
+    assert np.all(env.get(b) == c(k["value"]))
+    k = kats["add"]
+    a, b = env.put(filled("c64", k["n"], k["a"])), env.put(filled("c64", k["n"], k["b"]))
+    env.ctx.add(a, b, a)
+    assert np.all(env.get(a) == c(k["value"])) and np.all(env.get(b) == c(k["b"]))
+    for k in kats["simd_add"]:
+        a, b = env.put(filled("c64", k["n"], k["a"])), env.put(filled("c64", k["n"], k["b"]))
+        out = a if k.get("in_place") else env.zeros("c64", k["n"])
+        env.ctx.add(a, b, out)
+        assert np.all(env.get(out) == c(k["value"]))
+    k = kats["simd_add_subslice_guard"]
+    a, b, o = (env.put(filled("c64", k["n"], k["a"])), env.put(filled("c64", k["n"], k["b"])),
+               env.zeros("c64", k["n"]))
+    env.ctx.add(a[k["lo"]:k["hi"]], b[k["lo"]:k["hi"]], o[k["lo"]:k["hi"]])
+    got = env.get(o)
+    assert np.all(got[:k["lo"]] == 0) and np.all(got[k["hi"]:] == 0)
+    assert np.all(got[k["lo"]:k["hi"]] == c(k["value"]))
+    k = kats["simd_scale_subslice_guard"]
+    b = env.put(filled("c64", k["n"], k["fill"]))
+    env.ctx.scale(b[:k["hi"]], k["r"])
+    got = env.get(b)
+    assert np.all(got[:k["hi"]] == c(k["value"])) and np.all(got[k["hi"]:] == c(k["fill"]))
+    k = kats["simd_rotate"]
+    b = env.put(filled("c64", k["n"], k["fill"]))
+    env.ctx.rotate(b, c(k["m"]))
+    assert np.all(env.get(b) == c(k["value"]))
+    with pytest.raises(env.hz.ErrLengthMismatch):
+        env.ctx.add(env.zeros("c64", 3), env.zeros("c64", 4), env.zeros("c64", 3))
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 1023, 100003])
+def test_scale_rotate_add_random_bit_exact(env, orc, n):
+    x, y = rand_c64(n, n), rand_c64(n + 7, n)
+    for off in (0, 1):  # 16-B aligned and 8-B aligned starts
+        want = x.copy()
+        orc.scale(want[off:], 0.3)
+        d = env.put(x)
+        env.ctx.scale(d[off:], 0.3)
+        assert bits_equal(env.get(d), want)
+        want = x.copy()
+        orc.rotate(want[off:], 0.70710678 + 0.25881904j)
+        d = env.put(x)
+        env.ctx.rotate(d[off:], 0.70710678 + 0.25881904j)
+        assert bits_equal(env.get(d), want)
+        want = zeros("c64", n)
+        orc.add(x[off:], y[off:], want[off:])
+        d = env.zeros("c64", n)
+        env.ctx.add(env.put(x)[off:], env.put(y)[off:], d[off:])
+        assert bits_equal(env.get(d), want)
+
+
+def test_stream_add_sum(env, orc, kats):
+    k = kats["stream_add_c64"]
+    bufs = [env.put(filled("c64", k["n"], k["fill"])) for _ in range(k["k"])]
+    out = env.put(filled("c64", k["n"], [7, 7]))
+    env.ctx.sum(out, bufs)
+    assert np.all(env.get(out) == c(k["value"]))
+    for name, fmt in (("stream_add_i8", "i8"), ("stream_add_i16", "i16")):
+        k = kats[name]
+        out = env.zeros(fmt, k["n"])
+        env.ctx.sum(out, [env.put(filled(fmt, k["n"], k["fill"])) for _ in range(k["k"])])
+        assert np.all(env.get(out) == np.asarray(k["value"]))
+    # random, 4-way, ordered float sum; wrapping integer sums; odd length
+    for fmt, gen in (("c64", rand_c64), ("i16", rand_i16), ("i8", rand_i8)):
+        n = 10007
+        src = [gen(30 + i, n) for i in range(4)]
+        want = zeros(fmt, n)
+        orc.sum_(want, src)
+        out = env.zeros(fmt, n)
+        env.ctx.sum(out, [env.put(s) for s in src])
+        assert bits_equal(env.get(out), want)
+    with pytest.raises(env.hz.ErrSampleFormatUnknown):  # stream/add.go:55-61
+        env.ctx.sum(env.zeros("u8", 4), [env.zeros("u8", 4)])
+    out = env.zeros("c64", 2)  # -0 inputs give +0
+    env.ctx.sum(out, [env.put(samples("c64", [[-0.0, -0.0], [-0.0, 1.0]]))])
+    g = env.get(out)
+    assert not np.signbit(g[0].real) and not np.signbit(g[0].imag)
+
+
+# ---- lookup tables -----------------------------------------------------------------------
+
+@pytest.mark.parametrize("dst_fmt", ["u8", "i8", "i16", "c64"])
+@pytest.mark.parametrize("src_fmt", ["u8", "i8"])
+def test_lookup_table(env, orc, src_fmt, dst_fmt):
+    ident = orc.lut_identity()
+    tab = zeros(dst_fmt, 65536)
+    if dst_fmt == src_fmt:
+        tab = ident.view(tab.dtype).copy()
+    else:
+        orc.convert(tab, ident.view(np.int8) if src_fmt == "i8" else ident)
+    n = 50001
+    src = rand_u8(9, n) if src_fmt == "u8" else rand_i8(9, n)
+    want = zeros(dst_fmt, n)
+    assert orc.lut_apply(want, tab, src.view(np.uint8)) == n
+    lut = env.ctx.lut(FMTS[src_fmt], env.put(tab))
+    dst = env.zeros(dst_fmt, n)
+    assert lut.lookup(dst, env.put(src)) == n
+    assert bits_equal(env.get(dst), want)
+    assert lut.source_sample_format() == FMTS[src_fmt] and lut.destination_sample_format() == FMTS[dst_fmt]
+    with pytest.raises(env.hz.ErrDstTooSmall):
+        lut.lookup(env.zeros(dst_fmt, 10), env.put(src))
+    other = "i16" if dst_fmt != "i16" else "c64"
+    with pytest.raises(env.hz.ErrSampleFormatMismatch):
+        lut.lookup(env.zeros(other, n), env.put(src))
+    lut.close()
+
+
+def test_lookup_table_create_errors(env):
+    with pytest.raises(env.hz.HzsdrError):
+        env.ctx.lut(env.hz.FMT_U8, env.zeros("u8", 100))  # must be 65536 samples
+    with pytest.raises(env.hz.ErrSampleFormatUnknown):
+        env.ctx.lut(env.hz.FMT_C64, env.zeros("u8", 65536))
+
+
+def _counter_u8(n):
+    i = np.arange(n, dtype=np.uint32) & 0xFFFF
+    return np.stack([i & 0xFF, (i & 0xFF00) >> 8], 1).astype(np.uint8)
+
+
+def test_rotate_lut_u8(env, orc, kats):
+    """stream/multiply_test.go:71-112 + the I*255+Q aliasing quirk."""
+    k = kats["rotate_lut_u8"]
+    vals = _counter_u8(k["n"])
+    for m in (c(k["m"]), np.complex64(0.6 + 0.3j), np.complex64(1.7 - 0.2j)):
+        want = vals.copy()
+        orc.rotate_u8_apply(orc.rotate_table_u8(m), want)
+        t = env.ctx.rotlut(env.hz.FMT_U8, m)
+        buf = env.put(vals)
+        t.apply(buf)
+        assert bits_equal(env.get(buf), want)
+        t.close()
+    # the KAT proper: equals convert -> multiply -> convert done with the GPU ops
+    m = c(k["m"])
+    cbuf, ref = env.zeros("c64", k["n"]), env.zeros("u8", k["n"])
+    env.ctx.convert(cbuf, env.put(vals))
+    env.ctx.rotate(cbuf, m)
+    env.ctx.convert(ref, cbuf)
+    t = env.ctx.rotlut(env.hz.FMT_U8, 1)
+    t.set_multiplier(m)  # SetMultiplier rebuilds the table
+    buf = env.put(vals)
+    t.apply(buf)
+    assert bits_equal(env.get(buf), env.get(ref))
+    a = env.put(samples("u8", [[3, 255], [4, 0]]))
+    t.set_multiplier(1)
+    t.apply(a)
+    g = env.get(a)
+    assert g[0].tolist() == g[1].tolist() == [4, 0]
+    t.close()
+
+
+def test_rotate_lut_i8(env, orc, kats):
+    k = kats["rotate_lut_i8"]
+    i = np.arange(k["n"], dtype=np.int64) & 0xFFFF
+    vals = np.stack([(i & 0xFF), ((i & 0xFF00) >> 8) - 127], 1).astype(np.int8)
+    for m in (c(k["m"]), np.complex64(-0.4 + 0.9j)):
+        want = zeros("i8", k["n"])
+        orc.lut_apply(want, orc.rotate_table_i8(m), vals.view(np.uint8))
+        t = env.ctx.rotlut(env.hz.FMT_I8, m)
+        buf = env.put(vals)
+        t.apply(buf)
+        assert bits_equal(env.get(buf), want)
+        t.close()
+
+
+# ---- NCO / Shift ---------------------------------------------------------------------------
+
+@pytest.mark.parametrize("rate,shift,n", [
+    (20_000_000, 2.5e6, 300_000), (1_800_000, 1000.0, 61_440), (200_000_000, -70e6, 200_000),
+    (1000, 123.0, 50_000), (48_000, -7000.5, 100_001)])
+def test_shift_bit_exact_and_state_carries(env, orc, rate, shift, n):
+    """The GPU runs the same restated math.Sincos as the oracle on an exactly
+    reproduced clock, so the <= 1 ULP bar is met with 0 ULP."""
+    x = rand_c64(2, n)
+    want = x.copy()
+    ref = orc.Shifter(rate)
+    nco = env.ctx.nco(rate)
+    d = env.put(x)
+    cuts = [0, n // 3 + 1, n // 2, n]  # three buffers, odd boundaries
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        ref(shift, want[lo:hi])
+        nco(shift, d[lo:hi])
+        assert nco.ts == ref.ts.value
+    got = env.get(d)
+    assert ulp_diff(got, want).max() <= 1
+    assert bits_equal(got, want)
+    nco.close()
+
+
+def test_shift_large_phase_uses_payne_hanek(env, orc):
+    """2*pi*shift*ts beyond 2^29 rad takes trigReduce (src/math/trig_reduce.go)."""
+    n, rate, shift = 100_000, 200_000_000, 95e6
+    x = rand_c64(4, n)
+    want = x.copy()
+    ref = orc.Shifter(rate)
+    ref.ts.value = 5.0  # phase ~ 3e9 rad
+    ref(shift, want)
+    nco = env.ctx.nco(rate)
+    nco.ts = 5.0
+    d = env.put(x)
+    nco(shift, d)
+    assert bits_equal(env.get(d), want)
+    # and stays within 1 ULP of an independent libm evaluation
+    lib = x.copy()
+    ref2 = orc.Shifter(rate, use_libm=True)
+    ref2.ts.value = 5.0
+    ref2(shift, lib)
+    assert ulp_diff(env.get(d), lib).max() <= 1
+    nco.close()
+
+
+def test_shift_roundtrip_kat(env, orc, kats):
+    k = kats["shift_roundtrip"]
+    cw = orc.cw(k["n"], k["freq"], k["rate"], 0.0)
+    d = env.put(cw)
+    hi, lo = env.ctx.nco(k["rate"]), env.ctx.nco(k["rate"])
+    hi(k["shift"], d)
+    lo(-k["shift"], d)
+    got = env.get(d)
+    assert in_epsilon(1 + cw.real, 1 + got.real, k["eps"]) and in_epsilon(1 + cw.imag, 1 + got.imag, k["eps"])
+
+
+# ---- decimate / downsample -------------------------------------------------------------------
+
+def test_decimate(env, orc, kats):
+    hz = env.hz
+    k = kats["decimate_count"]
+    for fmt in k["formats"]:
+        assert env.ctx.decimate(env.zeros(fmt, k["n"]), env.zeros(fmt, k["n"]), k["factor"]) == k["count"]
+    k = kats["decimate_skippy"]
+    i = (np.arange(k["n"]) % 10).astype(np.uint8)
+    dst = env.put(filled("u8", k["count"], [9, 9]))
+    assert env.ctx.decimate(dst, env.put(np.stack([i, i], 1)), k["factor"]) == k["count"]
+    assert np.all(env.get(dst) == 0)
+    with pytest.raises(hz.ErrSampleFormatMismatch):
+        env.ctx.decimate(env.zeros("u8", 32768), env.zeros("c64", 32768), 10)
+    with pytest.raises(hz.ErrDstTooSmall):
+        env.ctx.decimate(env.zeros("u8", 10), env.zeros("u8", 32768), 10)
+    with pytest.raises(hz.ErrSampleFormatUnknown):  # no i8 case: stream/decimate.go:85-97
+        env.ctx.decimate(env.zeros("i8", 8), env.zeros("i8", 8), 2)
+    for fmt, gen in (("c64", rand_c64), ("i16", rand_i16), ("u8", rand_u8)):
+        for factor, n in ((7, 100001), (8, 65536), (1, 1000), (3, 2)):
+            x = gen(1, n)
+            want = zeros(fmt, n // factor + 3)
+            cnt = orc.decimate(want, x, factor)
+            d = env.zeros(fmt, n // factor + 3)
+            assert env.ctx.decimate(d, env.put(x), factor) == cnt
+            assert bits_equal(env.get(d), want)
+
+
+def test_downsample(env, orc, kats):
+    hz = env.hz
+    k = kats["downsample_calc"]
+    e = (np.arange(k["n"]) % 4).astype(np.float32)
+    dst = env.zeros("c64", k["n"])
+    assert env.ctx.downsample(dst, env.put((e + 1j * e).astype(np.complex64)), k["factor"]) == k["count"]
+    assert np.all(env.get(dst)[:k["count"]] == c(k["value"]))
+    for fmt, gen in (("i16", rand_i16), ("u8", rand_u8), ("c64", rand_c64)):
+        for factor, n in ((8, 8 * 4096 + 5), (4, 4 * 1000), (3, 3001), (16, 16 * 513), (1, 77), (5, 4)):
+            x = gen(4, n)
+            want = zeros("c64", n // factor + 1)
+            cnt = orc.downsample(want, x, factor)
+            d = env.zeros("c64", n // factor + 1)
+            assert env.ctx.downsample(d, env.put(x), factor) == cnt
+            assert bits_equal(env.get(d), want), (fmt, factor, n)
+    with pytest.raises(hz.ErrSampleFormatMismatch):
+        env.ctx.downsample(env.zeros("u8", 8), env.zeros("i16", 64), 8)
+    with pytest.raises(hz.ErrDstTooSmall):
+        env.ctx.downsample(env.zeros("c64", 7), env.zeros("i16", 64), 8)
+    with pytest.raises(hz.ErrSampleFormatUnknown):
+        env.ctx.downsample(env.zeros("c64", 8), env.zeros("i8", 8), 2)
+
+
+# ---- FFT / convolution -------------------------------------------------------------------------
+
+def _rel_l2(got, want):
+    want = want.astype(np.complex128)
+    return float(np.linalg.norm(got.astype(np.complex128) - want) / max(np.linalg.norm(want), 1e-30))
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536])
+def test_fft_against_float64(env, n):
+    """Tolerance: relative L2 error <= 3e-7 * log2(N) + 1e-7 against numpy's
+    float64 FFT (float32 butterflies; the reference pins no values: SURVEY 2b)."""
+    tol = 3e-7 * max(1, math.log2(n)) + 1e-7
+    batch = 3 if n <= 8192 else 1
+    x = rand_c64(n, n * batch)
+    X = np.fft.fft(x.astype(np.complex128).reshape(batch, n), axis=1).reshape(-1)
+    iq, fr = env.put(x), env.zeros("c64", n * batch)
+    p = env.ctx.fft_plan(iq, fr, env.hz.FFT_FORWARD, batch=batch)
+    p.transform()
+    assert _rel_l2(env.get(fr), X) < tol
+    p.close()
+    Y = np.fft.ifft(x.astype(np.complex128).reshape(batch, n), axis=1).reshape(-1) * n  # unnormalised
+    fr, iq = env.put(x), env.zeros("c64", n * batch)
+    p = env.ctx.fft_plan(iq, fr, env.hz.FFT_BACKWARD, batch=batch)
+    p.transform()
+    assert _rel_l2(env.get(iq), Y) < tol
+    p.close()
+
+
+def test_fft_conformance_kats(env, orc, kats):
+    """testutils/fft.go:54-138, the suite any Planner must pass."""
+    hz = env.hz
+    k = kats["fft_forward_bins"]
+    for freq, idx in k["cases"]:
+        iq, out = env.put(orc.cw(k["n"], freq, k["rate"], 0.0)), env.zeros("c64", k["n"])
+        p = env.ctx.fft_plan(iq, out, hz.FFT_FORWARD)
+        p.transform()
+        p.close()
+        assert int(np.argmax(np.abs(env.get(out).astype(np.complex128)))) == idx
+    k = kats["fft_backward_roundtrip"]
+    for b in k["bins"]:
+        f = zeros("c64", k["n"])
+        f[b] = 1 + 1j
+        fr, iq = env.put(f), env.zeros("c64", k["n"])
+        p = env.ctx.fft_plan(iq, fr, hz.FFT_BACKWARD)
+        p.transform()
+        p.close()
+        fr2 = env.zeros("c64", k["n"])
+        p = env.ctx.fft_plan(iq, fr2, hz.FFT_FORWARD)
+        p.transform()
+        p.close()
+        assert int(np.argmax(np.abs(env.get(fr2)))) == b
+    for a, b, d in kats["fft_mismatch"]["cases"]:
+        with pytest.raises(hz.ErrDstTooSmall):
+            env.ctx.fft_plan(env.zeros("c64", a), env.zeros("c64", b),
+                             hz.FFT_FORWARD if d == "forward" else hz.FFT_BACKWARD)
+
+
+def _lowpass_bins(n, taps=None):
+    t = np.arange(n) - (n - 1) / 2
+    h = np.sinc(t / 8) / 8 * np.hamming(n)
+    return np.fft.fft(h.astype(np.complex128) / n).astype(np.complex64)
+
+
+@pytest.mark.parametrize("flen", [4, 64, 1024, 2048, 8192])
+def test_convolution_blocks_reference_semantics(env, orc, flen):
+    """stream.ConvolutionReader: block-circular, no overlap; vs the oracle's
+    float64-FFT restatement.  Tolerance: relative L2 <= 2e-6."""
+    nblk = 5
+    x = rand_c64(3, nblk * flen + flen // 2)
+    H = _lowpass_bins(flen)
+    want = zeros("c64", len(x))
+    assert orc.convolution_reader(want, x, H) == nblk * flen
+    out = env.zeros("c64", len(x))
+    assert env.ctx.convolution_blocks(out, env.put(x), env.put(H)) == nblk * flen
+    got = env.get(out)
+    assert _rel_l2(got[:nblk * flen], want[:nblk * flen]) < 2e-6
+    assert np.all(got[nblk * flen:] == 0)  # the partial block is never produced
+
+
+@pytest.mark.parametrize("n", [8, 1024, 32768])
+def test_convolve_closures(env, orc, n):
+    hz = env.hz
+    a, b = rand_c64(5, n), rand_c64(6, n)
+    H = _lowpass_bins(n)
+    for kind in ("freq", "convolve", "xcorr"):
+        want = zeros("c64", n)
+        if kind == "freq":
+            orc.convolve_freq(want, a, H)
+            da, db, dd = env.put(a), env.put(H), env.zeros("c64", n)
+            cv = env.ctx.convolve_freq(dd, da, db)
+        else:
+            orc.convolve(want, a, b, conj=(kind == "xcorr"))
+            da, db, dd = env.put(a), env.put(b), env.zeros("c64", n)
+            cv = (env.ctx.convolve if kind == "convolve" else env.ctx.cross_correlate)(dd, da, db)
+        cv()
+        assert _rel_l2(env.get(dd), want) < 3e-6, kind
+        cv.close()
+    with pytest.raises(hz.ErrLengthMismatch):  # fft/convolution.go:156-158
+        env.ctx.convolve_freq(env.zeros("c64", 8), env.zeros("c64", 8), env.zeros("c64", 4))
+    with pytest.raises(hz.ErrLengthMismatch):  # fft/convolution.go:37-39
+        env.ctx.convolve(env.zeros("c64", 8), env.zeros("c64", 4), env.zeros("c64", 8))
+
+
+# ---- beamform ------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("fmt", ["c64", "u8", "i16", "i8"])
+def test_beamform_bit_exact(env, orc, fmt):
+    n = 40001
+    gen = {"c64": rand_c64, "u8": rand_u8, "i16": rand_i16, "i8": rand_i8}[fmt]
+    ch = [gen(20 + i, n) for i in range(4)]
+    w = env.hz.beamform_angles(433e6, 30.0, [0.0, 0.1, 0.2, 0.3])
+    assert w[0] == 1  # the first channel's multiply is skipped
+    chc = []
+    for x in ch:  # the per-channel ConvertReader of stream/beamform.go:151
+        y = zeros("c64", n)
+        orc.convert(y, x)
+        chc.append(y)
+    want = zeros("c64", n)
+    orc.beamform(want, chc, w)
+    out = env.zeros("c64", n)
+    dch = [env.put(x) for x in ch]
+    env.ctx.beamform(out, dch, w)
+    assert bits_equal(env.get(out), want)
+    # sharded form: ranks continue the ordered sum
+    out2 = env.zeros("c64", n)
+    env.ctx.beamform(out2, dch[:2], w[:2], accumulate=False)
+    env.ctx.beamform(out2, dch[2:], w[2:], accumulate=True)
+    assert bits_equal(env.get(out2), want)
+
+
+# ---- fused chains ----------------------------------------------------------------------------------
+
+def test_chain_convert_shift_gain_equals_separate_ops(env, orc):
+    """BASELINE config 2 shape: u8 -> c64 -> Shift -> Gain in ONE kernel must be
+    bit-identical to the three reference ops applied one after another."""
+    rate, shift, gain = 20_000_000, 2.5e6, 0.5
+    n = 150_001
+    x = rand_u8(9, n)
+    want = zeros("c64", n)
+    orc.convert(want, x)
+    ref = orc.Shifter(rate)
+    ch = env.ctx.chain(env.hz.FMT_U8, rate).shift(shift).gain(gain)
+    out = env.zeros("c64", n)
+    dx = env.put(x)
+    cuts = [0, 50_001, n]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        ref(shift, want[lo:hi])
+        orc.scale(want[lo:hi], gain)
+        cons, outn = ch.run(dx[lo:hi], out[lo:hi])
+        assert (cons, outn) == (hi - lo, hi - lo)
+    assert bits_equal(env.get(out), want)
+    ch.close()
+
+
+def test_chain_shift_roundtrip_two_ncos(env, orc, kats):
+    k = kats["shift_roundtrip"]
+    cw = orc.cw(k["n"], k["freq"], k["rate"], 0.0)
+    ch = env.ctx.chain(env.hz.FMT_C64, k["rate"]).shift(k["shift"]).shift(-k["shift"])
+    out = env.zeros("c64", k["n"])
+    ch.run(env.put(cw), out)
+    got = env.get(out)
+    assert in_epsilon(1 + cw.real, 1 + got.real, k["eps"]) and in_epsilon(1 + cw.imag, 1 + got.imag, k["eps"])
+    want = cw.copy()
+    a, b = orc.Shifter(k["rate"]), orc.Shifter(k["rate"])
+    a(k["shift"], want)
+    b(-k["shift"], want)
+    assert bits_equal(got, want)
+    ch.close()
+
+
+@pytest.mark.parametrize("factor", [8, 10])
+def test_chain_decimate_and_downsample_follow_reader_blocks(env, orc, factor):
+    """DecimateReader / DownsampleReader work in 32 Ki blocks and restart their
+    phase per block (stream/decimate.go:34-55, downsample.go:47-64)."""
+    B = 32768
+    n = 3 * B + 1234
+    x = rand_i16(4, n)
+    xc = zeros("c64", n)
+    orc.convert(xc, x)
+    orc.rotate(xc, 0.5 - 0.25j)
+    per = B // factor
+    for term in ("decimate", "downsample"):
+        want = zeros("c64", 3 * per)
+        for b in range(3):
+            fn = orc.decimate if term == "decimate" else orc.downsample
+            assert fn(want[b * per:(b + 1) * per], xc[b * B:(b + 1) * B], factor) == per
+        ch = env.ctx.chain(env.hz.FMT_I16).rotate(0.5 - 0.25j)
+        ch = ch.decimate(factor) if term == "decimate" else ch.downsample(factor)
+        assert ch.plan(n) == (3 * B, 3 * per)
+        out = env.zeros("c64", 3 * per)
+        assert ch.run(env.put(x), out) == (3 * B, 3 * per)
+        assert bits_equal(env.get(out), want), term
+        with pytest.raises(env.hz.ErrDstTooSmall):
+            ch.run(env.put(x), env.zeros("c64", 10))
+        ch.close()
+
+
+def test_chain_reference_convolution_then_decimate(env, orc):
+    """u8 -> c64 -> Shift -> ConvolutionReader(1024 bins) -> DecimateReader(8),
+    the chain spelt with the reference's own operators.  The first two stages
+    are bit-exact, so the only difference from the oracle is FFT round-off:
+    relative L2 <= 2e-6."""
+    rate, shift, flen, D = 20_000_000, -2.5e6, 1024, 8
+    n = 4 * 32768
+    x = rand_u8(9, n)
+    H = _lowpass_bins(flen)
+    xc = zeros("c64", n)
+    orc.convert(xc, x)
+    orc.Shifter(rate)(shift, xc)
+    conv = zeros("c64", n)
+    orc.convolution_reader(conv, xc, H)
+    want = zeros("c64", n // D)
+    for b in range(4):
+        orc.decimate(want[b * 4096:(b + 1) * 4096], conv[b * 32768:(b + 1) * 32768], D)
+    ch = env.ctx.chain(env.hz.FMT_U8, rate).shift(shift).convolution(env.put(H), decimate=D)
+    out = env.zeros("c64", n // D)
+    assert ch.run(env.put(x), out) == (n, n // D)
+    assert _rel_l2(env.get(out), want) < 2e-6
+    ch.close()
+
+
+@pytest.mark.parametrize("ntaps,D", [(1024, 8), (33, 4), (129, 10), (1, 1), (2048, 16)])
+def test_chain_fir_decimate_overlap_save(env, orc, ntaps, D):
+    """North-star op: y[m] = sum_k h[k] x[D m - k] with history across runs, vs
+    the oracle's float64 direct form.  Tolerance: |err| <= 4e-6 * sum|h| * max|x|
+    per output (float32 FFT round-off, N_fft <= 8192)."""
+    rate, shift = 20_000_000, -2.5e6
+    n1, n2 = 40 * D * 100, 13 * D * 100
+    x = rand_u8(9, n1 + n2)
+    k = np.arange(ntaps) - (ntaps - 1) / 2
+    taps = (np.sinc(k / 16) / 16 * np.hamming(ntaps) * np.exp(0.3j * k)).astype(np.complex64)
+    xc = zeros("c64", n1 + n2)
+    orc.convert(xc, x)
+    orc.Shifter(rate)(shift, xc)
+    want = zeros("c64", (n1 + n2) // D)
+    orc.fir_decimate_f64(want, xc, taps, D)  # zero initial history
+    ch = env.ctx.chain(env.hz.FMT_U8, rate).shift(shift).fir_decimate(taps, D)
+    out = env.zeros("c64", (n1 + n2) // D)
+    dx = env.put(x)
+    assert ch.run(dx[:n1], out[:n1 // D]) == (n1, n1 // D)
+    assert ch.run(dx[n1:], out[n1 // D:]) == (n2, n2 // D)
+    got = env.get(out)
+    bound = 4e-6 * float(np.abs(taps).sum()) * float(np.abs(xc).max())
+    assert np.abs(got.astype(np.complex128) - want.astype(np.complex128)).max() <= bound
+    ch.reset()  # forget history and NCO time: first run reproduces
+    out2 = env.zeros("c64", n1 // D)
+    ch.run(dx[:n1], out2)
+    assert np.abs(env.get(out2).astype(np.complex128) - want[:n1 // D]).max() <= bound
+    ch.close()
