@@ -223,6 +223,9 @@ class Context:
         """Adopt a hipStream_t given as an int (e.g. torch.cuda.current_stream().cuda_stream)."""
         self._ck(lib.hzsdr_set_stream(self._h, hip_stream))
 
+    def use_own_stream(self):
+        self._ck(lib.hzsdr_use_own_stream(self._h))
+
     def stream(self):
         return lib.hzsdr_get_stream(self._h)
 

@@ -47,6 +47,7 @@ SIGNATURES = {
     "hzsdr_last_error": (C.c_char_p, [vp]),
     "hzsdr_memspace": (i32, [vp]),
     "hzsdr_set_stream": (i32, [vp, vp]),
+    "hzsdr_use_own_stream": (i32, [vp]),
     "hzsdr_get_stream": (vp, [vp]),
     "hzsdr_synchronize": (i32, [vp]),
     "hzsdr_malloc_device": (i32, [vp, sz, pvp]),

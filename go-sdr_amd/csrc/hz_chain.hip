@@ -157,27 +157,78 @@ __device__ __forceinline__ void conv_store(float2 *out, size_t g, float2 v, unsi
     }
 }
 
+// Stage N post-elementwise samples of one block into LDS in natural order with a
+// ROLLED loop (two samples per lane per trip: one 16-B LDS store, the float64
+// sincos of the Shift stage instantiated twice, not N/TPT times -- the unrolled
+// register-direct form needs 256 VGPRs and drops to one wave per SIMD).
+// lds[i] = sample at stream position p0 + i; positions < 0 come from `hist`
+// (`off` entries, may be null = zeros), positions >= n_in are zero.
 template <int N, int FMT>
-__global__ __launch_bounds__(fft_block(N)) void conv_blocks_kernel(const void *in, float2 *out,
+__device__ __forceinline__ void stage_block(float2 *lds, const void *in, const EwProgram &P, int64_t p0,
+                                            size_t n_in, const float2 *hist, unsigned off, int lane,
+                                            bool live) {
+    using R = typename Raw<FMT>::t;
+    constexpr int TPT = fft_tpt(N);
+    struct alignas(sizeof(R) * 2) RV { R v[2]; };
+    // pair loads need 2*sizeof(R) alignment of in + p0 (i0 is even); mod-2 arithmetic wraps safely
+    const bool vec_ok = ((((uintptr_t)in / sizeof(R)) + (uint64_t)p0) & 1) == 0;
+#pragma unroll 1
+    for (int i0 = lane * 2; i0 < N; i0 += TPT * 2) {
+        const int64_t p = p0 + i0;
+        float2 a = make_float2(0.f, 0.f), b = a;
+        if (live) {
+            if (vec_ok && p >= 0 && (size_t)(p + 2) <= n_in) {
+                RV x = *reinterpret_cast<const RV *>((const R *)in + p);
+                a = ew_apply(P, Raw<FMT>::cvt(x.v[0]), (uint64_t)p);
+                b = ew_apply(P, Raw<FMT>::cvt(x.v[1]), (uint64_t)p + 1);
+            } else {
+                if (p < 0) { if (hist) a = hist[p + off]; }
+                else if ((size_t)p < n_in) a = chain_sample<FMT>(in, P, (uint64_t)p);
+                if (p + 1 < 0) { if (hist) b = hist[p + 1 + off]; }
+                else if ((size_t)(p + 1) < n_in) b = chain_sample<FMT>(in, P, (uint64_t)p + 1);
+            }
+        }
+        *reinterpret_cast<float4 *>(lds + i0) = make_float4(a.x, a.y, b.x, b.y);
+    }
+}
+
+// first-pass register image from staged LDS
+template <int N> __device__ __forceinline__ void load_edge_from_lds(FftRegs<N> &R, const float2 *lds, int lane) {
+    if constexpr (fft_odd(N)) r2_load_lds<N>(R, lds, lane); else r4_load_lds<N>(R, lds, lane);
+}
+
+// STAGED = the source needs the elementwise program (or a non-c64 format):
+// samples go through stage_block; otherwise c64 samples are loaded straight
+// into the first pass's registers.
+template <int N, int FMT, bool STAGED>
+__global__ __launch_bounds__(fft_block(N), fft_waves(N)) void conv_blocks_kernel(const void *in, float2 *out,
                                                                    const float2 *__restrict__ filt,
                                                                    const float2 *__restrict__ tw,
                                                                    size_t nblocks, unsigned dec,
                                                                    size_t per, EwProgram P) {
     constexpr int TPT = fft_tpt(N), XPB = fft_xpb(N), CNT = N / TPT;
-    __shared__ float2 lds_all[XPB * N];
+    __shared__ __attribute__((aligned(16))) float2 lds_all[XPB * N];
     const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
     float2 *lds = lds_all + sub * N;
-    for (size_t b0 = (size_t)blockIdx.x * XPB; b0 < nblocks; b0 += (size_t)gridDim.x * XPB) {
+    {   // one workgroup per XPB blocks, no grid-stride loop (see hz_fft.hip: LICM of twiddles)
+        const size_t b0 = (size_t)blockIdx.x * XPB;
         const size_t b = b0 + sub;
         const bool live = b < nblocks;
         FftRegs<N> R;
         __syncthreads();
+        if constexpr (STAGED) {
+            stage_block<N, FMT>(lds, in, P, (int64_t)(b * N), ~(size_t)0, nullptr, 0, lane, live);
+            __syncthreads();
+            load_edge_from_lds<N>(R, lds, lane);
+            fft_forward_regs<N, true>(R, lds, tw, lane);
+        } else {
 #pragma unroll
-        for (int q = 0; q < CNT; q++) {
-            const int idx = fft_odd(N) ? edge2_index<N>(q, lane) : edge4_index<N>(q, lane);
-            R.v[q] = live ? chain_sample<FMT>(in, P, b * N + idx) : make_float2(0.f, 0.f);
+            for (int q = 0; q < CNT; q++) {
+                const int idx = fft_odd(N) ? edge2_index<N>(q, lane) : edge4_index<N>(q, lane);
+                R.v[q] = live ? Raw<FMT>::cvt(((const typename Raw<FMT>::t *)in)[b * N + idx]) : make_float2(0.f, 0.f);
+            }
+            fft_forward_regs<N>(R, lds, tw, lane);
         }
-        fft_forward_regs<N>(R, lds, tw, lane);
 #pragma unroll
         for (int q = 0; q < CNT; q++)  // freq1[i] = freq1[i] * freq[i], fft/convolution.go:187-189
             R.v[q] = go_cmul(R.v[q], filt[edge4_index<N>(q, lane)]);
@@ -198,42 +249,72 @@ __global__ __launch_bounds__(fft_block(N)) void conv_blocks_kernel(const void *i
 // come from `hist` (the last `off` post-elementwise samples of the previous
 // run), positions >= n_in are zero.  Circular outputs at idx in [off, off+hop)
 // on the decimation grid are y[(b*hop + idx - off) / D].
-template <int N, int FMT>
-__global__ __launch_bounds__(fft_block(N)) void fir_decimate_kernel(
+// FOLD = D when the decimation folds into the spectrum (D a power of two that
+// divides the per-lane bin count): y[D i] = IFFT_{N/D}( sum_q Y[k + q N/D] )[i],
+// so the backward transform is N/D points instead of N, and the fold itself is
+// lane-local in the edge4 register image.  FOLD = 0: full backward transform,
+// outputs picked on the decimation grid.
+template <int N, int FMT, int FOLD>
+__global__ __launch_bounds__(fft_block(N), fft_waves(N)) void fir_decimate_kernel(
     const void *in, float2 *out, const float2 *__restrict__ hist, const float2 *__restrict__ hfreq,
-    const float2 *__restrict__ tw, size_t nblocks, size_t n_in, unsigned hop, unsigned off, unsigned D,
-    EwProgram P) {
-    constexpr int TPT = fft_tpt(N), XPB = fft_xpb(N), CNT = N / TPT;
-    __shared__ float2 lds_all[XPB * N];
-    const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
-    float2 *lds = lds_all + sub * N;
-    for (size_t b0 = (size_t)blockIdx.x * XPB; b0 < nblocks; b0 += (size_t)gridDim.x * XPB) {
-        const size_t b = b0 + sub;
-        const bool live = b < nblocks;
+    const float2 *__restrict__ tw, const float2 *__restrict__ tw_small, size_t nblocks, size_t n_in,
+    unsigned hop, unsigned off, unsigned D, EwProgram P) {
+    constexpr int TPT = fft_tpt(N), CNT = N / TPT;
+    static_assert(fft_xpb(N) == 1, "fir_decimate_kernel: one block per workgroup");
+    __shared__ __attribute__((aligned(16))) float2 lds[N];
+    const int lane = threadIdx.x;
+    {   // one workgroup per overlap-save block (no grid-stride loop: see hz_fft.hip)
+        const size_t b = blockIdx.x;
         FftRegs<N> R;
         __syncthreads();
-#pragma unroll
-        for (int q = 0; q < CNT; q++) {
-            const int idx = fft_odd(N) ? edge2_index<N>(q, lane) : edge4_index<N>(q, lane);
-            const int64_t p = (int64_t)(b * hop) + idx - (int64_t)off;
-            float2 v = make_float2(0.f, 0.f);
-            if (live) {
-                if (p < 0) v = hist[p + off];
-                else if ((size_t)p < n_in) v = chain_sample<FMT>(in, P, (uint64_t)p);
-            }
-            R.v[q] = v;
-        }
-        fft_forward_regs<N>(R, lds, tw, lane);
+        stage_block<N, FMT>(lds, in, P, (int64_t)(b * hop) - (int64_t)off, n_in, hist, off, lane, true);
+        __syncthreads();
+        load_edge_from_lds<N>(R, lds, lane);
+        fft_forward_regs<N, true>(R, lds, tw, lane);
 #pragma unroll
         for (int q = 0; q < CNT; q++) R.v[q] = cmulf(R.v[q], hfreq[edge4_index<N>(q, lane)]);
-        fft_backward_regs<N>(R, lds, tw, lane);
-        if (live) {
+        if constexpr (FOLD == 0) {
+            fft_backward_regs<N>(R, lds, tw, lane);
 #pragma unroll
             for (int q = 0; q < CNT; q++) {
                 const unsigned idx = fft_odd(N) ? edge2_index<N>(q, lane) : edge4_index<N>(q, lane);
                 if (idx >= off && idx < off + hop && ((idx - off) % D) == 0) {
                     const size_t p = b * hop + (idx - off);
                     if (p < n_in) out[p / D] = R.v[q];
+                }
+            }
+        } else {
+            constexpr int M = N / FOLD, S = CNT / FOLD, TPTM = fft_tpt(M), CNTM = M / TPTM;
+            static_assert(S >= 1 && M >= 4, "fold geometry");
+            // register slot q holds bin lane + TPT*m(q), m(q) = (q>>2) + (q&3)*(CNT/4);
+            // folded bin lane + TPT*s collects every m with m % S == s
+            float2 z[S];
+#pragma unroll
+            for (int s2 = 0; s2 < S; s2++) z[s2] = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < CNT; q++) {
+                constexpr int B4 = CNT / 4;
+                const int m = (q >> 2) + (q & 3) * B4;
+                z[m % S] = cadd(z[m % S], R.v[q]);
+            }
+            __syncthreads();  // forward's last-pass LDS reads are done
+#pragma unroll
+            for (int s2 = 0; s2 < S; s2++) lds[lane + TPT * s2] = z[s2];
+            __syncthreads();
+            const int g = lane / TPTM, l2 = lane % TPTM;
+            FftRegs<M> Q;
+#pragma unroll
+            for (int q = 0; q < CNTM; q++) Q.v[q] = lds[edge4_index<M>(q, l2)];
+            fft_backward_regs<M>(Q, lds + g * M, tw_small, l2);  // groups > 0 redo it in their own region
+            if (g == 0) {
+                const unsigned i_lo = off / FOLD, i_hi = (off + hop) / FOLD;
+#pragma unroll
+                for (int q = 0; q < CNTM; q++) {
+                    const unsigned i = fft_odd(M) ? edge2_index<M>(q, l2) : edge4_index<M>(q, l2);
+                    if (i >= i_lo && i < i_hi) {
+                        const size_t m_out = b * (hop / FOLD) + (i - i_lo);
+                        if (m_out * FOLD < n_in) out[m_out] = Q.v[q];
+                    }
                 }
             }
         }
@@ -301,10 +382,14 @@ template <int N, int FMT>
 static void launch_conv_n(hzsdr_ctx *ctx, const void *in, void *out, const void *filt, const float2 *tw,
                           size_t nblocks, unsigned dec, size_t per, const EwProgram &P) {
     constexpr int XPB = fft_xpb(N);
-    size_t groups = (nblocks + XPB - 1) / XPB, cap = (size_t)ctx->num_cus * 16;
-    hipLaunchKernelGGL((conv_blocks_kernel<N, FMT>), dim3((unsigned)(groups < cap ? groups : cap)),
-                       dim3(fft_block(N)), 0, ctx->stream, in, (float2 *)out, (const float2 *)filt, tw,
-                       nblocks, dec, per, P);
+    size_t groups = (nblocks + XPB - 1) / XPB;
+    const dim3 grid((unsigned)groups), block(fft_block(N));
+    if (FMT == HZSDR_FMT_C64 && P.n == 0)
+        hipLaunchKernelGGL((conv_blocks_kernel<N, FMT, false>), grid, block, 0, ctx->stream, in,
+                           (float2 *)out, (const float2 *)filt, tw, nblocks, dec, per, P);
+    else
+        hipLaunchKernelGGL((conv_blocks_kernel<N, FMT, true>), grid, block, 0, ctx->stream, in,
+                           (float2 *)out, (const float2 *)filt, tw, nblocks, dec, per, P);
 }
 
 template <int FMT>
@@ -396,26 +481,39 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
         return conv_blocks_device(ctx, FMT, c->flen, in, out, c->filt, n_cons / c->flen, c->factor,
                                   c->factor > 1 ? kReaderBlock / c->factor : 0, P);
     case TERM_FIR: {
-        const float2 *tw;
+        const float2 *tw, *tws = nullptr;
         HZ_TRY(get_twiddles(ctx, c->nfft, &tw));
         const size_t nblocks = (n_cons + c->hop - 1) / c->hop;
         const float2 *hist = (const float2 *)c->hist[c->hist_cur];
         float2 *nhist = (float2 *)c->hist[c->hist_cur ^ 1];
-        size_t cap = (size_t)ctx->num_cus * 16;
-        unsigned grid = (unsigned)(nblocks < cap ? nblocks : cap);
-#define HZ_FIR(N)                                                                                     \
-    hipLaunchKernelGGL((fir_decimate_kernel<N, FMT>), dim3(grid), dim3(fft_block(N)), 0, ctx->stream, \
-                       in, (float2 *)out, hist, (const float2 *)c->hfreq, tw, nblocks, n_cons, c->hop, \
-                       c->off, c->factor, P)
+        unsigned grid = (unsigned)nblocks;
+        const unsigned D = c->factor;
+#define HZ_FIR(N, FOLD)                                                                                  \
+    hipLaunchKernelGGL((fir_decimate_kernel<N, FMT, FOLD>), dim3(grid), dim3(fft_block(N)), 0,           \
+                       ctx->stream, in, (float2 *)out, hist, (const float2 *)c->hfreq, tw, tws, nblocks, \
+                       n_cons, c->hop, c->off, D, P)
+#define HZ_FIR_N(N)                                                                      \
+    do {                                                                                 \
+        constexpr int CNT_ = N / fft_tpt(N);                                             \
+        const bool pow2 = (D & (D - 1)) == 0;                                            \
+        if (pow2 && D >= 2 && D <= 16 && (int)D <= CNT_ && N / D >= 4)                   \
+            HZ_TRY(get_twiddles(ctx, N / D, &tws));                                      \
+        if (pow2 && D == 2 && 2 <= CNT_) HZ_FIR(N, (2 <= CNT_ ? 2 : 0));                 \
+        else if (pow2 && D == 4 && 4 <= CNT_) HZ_FIR(N, (4 <= CNT_ ? 4 : 0));            \
+        else if (pow2 && D == 8 && 8 <= CNT_) HZ_FIR(N, (8 <= CNT_ ? 8 : 0));            \
+        else if (pow2 && D == 16 && 16 <= CNT_) HZ_FIR(N, (16 <= CNT_ ? 16 : 0));        \
+        else HZ_FIR(N, 0);                                                               \
+    } while (0)
         switch (c->nfft) {
-        case 256: HZ_FIR(256); break;
-        case 512: HZ_FIR(512); break;
-        case 1024: HZ_FIR(1024); break;
-        case 2048: HZ_FIR(2048); break;
-        case 4096: HZ_FIR(4096); break;
-        case 8192: HZ_FIR(8192); break;
+        case 256: HZ_FIR_N(256); break;
+        case 512: HZ_FIR_N(512); break;
+        case 1024: HZ_FIR_N(1024); break;
+        case 2048: HZ_FIR_N(2048); break;
+        case 4096: HZ_FIR_N(4096); break;
+        case 8192: HZ_FIR_N(8192); break;
         default: return HZSDR_ERR_INVALID_ARGUMENT;
         }
+#undef HZ_FIR_N
 #undef HZ_FIR
         hipLaunchKernelGGL((fir_history_kernel<FMT>), dim3(blocks_for(ctx, c->off)), dim3(kThreads), 0,
                            ctx->stream, in, hist, nhist, n_cons, c->off, P);

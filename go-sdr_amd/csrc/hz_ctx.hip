@@ -149,7 +149,14 @@ int hzsdr_memspace(const hzsdr_ctx *ctx) { return ctx ? ctx->memspace : -1; }
 int hzsdr_set_stream(hzsdr_ctx *ctx, void *hip_stream) {
     HZ_TRY(hz::enter(ctx));
     HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;
+    return HZSDR_OK;
+}
+
+int hzsdr_use_own_stream(hzsdr_ctx *ctx) {
+    HZ_TRY(hz::enter(ctx));
+    HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = ctx->own_stream;
     return HZSDR_OK;
 }
 

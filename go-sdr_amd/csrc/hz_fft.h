@@ -34,6 +34,10 @@ constexpr int kFftMaxLds = 8192;
 constexpr int fft_tpt(int n) { return n / 4 < 256 ? (n / 4 < 1 ? 1 : n / 4) : 256; }  // lanes per transform
 constexpr int fft_block(int n) { return fft_tpt(n) < 64 ? 64 : fft_tpt(n); }          // lanes per workgroup
 constexpr int fft_xpb(int n) { return fft_block(n) / fft_tpt(n); }                    // transforms per workgroup
+// __launch_bounds__ second argument (minimum waves per SIMD): what the LDS
+// footprint lets a CU hold anyway, so the register allocator does not trade
+// occupancy for a few hoisted loads (N*8 bytes of LDS per 256-lane workgroup).
+constexpr int fft_waves(int n) { return n <= 2048 ? 8 : (n <= 4096 ? 4 : 2); }
 constexpr bool fft_odd(int n) {
     int l = 0;
     while ((1 << l) < n) l++;
@@ -170,16 +174,20 @@ template <int N> __device__ __forceinline__ int edge2_index(int q, int lane) {
 // FORWARD transform.  On entry R holds the inputs in the edge layout of the
 // first pass (edge2 when log2 N is odd, else edge4); on exit R holds the
 // spectrum in edge4 layout.
-template <int N>
+// FROM_LDS: the caller filled R from `lds` itself (staged inputs), so other
+// lanes may still be reading it: barrier before the first in-place store.
+template <int N, bool FROM_LDS = false>
 __device__ __forceinline__ void fft_forward_regs(FftRegs<N> &R, float2 *lds, const float2 *tw, int lane) {
     int Ns = 1;
     if constexpr (fft_odd(N)) {
         r2_twiddle_butterfly<N, false>(R, tw, lane, 1);
+        if constexpr (FROM_LDS) __syncthreads();
         r2_store_lds<N>(R, lds, lane, 1);
         Ns = 2;
     } else {
         r4_twiddle_butterfly<N, false>(R, tw, lane, 1);
         if constexpr (N == 4) return;
+        if constexpr (FROM_LDS) __syncthreads();
         r4_store_lds<N>(R, lds, lane, 1);
         Ns = 4;
     }

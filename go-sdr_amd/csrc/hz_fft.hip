@@ -42,7 +42,7 @@ int get_twiddles(hzsdr_ctx *ctx, size_t n, const float2 **out) {
 // ---- LDS kernels ---------------------------------------------------------------------
 
 template <int N, bool FWD>
-__global__ __launch_bounds__(fft_block(N)) void fft_plan_kernel(const float2 *__restrict__ in,
+__global__ __launch_bounds__(fft_block(N), fft_waves(N)) void fft_plan_kernel(const float2 *__restrict__ in,
                                                                 float2 *__restrict__ out,
                                                                 const float2 *__restrict__ tw,
                                                                 size_t batch) {
@@ -50,7 +50,9 @@ __global__ __launch_bounds__(fft_block(N)) void fft_plan_kernel(const float2 *__
     __shared__ float2 lds_all[XPB * N];
     const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
     float2 *lds = lds_all + sub * N;
-    for (size_t t0 = (size_t)blockIdx.x * XPB; t0 < batch; t0 += (size_t)gridDim.x * XPB) {
+    {   // one workgroup per XPB transforms, no grid-stride loop: a loop lets LICM hoist every
+        // pass's twiddles into registers (254 VGPRs at N = 4096) and collapses occupancy
+        const size_t t0 = (size_t)blockIdx.x * XPB;
         const size_t t = t0 + sub;
         const bool live = t < batch;
         const float2 *src = in + t * N;
@@ -88,8 +90,7 @@ static void launch_plan_n(hzsdr_ctx *ctx, const float2 *in, float2 *out, const f
                           bool fwd) {
     constexpr int XPB = fft_xpb(N);
     size_t groups = (batch + XPB - 1) / XPB;
-    size_t cap = (size_t)ctx->num_cus * 16;
-    unsigned grid = (unsigned)(groups < cap ? groups : cap);
+    unsigned grid = (unsigned)groups;
     if (fwd)
         hipLaunchKernelGGL((fft_plan_kernel<N, true>), dim3(grid), dim3(fft_block(N)), 0, ctx->stream, in, out, tw, batch);
     else

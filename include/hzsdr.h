@@ -85,8 +85,10 @@ int hzsdr_close(hzsdr_ctx *ctx);
 const char *hzsdr_last_error(const hzsdr_ctx *ctx);
 int hzsdr_memspace(const hzsdr_ctx *ctx);
 /* Adopt the caller's hipStream_t (e.g. the stream a host framework already
- * orders its work on); NULL restores the context's own stream. */
+ * orders its work on).  NULL is HIP's default (null) stream, as everywhere in
+ * HIP.  hzsdr_use_own_stream goes back to the context's private stream. */
 int hzsdr_set_stream(hzsdr_ctx *ctx, void *hip_stream);
+int hzsdr_use_own_stream(hzsdr_ctx *ctx);
 void *hzsdr_get_stream(const hzsdr_ctx *ctx);
 /* Block until everything enqueued on the context's stream has finished. */
 int hzsdr_synchronize(hzsdr_ctx *ctx);
