@@ -36,14 +36,27 @@ __device__ __forceinline__ int32_t go_f32_to_i32(float x) {
 
 // ---- per-component converters (one float / integer component each) --------
 
+// Correctly rounded x / d for a CONSTANT divisor without the ~10-instruction
+// IEEE divide expansion: q0 = RN(x * RN(1/d)); the remainder x - d*q0 is exact
+// in one fma; one more fma applies the correction (Markstein).  The result is
+// the IEEE quotient for every input the converters can produce -- the domains
+// are 256 and 65 536 values and tests/test_gpu_parity.py checks all of them
+// bit for bit against the oracle's real division.
+__device__ __forceinline__ float div_const_rn(float x, float d, float rcp_d) {
+    float q0 = __fmul_rn(x, rcp_d);
+    float rem = __fmaf_rn(-d, q0, x);
+    return __fmaf_rn(rem, rcp_d, q0);
+}
 // iq_u8.go:111-121 / iq_u8_amd64.s:71-89: (float32(b) - 127.5) / 127.5
 __device__ __forceinline__ float u8_to_f32(uint32_t b) {
-    return __fdiv_rn(__fsub_rn((float)b, 127.5f), 127.5f);
+    return div_const_rn(__fsub_rn((float)b, 127.5f), 127.5f, 1.0f / 127.5f);
 }
-// iq_i8.go:109-119: float32(b) / 128 (exact)
-__device__ __forceinline__ float i8_to_f32(int32_t b) { return __fdiv_rn((float)b, 128.0f); }
+// iq_i8.go:109-119: float32(b) / 128 (a power of two: the multiply is exact)
+__device__ __forceinline__ float i8_to_f32(int32_t b) { return __fmul_rn((float)b, 0.0078125f); }
 // iq_i16.go:137-147: float32(v) / 32767
-__device__ __forceinline__ float i16_to_f32(int32_t v) { return __fdiv_rn((float)v, 32767.0f); }
+__device__ __forceinline__ float i16_to_f32(int32_t v) {
+    return div_const_rn((float)v, 32767.0f, 1.0f / 32767.0f);
+}
 // iq_c64.go:77-89: uint8(x*127.5 + 127.5), un-fused
 __device__ __forceinline__ uint32_t f32_to_u8(float x) {
     float v = __fadd_rn(__fmul_rn(x, 127.5f), 127.5f);
@@ -115,33 +128,27 @@ __device__ __forceinline__ void go_sincos(double x, double &sn, double &cs) {
     const double PI4B = 3.77489470793079817668e-8;
     const double PI4C = 2.69515142907905952645e-15;
     const double M4PI = 1.27323954473516268615107010698;
-    if (x == 0.0) {
-        sn = x;
-        cs = 1.0;
-        return;
-    }
-    if (!(fabs(x) <= 1.7976931348623157e308)) {  // NaN or Inf
-        sn = __longlong_as_double(0x7FF8000000000001LL);
-        cs = sn;
-        return;
-    }
-    bool sin_sign = false, cos_sign = false;
-    if (x < 0) {
-        x = -x;
-        sin_sign = true;
-    }
+    // Straight-line common path (|x| < 2^29): the special cases of the Go source
+    // (x == 0 returns (x, 1); NaN / Inf return NaN) are folded into selects at the
+    // end, and j fits an int32 (|x| * 4/pi < 2^31), so the float64 <-> uint64
+    // conversion sequences become single instructions with identical values.
+    const double x_in = x;
+    bool sin_sign = x < 0, cos_sign = false;
+    x = fabs(x);
     uint32_t j;
     double z;
-    if (x >= 536870912.0) {
+    if (x >= 536870912.0) {  // also Inf; NaN takes the other side and stays NaN
+        if (x > 1.7976931348623157e308) {
+            sn = __longlong_as_double(0x7FF8000000000001LL);
+            cs = sn;
+            return;
+        }
         go_trig_reduce(x, j, z);
     } else {
-        uint64_t jj = (uint64_t)__dmul_rn(x, M4PI);
-        double y = (double)jj;
-        if (jj & 1) {
-            jj++;
-            y = __dadd_rn(y, 1.0);
-        }
-        j = (uint32_t)(jj & 7);
+        int32_t ji = __double2int_rz(__dmul_rn(x, M4PI));
+        ji += ji & 1;  // map zeros to origin: j++, y++ (y + 1 is exact)
+        const double y = (double)ji;
+        j = (uint32_t)ji & 7;
         z = __dsub_rn(__dsub_rn(__dsub_rn(x, __dmul_rn(y, PI4A)), __dmul_rn(y, PI4B)),
                       __dmul_rn(y, PI4C));
     }
@@ -175,6 +182,7 @@ __device__ __forceinline__ void go_sincos(double x, double &sn, double &cs) {
     }
     sn = sin_sign ? -s : s;
     cs = cos_sign ? -c : c;
+    if (x_in == 0.0) sn = x_in;  // +-0 in, +-0 out (cs is already exactly 1)
 }
 
 }  // namespace hz

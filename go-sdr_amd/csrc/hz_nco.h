@@ -51,7 +51,12 @@ __device__ __forceinline__ double nco_ts(const NcoSegs &sg, uint64_t j) {
         t0 = sg.big[lo].t0;
         step = sg.big[lo].step;
     }
-    return __fma_rn((double)(j - first), step, t0);  // exact: the value is representable
+    // exact: the true value is representable.  The run offset is < 2^32 for any
+    // buffer that fits in memory, so one 32-bit conversion replaces the 64-bit one.
+    const uint64_t d = j - first;
+    double k = (double)(uint32_t)d;
+    if (d >> 32) k = __fma_rn((double)(uint32_t)(d >> 32), 4294967296.0, k);
+    return __fma_rn(k, step, t0);
 }
 
 // Plans the next n clock values from *ts (advancing it) into `sg`; a table too

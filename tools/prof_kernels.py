@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Runs a chosen hot-path kernel a few times on 2^24-sample buffers, and nothing
+else, so a rocprofv3 pass (kernel trace or PMC counters) sees a clean stream.
+
+    rocprofv3 --kernel-trace --stats --output-format csv -d out -- python3 tools/prof_kernels.py chain conv
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d out -- python3 tools/prof_kernels.py chain
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench as B  # noqa: E402  (synthetic generators)
+
+
+def main():
+    import torch
+    which = sys.argv[1:] or ["chain"]
+    reps = int(os.environ.get("REPS", "5"))
+    log2n = int(os.environ.get("LOG2N", "24"))
+    hz = importlib.import_module("go-sdr_amd")
+    s = torch.cuda.Stream()
+    torch.cuda.set_stream(s)
+    ctx = hz.Context(0, hz.MEM_DEVICE, stream=s.cuda_stream)
+    n, fs, D = 1 << log2n, 20_000_000, 8
+    taps = B.lowpass_taps(1024, 1 / 16)
+    xu8 = torch.from_numpy(B.synth_u8(9, n)).cuda()
+    xc = torch.from_numpy(B.synth_c64(2, n)).cuda()
+    out = torch.zeros(n, dtype=torch.complex64, device="cuda")
+    for w in which:
+        if w == "chain":
+            ch = ctx.chain(hz.FMT_U8, fs).shift(-fs / 8).fir_decimate(taps, D)
+            fn = lambda: ch.run(xu8, out[:n // D])
+        elif w == "chain_noshift":
+            ch = ctx.chain(hz.FMT_U8, fs).fir_decimate(taps, D)
+            fn = lambda: ch.run(xu8, out[:n // D])
+        elif w == "chain_c64":
+            ch = ctx.chain(hz.FMT_C64, fs).fir_decimate(taps, D)
+            fn = lambda: ch.run(xc, out[:n // D])
+        elif w == "conv":
+            H = torch.from_numpy(np.fft.fft(np.asarray(taps, np.complex128) / 1024).astype(np.complex64)).cuda()
+            fn = lambda: ctx.convolution_blocks(out, xc, H)
+        elif w == "fft1024":
+            p = ctx.fft_plan(xc, out, hz.FFT_FORWARD, batch=n // 1024)
+            fn = p.transform
+        elif w == "fft4096":
+            p = ctx.fft_plan(xc, out, hz.FFT_FORWARD, batch=n // 4096)
+            fn = p.transform
+        elif w == "shift":
+            nco = ctx.nco(fs)
+            fn = lambda: nco(2.5e6, xc)
+        elif w == "shift_gain":
+            ch = ctx.chain(hz.FMT_C64, fs).shift(2.5e6).gain(0.5)
+            fn = lambda: ch.run(xc, out)
+        elif w == "convert":
+            fn = lambda: ctx.convert(out, xu8)
+        elif w == "scale":
+            fn = lambda: ctx.scale(xc, 0.999)
+        elif w == "rotate":
+            fn = lambda: ctx.rotate(xc, 0.6 + 0.8j)
+        elif w == "beamform":
+            chans = [torch.from_numpy(B.synth_c64(5 + i, n)).cuda() for i in range(4)]
+            wts = hz.beamform_angles(433e6, 30.0, [0.0, 0.1, 0.2, 0.3])
+            fn = lambda: ctx.beamform(out, chans, wts)
+        elif w == "downsample":
+            xi = torch.from_numpy(B.synth_i16(4, n)).cuda()
+            fn = lambda: ctx.downsample(out[:n // 8], xi, 8)
+        else:
+            raise SystemExit(f"unknown kernel {w}")
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
