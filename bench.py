@@ -176,7 +176,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "kernel": "hz::fir_decimate_kernel<4096, u8>", "kernel_ms": round(kernel_ms, 4),
+            "kernel": "hz::fir_decimate_kernel16<4096, u8, fold 8>", "kernel_ms": round(kernel_ms, 4),
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "note": "3 B/sample puts this chain above the ridge: f32 vector work binds, not HBM",
             "fp32_vector_frac": round(flops / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),

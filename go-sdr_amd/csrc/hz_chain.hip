@@ -20,6 +20,7 @@
 #include "hz_common.h"
 #include "hz_device.h"
 #include "hz_fft.h"
+#include "hz_fft16.h"
 #include "hz_fft_api.h"
 #include "hz_nco.h"
 
@@ -40,9 +41,11 @@ struct EwProgram {
     NcoSegs segs;  // one clock serves every Shift stage: same rate, same start, same length
 };
 
-__device__ __forceinline__ float2 ew_apply(const EwProgram &P, float2 v, uint64_t j) {
+// `w`: the NCO runs that can contain sample j (nco_window of the caller's span)
+__device__ __forceinline__ float2 ew_apply(const EwProgram &P, float2 v, uint64_t j, NcoWin w) {
     double ts = 0.0;
     bool have_ts = false;
+#pragma unroll 1
     for (int i = 0; i < P.n; i++) {  // uniform
         const EwOp &o = P.op[i];
         if (o.kind == EW_SCALE) {
@@ -51,7 +54,7 @@ __device__ __forceinline__ float2 ew_apply(const EwProgram &P, float2 v, uint64_
             v = go_cmul(v, make_float2(o.a, o.b));  // stream/multiply.go:46-70
         } else {
             if (!have_ts) {
-                ts = nco_ts(P.segs, j);
+                ts = nco_ts(P.segs, w, j);
                 have_ts = true;
             }
             double ph = __dmul_rn(o.tau_shift, ts);  // stream/shifter.go:81
@@ -85,7 +88,7 @@ template <> struct Raw<HZSDR_FMT_I16> {
 template <int FMT>
 __device__ __forceinline__ float2 chain_sample(const void *in, const EwProgram &P, uint64_t j) {
     using R = typename Raw<FMT>::t;
-    return ew_apply(P, Raw<FMT>::cvt(((const R *)in)[j]), j);
+    return ew_apply(P, Raw<FMT>::cvt(((const R *)in)[j]), j, nco_window_all(P.segs));
 }
 
 // ---- streaming terminals ---------------------------------------------------------------
@@ -98,13 +101,29 @@ __global__ __launch_bounds__(kThreads) void chain_map_kernel(const void *__restr
     using R = typename Raw<FMT>::t;
     struct alignas(sizeof(R) * W) RV { R v[W]; };
     struct alignas(8 * W) OV { float2 v[W]; };
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-        RV x = ((const RV *)in)[i];
-        OV o;
+    // a workgroup owns a contiguous tile per trip and issues its U loads per lane
+    // back to back before the arithmetic (memory-level parallelism, see hz_nco.hip)
+    constexpr int U = 2;
+    const size_t tile = (size_t)kThreads * U;
+    for (size_t t0 = (size_t)blockIdx.x * tile; t0 < nvec; t0 += (size_t)gridDim.x * tile) {
+        const uint64_t j_lo = base + t0 * W;
+        const NcoWin w = nco_window(P.segs, j_lo, j_lo + tile * W - 1);
+        RV x[U];
 #pragma unroll
-        for (int l = 0; l < W; l++) o.v[l] = ew_apply(P, Raw<FMT>::cvt(x.v[l]), base + i * W + l);
-        ((OV *)out)[i] = o;
+        for (int u = 0; u < U; u++) {
+            const size_t i = t0 + (size_t)u * kThreads + threadIdx.x;
+            if (i < nvec) x[u] = ((const RV *)in)[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t i = t0 + (size_t)u * kThreads + threadIdx.x;
+            if (i < nvec) {
+                OV o;
+#pragma unroll
+                for (int l = 0; l < W; l++) o.v[l] = ew_apply(P, Raw<FMT>::cvt(x[u].v[l]), base + i * W + l, w);
+                ((OV *)out)[i] = o;
+            }
+        }
     }
 }
 
@@ -173,14 +192,18 @@ __device__ __forceinline__ void stage_block(float2 *lds, const void *in, const E
     // pair loads need 2*sizeof(R) alignment of in + p0 (i0 is even); mod-2 arithmetic wraps safely
     const bool vec_ok = ((((uintptr_t)in / sizeof(R)) + (uint64_t)p0) & 1) == 0;
 #pragma unroll 1
-    for (int i0 = lane * 2; i0 < N; i0 += TPT * 2) {
+    for (int ib = 0; ib < N; ib += TPT * 2) {
+        const int i0 = ib + lane * 2;
         const int64_t p = p0 + i0;
+        const int64_t span_lo = p0 + ib;  // uniform: the TPT*2 samples this trip covers
+        const NcoWin w = nco_window(P.segs, span_lo < 0 ? 0 : (uint64_t)span_lo,
+                                    span_lo + TPT * 2 <= 0 ? 0 : (uint64_t)(span_lo + TPT * 2 - 1));
         float2 a = make_float2(0.f, 0.f), b = a;
         if (live) {
             if (vec_ok && p >= 0 && (size_t)(p + 2) <= n_in) {
                 RV x = *reinterpret_cast<const RV *>((const R *)in + p);
-                a = ew_apply(P, Raw<FMT>::cvt(x.v[0]), (uint64_t)p);
-                b = ew_apply(P, Raw<FMT>::cvt(x.v[1]), (uint64_t)p + 1);
+                a = ew_apply(P, Raw<FMT>::cvt(x.v[0]), (uint64_t)p, w);
+                b = ew_apply(P, Raw<FMT>::cvt(x.v[1]), (uint64_t)p + 1, w);
             } else {
                 if (p < 0) { if (hist) a = hist[p + off]; }
                 else if ((size_t)p < n_in) a = chain_sample<FMT>(in, P, (uint64_t)p);
@@ -321,6 +344,149 @@ __global__ __launch_bounds__(fft_block(N), fft_waves(N)) void fir_decimate_kerne
     }
 }
 
+// ==== the same two kernels on the radix-16 core (hz_fft16.h), N = 256 .. 4096 ================
+
+// stage_block for the padded LDS image of the radix-16 core
+template <int N, int FMT>
+__device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const EwProgram &P, int64_t p0,
+                                              size_t n_in, const float2 *hist, unsigned off, int lane,
+                                              bool live) {
+    using R = typename Raw<FMT>::t;
+    constexpr int TPT = f16::tpt(N);
+    struct alignas(sizeof(R) * 2) RV { R v[2]; };
+    const bool vec_ok = ((((uintptr_t)in / sizeof(R)) + (uint64_t)p0) & 1) == 0;
+#pragma unroll 1
+    for (int ib = 0; ib < N; ib += TPT * 2) {
+        const int i0 = ib + lane * 2;
+        const int64_t p = p0 + i0;
+        const int64_t span_lo = p0 + ib;  // uniform: the TPT*2 samples this trip covers
+        const NcoWin w = nco_window(P.segs, span_lo < 0 ? 0 : (uint64_t)span_lo,
+                                    span_lo + TPT * 2 <= 0 ? 0 : (uint64_t)(span_lo + TPT * 2 - 1));
+        float2 a = make_float2(0.f, 0.f), b = a;
+        if (live) {
+            if (vec_ok && p >= 0 && (size_t)(p + 2) <= n_in) {
+                RV x = *reinterpret_cast<const RV *>((const R *)in + p);
+                a = ew_apply(P, Raw<FMT>::cvt(x.v[0]), (uint64_t)p, w);
+                b = ew_apply(P, Raw<FMT>::cvt(x.v[1]), (uint64_t)p + 1, w);
+            } else {
+                if (p < 0) { if (hist) a = hist[p + off]; }
+                else if ((size_t)p < n_in) a = chain_sample<FMT>(in, P, (uint64_t)p);
+                if (p + 1 < 0) { if (hist) b = hist[p + 1 + off]; }
+                else if ((size_t)(p + 1) < n_in) b = chain_sample<FMT>(in, P, (uint64_t)p + 1);
+            }
+        }
+        const int q = f16::pad(i0);  // i0 even: i0 and i0+1 share a 16-element row
+        lds[q] = a;
+        lds[q + 1] = b;
+    }
+}
+
+template <int N, int FMT, bool STAGED>
+__global__ __launch_bounds__(f16::block(N)) void conv_blocks_kernel16(const void *in, float2 *out,
+                                                                      const float2 *__restrict__ filt,
+                                                                      const float2 *__restrict__ tw,
+                                                                      size_t nblocks, unsigned dec,
+                                                                      size_t per, EwProgram P) {
+    constexpr int TPT = f16::tpt(N), XPB = f16::xpb(N), R0 = f16::first_radix(N);
+    __shared__ float2 lds_all[XPB * f16::lds_elems(N)];
+    const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
+    float2 *lds = lds_all + sub * f16::lds_elems(N);
+    const size_t b = (size_t)blockIdx.x * XPB + sub;
+    const bool live = b < nblocks;
+    float2 v[16];
+    if constexpr (STAGED) {
+        stage_block16<N, FMT>(lds, in, P, (int64_t)(b * N), ~(size_t)0, nullptr, 0, lane, live);
+        __syncthreads();
+        f16::load_lds<N, R0>(v, lds, lane);
+        f16::forward<N, true>(v, lds, tw, lane);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            v[q] = live ? Raw<FMT>::cvt(((const typename Raw<FMT>::t *)in)[b * N + f16::edge_index<N, R0>(q, lane)])
+                        : make_float2(0.f, 0.f);
+        f16::forward<N>(v, lds, tw, lane);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++)  // freq1[i] = freq1[i] * freq[i], fft/convolution.go:187-189
+        v[q] = go_cmul(v[q], filt[f16::edge_index<N, 16>(q, lane)]);
+    f16::backward<N>(v, lds, tw, lane);
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) conv_store(out, b * N + f16::edge_index<N, R0>(q, lane), v[q], dec, per);
+    }
+}
+
+// FOLD = D (power of two <= 16 with N/D >= 256): lane-local spectral fold, then a
+// backward transform of M = N/D points run by groups of M/16 lanes (group 0's
+// result is kept; the others run the same program on their own LDS slices so the
+// workgroup barriers stay uniform).  FOLD = 0: full backward transform + pick.
+template <int N, int FMT, int FOLD>
+__global__ __launch_bounds__(f16::block(N)) void fir_decimate_kernel16(
+    const void *in, float2 *out, const float2 *__restrict__ hist, const float2 *__restrict__ hfreq,
+    const float2 *__restrict__ tw, const float2 *__restrict__ tw_small, size_t nblocks, size_t n_in,
+    unsigned hop, unsigned off, unsigned D, EwProgram P) {
+    constexpr int R0 = f16::first_radix(N), TPT = f16::tpt(N);
+    static_assert(f16::xpb(N) == 1 || FOLD == 0, "fold path assumes one block per workgroup");
+    __shared__ float2 lds_all[f16::xpb(N) * f16::lds_elems(N)];
+    const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
+    float2 *lds = lds_all + sub * f16::lds_elems(N);
+    const size_t b = (size_t)blockIdx.x * f16::xpb(N) + sub;
+    const bool live = b < nblocks;
+    float2 v[16];
+    stage_block16<N, FMT>(lds, in, P, (int64_t)(b * hop) - (int64_t)off, n_in, hist, off, lane, live);
+    __syncthreads();
+    f16::load_lds<N, R0>(v, lds, lane);
+    f16::forward<N, true>(v, lds, tw, lane);
+#pragma unroll
+    for (int q = 0; q < 16; q++) v[q] = f16::cmul(v[q], hfreq[f16::edge_index<N, 16>(q, lane)]);
+    if constexpr (FOLD == 0) {
+        f16::backward<N>(v, lds, tw, lane);
+        if (live) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const unsigned idx = f16::edge_index<N, R0>(q, lane);
+                if (idx >= off && idx < off + hop && ((idx - off) % D) == 0) {
+                    const size_t p = b * hop + (idx - off);
+                    if (p < n_in) out[p / D] = v[q];
+                }
+            }
+        }
+    } else {
+        constexpr int M = N / FOLD, S = 16 / FOLD, TPTM = f16::tpt(M), RM = f16::first_radix(M);
+        static_assert(f16::ok(M) && S >= 1, "fold geometry");
+        // slot q holds bin lane + q*TPT; folded bin lane + s*TPT sums the slots with q % S == s
+        float2 z[S];
+#pragma unroll
+        for (int s2 = 0; s2 < S; s2++) z[s2] = v[s2];
+#pragma unroll
+        for (int q = S; q < 16; q++) z[q % S] = f16::cadd(z[q % S], v[q]);
+        __syncthreads();  // forward's last-pass LDS reads are done
+#pragma unroll
+        for (int s2 = 0; s2 < S; s2++) lds[lane + TPT * s2] = z[s2];
+        __syncthreads();
+        // the M-point inverse runs on the first M/16 lanes only; the other waves just
+        // attend its barriers and leave their SIMD issue slots to co-resident blocks
+        const int g = lane / TPTM, l2 = lane % TPTM;
+        float2 w[16];
+        if (g == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) w[q] = lds[f16::edge_index<M, 16>(q, l2)];
+        }
+        f16::backward<M>(w, lds, tw_small, l2, g == 0);
+        if (g == 0) {
+            const unsigned i_lo = off / FOLD, i_hi = (off + hop) / FOLD;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const unsigned i = f16::edge_index<M, RM>(q, l2);
+                if (i >= i_lo && i < i_hi) {
+                    const size_t m_out = b * (hop / FOLD) + (i - i_lo);
+                    if (m_out * FOLD < n_in) out[m_out] = w[q];
+                }
+            }
+        }
+    }
+}
+
 // New history = the last `off` samples of (old history ++ this run's samples).
 template <int FMT>
 __global__ void fir_history_kernel(const void *in, const float2 *__restrict__ old_hist,
@@ -381,15 +547,26 @@ namespace hz {
 template <int N, int FMT>
 static void launch_conv_n(hzsdr_ctx *ctx, const void *in, void *out, const void *filt, const float2 *tw,
                           size_t nblocks, unsigned dec, size_t per, const EwProgram &P) {
-    constexpr int XPB = fft_xpb(N);
-    size_t groups = (nblocks + XPB - 1) / XPB;
-    const dim3 grid((unsigned)groups), block(fft_block(N));
-    if (FMT == HZSDR_FMT_C64 && P.n == 0)
-        hipLaunchKernelGGL((conv_blocks_kernel<N, FMT, false>), grid, block, 0, ctx->stream, in,
-                           (float2 *)out, (const float2 *)filt, tw, nblocks, dec, per, P);
-    else
-        hipLaunchKernelGGL((conv_blocks_kernel<N, FMT, true>), grid, block, 0, ctx->stream, in,
-                           (float2 *)out, (const float2 *)filt, tw, nblocks, dec, per, P);
+    const bool direct = FMT == HZSDR_FMT_C64 && P.n == 0;
+    if constexpr (f16::ok(N)) {  // radix-16 core
+        constexpr int XPB = f16::xpb(N);
+        const dim3 grid((unsigned)((nblocks + XPB - 1) / XPB)), block(f16::block(N));
+        if (direct)
+            hipLaunchKernelGGL((conv_blocks_kernel16<N, FMT, false>), grid, block, 0, ctx->stream, in,
+                               (float2 *)out, (const float2 *)filt, tw, nblocks, dec, per, P);
+        else
+            hipLaunchKernelGGL((conv_blocks_kernel16<N, FMT, true>), grid, block, 0, ctx->stream, in,
+                               (float2 *)out, (const float2 *)filt, tw, nblocks, dec, per, P);
+    } else {  // radix-4 core: N < 256 and N = 8192
+        constexpr int XPB = fft_xpb(N);
+        const dim3 grid((unsigned)((nblocks + XPB - 1) / XPB)), block(fft_block(N));
+        if (direct)
+            hipLaunchKernelGGL((conv_blocks_kernel<N, FMT, false>), grid, block, 0, ctx->stream, in,
+                               (float2 *)out, (const float2 *)filt, tw, nblocks, dec, per, P);
+        else
+            hipLaunchKernelGGL((conv_blocks_kernel<N, FMT, true>), grid, block, 0, ctx->stream, in,
+                               (float2 *)out, (const float2 *)filt, tw, nblocks, dec, per, P);
+    }
 }
 
 template <int FMT>
@@ -453,7 +630,7 @@ static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, cons
     const bool aligned = ((uintptr_t)in % (sizeof(R) * W) == 0) && ((uintptr_t)out % (8 * W) == 0);
     size_t nvec = aligned ? n / W : 0;
     if (nvec)
-        hipLaunchKernelGGL((chain_map_kernel<FMT, W>), dim3(blocks_for(ctx, nvec)), dim3(kThreads), 0,
+        hipLaunchKernelGGL((chain_map_kernel<FMT, W>), dim3(blocks_for(ctx, (nvec + 1) / 2)), dim3(kThreads), 0,
                            ctx->stream, in, (float2 *)out, nvec, (uint64_t)0, P);
     size_t done = nvec * W;
     if (done < n)
@@ -504,15 +681,40 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
         else if (pow2 && D == 16 && 16 <= CNT_) HZ_FIR(N, (16 <= CNT_ ? 16 : 0));        \
         else HZ_FIR(N, 0);                                                               \
     } while (0)
+// radix-16 core: fold when D is a power of two <= 16 and N/D is itself a radix-16 size
+#define HZ_FIR16(N, FOLD)                                                                               \
+    hipLaunchKernelGGL((fir_decimate_kernel16<N, FMT, FOLD>),                                           \
+                       dim3((unsigned)((nblocks + f16::xpb(N) - 1) / f16::xpb(N))), dim3(f16::block(N)), \
+                       0, ctx->stream, in, (float2 *)out, hist, (const float2 *)c->hfreq, tw, tws,      \
+                       nblocks, n_cons, c->hop, c->off, D, P)
+#define HZ_FIR16_FOLD(N, F)                                                            \
+    if (D == F) {                                                                      \
+        if constexpr (f16::xpb(N) == 1 && f16::ok(N / F)) {                            \
+            HZ_TRY(get_twiddles(ctx, N / F, &tws));                                    \
+            HZ_FIR16(N, F);                                                            \
+            break;                                                                     \
+        }                                                                              \
+    }
+#define HZ_FIR16_N(N)            \
+    do {                         \
+        HZ_FIR16_FOLD(N, 2)      \
+        HZ_FIR16_FOLD(N, 4)      \
+        HZ_FIR16_FOLD(N, 8)      \
+        HZ_FIR16_FOLD(N, 16)     \
+        HZ_FIR16(N, 0);          \
+    } while (0)
         switch (c->nfft) {
-        case 256: HZ_FIR_N(256); break;
-        case 512: HZ_FIR_N(512); break;
-        case 1024: HZ_FIR_N(1024); break;
-        case 2048: HZ_FIR_N(2048); break;
-        case 4096: HZ_FIR_N(4096); break;
+        case 256: HZ_FIR16_N(256); break;
+        case 512: HZ_FIR16_N(512); break;
+        case 1024: HZ_FIR16_N(1024); break;
+        case 2048: HZ_FIR16_N(2048); break;
+        case 4096: HZ_FIR16_N(4096); break;
         case 8192: HZ_FIR_N(8192); break;
         default: return HZSDR_ERR_INVALID_ARGUMENT;
         }
+#undef HZ_FIR16_N
+#undef HZ_FIR16_FOLD
+#undef HZ_FIR16
 #undef HZ_FIR_N
 #undef HZ_FIR
         hipLaunchKernelGGL((fir_history_kernel<FMT>), dim3(blocks_for(ctx, c->off)), dim3(kThreads), 0,

@@ -5,6 +5,7 @@
 // powers of two (1, 2, > 8192) take a plain global-memory Stockham radix-2 path:
 // correct, unoptimised (the 64 Ki-point kerberos sizes are a "next" row).
 #include "hz_fft.h"
+#include "hz_fft16.h"
 
 #include <math.h>
 
@@ -85,9 +86,47 @@ __global__ __launch_bounds__(fft_block(N), fft_waves(N)) void fft_plan_kernel(co
     }
 }
 
+// radix-16 core (hz_fft16.h), N = 256 .. 4096
+template <int N, bool FWD>
+__global__ __launch_bounds__(f16::block(N)) void fft_plan_kernel16(const float2 *__restrict__ in,
+                                                                   float2 *__restrict__ out,
+                                                                   const float2 *__restrict__ tw,
+                                                                   size_t batch) {
+    constexpr int TPT = f16::tpt(N), XPB = f16::xpb(N), R0 = f16::first_radix(N);
+    __shared__ float2 lds_all[XPB * f16::lds_elems(N)];
+    const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
+    float2 *lds = lds_all + sub * f16::lds_elems(N);
+    const size_t t = (size_t)blockIdx.x * XPB + sub;
+    const bool live = t < batch;
+    const float2 *src = in + t * N;
+    float2 *dst = out + t * N;
+    float2 v[16];
+    // time side = radix-R0 edge layout, frequency side = radix-16 edge layout
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int idx = FWD ? f16::edge_index<N, R0>(q, lane) : f16::edge_index<N, 16>(q, lane);
+        v[q] = live ? src[idx] : make_float2(0.f, 0.f);
+    }
+    if constexpr (FWD) f16::forward<N>(v, lds, tw, lane); else f16::backward<N>(v, lds, tw, lane);
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            dst[FWD ? f16::edge_index<N, 16>(q, lane) : f16::edge_index<N, R0>(q, lane)] = v[q];
+    }
+}
+
 template <int N>
 static void launch_plan_n(hzsdr_ctx *ctx, const float2 *in, float2 *out, const float2 *tw, size_t batch,
                           bool fwd) {
+    if constexpr (f16::ok(N)) {
+        constexpr int XPB16 = f16::xpb(N);
+        const dim3 grid16((unsigned)((batch + XPB16 - 1) / XPB16)), block16(f16::block(N));
+        if (fwd)
+            hipLaunchKernelGGL((fft_plan_kernel16<N, true>), grid16, block16, 0, ctx->stream, in, out, tw, batch);
+        else
+            hipLaunchKernelGGL((fft_plan_kernel16<N, false>), grid16, block16, 0, ctx->stream, in, out, tw, batch);
+        return;
+    }
     constexpr int XPB = fft_xpb(N);
     size_t groups = (batch + XPB - 1) / XPB;
     unsigned grid = (unsigned)groups;

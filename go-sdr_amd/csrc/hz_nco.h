@@ -26,15 +26,60 @@ struct NcoSegs {
     double step[kNcoMaxSegs];
 };
 
-// ts for sample j of the buffer the table was planned for
-__device__ __forceinline__ double nco_ts(const NcoSegs &sg, uint64_t j) {
+// The runs that can contain samples [j_lo, j_hi] (wave-uniform bounds): found
+// ONCE per workgroup-sized span with scalar code; lanes then only look inside
+// the window, which is a single run except at a run boundary.  Keeping the scan
+// rolled and scalar matters: unrolled over 32 runs it pulled the whole table
+// into SGPRs and spilled them through v_readlane/v_writelane.
+struct NcoWin {
+    int lo, hi;
+};
+
+__device__ __forceinline__ uint64_t nco_first(const NcoSegs &sg, int s) {
+    return sg.big_n ? sg.big[s].first : sg.first[s];
+}
+
+__device__ __forceinline__ NcoWin nco_window(const NcoSegs &sg, uint64_t j_lo, uint64_t j_hi) {
+    NcoWin w{0, 0};
+    if (sg.big_n == 0) {
+#pragma unroll 1
+        for (int s = 1; s < sg.n; s++) {
+            const uint64_t f = sg.first[s];
+            if (f <= j_lo) w.lo = s;
+            if (f <= j_hi) w.hi = s;
+        }
+    } else {
+        int lo = 0, hi = sg.big_n - 1;  // last run with first <= j_lo
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (sg.big[mid].first <= j_lo) lo = mid; else hi = mid - 1;
+        }
+        w.lo = lo;
+        hi = sg.big_n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (sg.big[mid].first <= j_hi) lo = mid; else hi = mid - 1;
+        }
+        w.hi = lo;
+    }
+    return w;
+}
+
+// every run: for callers whose sample index is not confined to a span
+__device__ __forceinline__ NcoWin nco_window_all(const NcoSegs &sg) {
+    return NcoWin{0, (sg.big_n ? sg.big_n : sg.n) - 1};
+}
+
+// ts for sample j (which must lie in the window's span)
+__device__ __forceinline__ double nco_ts(const NcoSegs &sg, NcoWin w, uint64_t j) {
     uint64_t first;
     double t0, step;
     if (sg.big_n == 0) {
-        first = sg.first[0];
-        t0 = sg.t0[0];
-        step = sg.step[0];
-        for (int s = 1; s < sg.n; s++) {
+        first = sg.first[w.lo];
+        t0 = sg.t0[w.lo];
+        step = sg.step[w.lo];
+#pragma unroll 1
+        for (int s = w.lo + 1; s <= w.hi; s++) {
             if (j >= sg.first[s]) {
                 first = sg.first[s];
                 t0 = sg.t0[s];
@@ -42,9 +87,9 @@ __device__ __forceinline__ double nco_ts(const NcoSegs &sg, uint64_t j) {
             }
         }
     } else {
-        int lo = 0, hi = sg.big_n - 1;  // last run with first <= j
+        int lo = w.lo, hi = w.hi;  // last run with first <= j, per lane
         while (lo < hi) {
-            int mid = (lo + hi + 1) >> 1;
+            const int mid = (lo + hi + 1) >> 1;
             if (sg.big[mid].first <= j) lo = mid; else hi = mid - 1;
         }
         first = sg.big[lo].first;

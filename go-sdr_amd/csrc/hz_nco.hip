@@ -19,24 +19,44 @@ __device__ __forceinline__ float2 nco_rotate(float2 v, double ts, double tau_shi
     return go_cmul(v, make_float2((float)c, (float)s));  // :82 complex64(complex(rl, im))
 }
 
+// Each workgroup owns a contiguous tile of kNcoTile vectors per trip; a lane
+// issues its kNcoUnroll 16-byte loads back to back before any arithmetic, so a
+// CU keeps ~4x the bytes in flight that one load per trip gave (that version
+// sat at 4.4 TB/s, latency-bound, not f64-bound).
+constexpr int kNcoUnroll = 4;
+
 __global__ __launch_bounds__(kThreads) void nco_shift_vec_kernel(float4 *buf, uint64_t base,
                                                                  size_t nvec, double tau_shift,
                                                                  NcoSegs sg) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-        float4 a = buf[i];
-        const uint64_t j = base + 2 * i;
-        float2 l = nco_rotate(make_float2(a.x, a.y), nco_ts(sg, j), tau_shift);
-        float2 h = nco_rotate(make_float2(a.z, a.w), nco_ts(sg, j + 1), tau_shift);
-        buf[i] = make_float4(l.x, l.y, h.x, h.y);
+    const size_t tile = (size_t)kThreads * kNcoUnroll;
+    for (size_t t0 = (size_t)blockIdx.x * tile; t0 < nvec; t0 += (size_t)gridDim.x * tile) {
+        const uint64_t j_lo = base + 2 * t0;
+        const NcoWin w = nco_window(sg, j_lo, j_lo + 2 * tile - 1);
+        float4 a[kNcoUnroll];
+#pragma unroll
+        for (int u = 0; u < kNcoUnroll; u++) {
+            const size_t i = t0 + (size_t)u * kThreads + threadIdx.x;
+            if (i < nvec) a[u] = buf[i];
+        }
+#pragma unroll
+        for (int u = 0; u < kNcoUnroll; u++) {
+            const size_t i = t0 + (size_t)u * kThreads + threadIdx.x;
+            if (i < nvec) {
+                const uint64_t j = base + 2 * i;
+                float2 l = nco_rotate(make_float2(a[u].x, a[u].y), nco_ts(sg, w, j), tau_shift);
+                float2 h = nco_rotate(make_float2(a[u].z, a[u].w), nco_ts(sg, w, j + 1), tau_shift);
+                buf[i] = make_float4(l.x, l.y, h.x, h.y);
+            }
+        }
     }
 }
 
 __global__ void nco_shift_scalar_kernel(float2 *buf, uint64_t base, size_t n, double tau_shift,
                                         NcoSegs sg) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const NcoWin w = nco_window_all(sg);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        buf[i] = nco_rotate(buf[i], nco_ts(sg, base + i), tau_shift);
+        buf[i] = nco_rotate(buf[i], nco_ts(sg, w, base + i), tau_shift);
 }
 
 // Plans the next n clock values from *ts into one table.
@@ -86,7 +106,7 @@ int nco_shift_device(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, double sh
     if (head)
         hipLaunchKernelGGL(nco_shift_scalar_kernel, dim3(1), dim3(64), 0, ctx->stream, q, (uint64_t)0, head, tau_shift, sg);
     if (nvec)
-        hipLaunchKernelGGL(nco_shift_vec_kernel, dim3(blocks_for(ctx, nvec)), dim3(kThreads), 0,
+        hipLaunchKernelGGL(nco_shift_vec_kernel, dim3(blocks_for(ctx, (nvec + kNcoUnroll - 1) / kNcoUnroll)), dim3(kThreads), 0,
                            ctx->stream, (float4 *)(q + head), (uint64_t)head, nvec, tau_shift, sg);
     if (tail)
         hipLaunchKernelGGL(nco_shift_scalar_kernel, dim3(1), dim3(64), 0, ctx->stream,

@@ -361,6 +361,29 @@ def test_shift_bit_exact_and_state_carries(env, orc, rate, shift, n):
     nco.close()
 
 
+def test_shift_bit_exact_at_volume(hz, orc):
+    """2^25 samples in one buffer: bit-identical to the oracle end to end (the
+    clock table, Sincos restatement and complex multiply at volume)."""
+    import torch
+    n, rate, shift = 1 << 25, 20_000_000, 2.5e6
+    x = rand_c64(77, n)
+    want = x.copy()
+    ref = orc.Shifter(rate)
+    ref.ts.value = 3.25
+    ref(shift, want)
+    ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+    nco = ctx.nco(rate)
+    nco.ts = 3.25
+    d = torch.from_numpy(x).cuda()
+    nco(shift, d)
+    ctx.synchronize()
+    got = d.cpu().numpy()
+    assert nco.ts == ref.ts.value
+    assert bits_equal(got, want)
+    nco.close()
+    ctx.close()
+
+
 def test_shift_large_phase_uses_payne_hanek(env, orc):
     """2*pi*shift*ts beyond 2^29 rad takes trigReduce (src/math/trig_reduce.go)."""
     n, rate, shift = 100_000, 200_000_000, 95e6
