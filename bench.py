@@ -183,6 +183,17 @@ def main():
         },
     }
     chain.close()
+    # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc
+    # passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_summary.py), not from this process.
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if n == (1 << 24) and os.path.exists(tpath):
+        try:
+            tk = json.load(open(tpath))["kernels"]
+            key = next(k for k in tk if "fir_decimate_kernel16<4096, 2, 8>" in k)
+            result["roofline"]["traffic"] = tk[key]["hbm_bytes"]
+            result["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+        except (StopIteration, KeyError, ValueError):
+            pass
 
     # ---- side measurements: the other BASELINE configs (rank 0, N = 1 semantics) ----
     if rank == 0 and not args.no_extra:

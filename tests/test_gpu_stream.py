@@ -1,0 +1,271 @@
+"""Reader-level tests, written after the reference's own (`stream/*_test.go`,
+`testutils/reader.go`, `mock/mock_test.go`): known buffers go in through an
+in-memory source, the GPU-backed operator's output is read with ReadFull and
+compared with the reference's expected values (KATs) and with the oracle.
+HOST contexts: what a cgo caller with Go slices would exercise."""
+import importlib
+import math
+
+import numpy as np
+import pytest
+
+from util import bits_equal, filled, in_epsilon, rand_c64, rand_i16, rand_u8, zeros
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hz():
+    return importlib.import_module("go-sdr_amd")
+
+
+@pytest.fixture(scope="module")
+def S(hz):
+    return importlib.import_module("go-sdr_amd.stream")
+
+
+@pytest.fixture(scope="module")
+def st(hz, S):
+    ctx = hz.Context(0, hz.MEM_HOST)
+    yield S.Stream(ctx)
+    ctx.close()
+
+
+def c(pair):
+    return np.complex64(complex(pair[0], pair[1]))
+
+
+def check_reader_contract(hz, S, reader):
+    """testutils.TestReader (testutils/reader.go:66-97): a buffer of the wrong
+    format must be refused with ErrSampleFormatMismatch."""
+    wrong = hz.FMT_I16 if reader.sample_format() != hz.FMT_I16 else hz.FMT_U8
+    with pytest.raises(hz.ErrSampleFormatMismatch):
+        reader.read(hz.make_samples(wrong, 16))
+
+
+def test_mock_u8_source_through_convert_reader(hz, S, st, orc):
+    """BASELINE config 1: u8 -> c64 on a 1 Mi-sample synthetic buffer through an
+    in-memory source and ConvertReader's 32 Ki blocks (mock/mock.go:149-163,
+    stream/convert.go:37-51)."""
+    n = 1 << 20
+    x = rand_u8(1, n)
+    r = st.convert_reader(S.BufferReader(x, 2_400_000, max_read=10_000), hz.FMT_C64)
+    assert r.sample_format() == hz.FMT_C64 and r.sample_rate() == 2_400_000
+    check_reader_contract(hz, S, r)
+    out = zeros("c64", n)
+    assert S.read_full(r, out) == n
+    want = zeros("c64", n)
+    orc.convert(want, x)
+    assert bits_equal(out, want)
+    with pytest.raises(S.EOF):
+        r.read(zeros("c64", 16))
+
+
+def test_convert_reader_drops_partial_block(hz, S, st):
+    """A trailing partial 32 Ki block never comes out (ReadFull fails first)."""
+    x = rand_u8(2, 32768 + 100)
+    r = st.convert_reader(S.BufferReader(x, 1000), hz.FMT_C64)
+    out = zeros("c64", 40000)
+    with pytest.raises(S.ErrUnexpectedEOF) as e:
+        S.read_full(r, out)
+    assert e.value.n == 32768
+
+
+def test_gain_reader(hz, S, st, kats):
+    """stream/gain_test.go:52-80."""
+    src = filled("c64", 1024, [10, 10])
+    g = st.gain(S.BufferReader(src, 10_000), 0.5)
+    check_reader_contract(hz, S, g)
+    out = zeros("c64", 1024)
+    assert S.read_full(g, out) == 1024
+    assert np.all(out == np.complex64(5 + 5j))
+    with pytest.raises(hz.ErrSampleFormatUnknown):  # stream/gain.go:45-46
+        st.gain(S.BufferReader(zeros("i16", 8), 1), 2.0).read(zeros("i16", 8))
+
+
+def test_add_reader_kats(hz, S, st, kats):
+    """stream/add_test.go:34-135."""
+    k = kats["stream_add_c64"]
+    rs = [S.BufferReader(filled("c64", k["n"], k["fill"]), 10_000) for _ in range(k["k"])]
+    mix = st.add(*rs)
+    out = zeros("c64", k["n"])
+    assert S.read_full(mix, out) == k["n"]
+    assert np.all(out == c(k["value"]))
+    for name, fmt in (("stream_add_i8", "i8"), ("stream_add_i16", "i16")):
+        k = kats[name]
+        rs = [S.BufferReader(filled(fmt, k["n"], k["fill"]), 10_000) for _ in range(k["k"])]
+        out = zeros(fmt, k["n"])
+        assert S.read_full(st.add(*rs), out) == k["n"]
+        assert np.all(out == np.asarray(k["value"]))
+    with pytest.raises(hz.ErrSampleFormatUnknown):  # u8 unsupported: stream/add.go:55-61
+        st.add(S.BufferReader(zeros("u8", 4), 1), S.BufferReader(zeros("u8", 4), 1))
+    with pytest.raises(hz.HzsdrError):
+        st.add()
+    one = S.BufferReader(zeros("c64", 4), 1)
+    assert st.add(one) is one  # stream/add.go:46-47
+
+
+def test_multiply_reader_cw(hz, S, st, orc, kats):
+    """stream/multiply_test.go:36-69: CW at phase 90 deg times -i is CW at phase 0."""
+    k = kats["rotate_cw"]
+    p0 = orc.cw(k["n"], k["freq"], k["rate"], 0.0)
+    p90 = orc.cw(k["n"], k["freq"], k["rate"], math.pi / 2)
+    r = st.multiply(S.BufferReader(p90, k["rate"]), c(k["m"]))
+    check_reader_contract(hz, S, r)
+    buf = zeros("c64", k["n"])
+    assert S.read_full(r, buf) == k["n"]
+    assert in_epsilon(1 + p0.real, 1 + buf.real, k["eps"]) and in_epsilon(1 + p0.imag, 1 + buf.imag, k["eps"])
+
+
+def test_multiply_reader_u8_i8_tables(hz, S, st, orc, kats):
+    """stream/multiply_test.go:71-112, 189-230: the LUT readers equal
+    ConvertBuffer -> Multiply -> ConvertBuffer exactly."""
+    k = kats["rotate_lut_u8"]
+    i = np.arange(k["n"], dtype=np.uint32) & 0xFFFF
+    vals = np.stack([i & 0xFF, (i & 0xFF00) >> 8], 1).astype(np.uint8)
+    cb, ref = zeros("c64", k["n"]), zeros("u8", k["n"])
+    st.ctx.convert(cb, vals)
+    st.ctx.rotate(cb, c(k["m"]))
+    st.ctx.convert(ref, cb)
+    r = st.multiply(S.BufferReader(vals, 1_800_000), c(k["m"]))
+    buf = zeros("u8", k["n"])
+    assert S.read_full(r, buf) == k["n"]
+    assert bits_equal(buf, ref)
+    k = kats["rotate_lut_i8"]
+    vals8 = np.stack([(i & 0xFF), ((i.astype(np.int64) & 0xFF00) >> 8) - 127], 1).astype(np.int8)
+    cb, ref = zeros("c64", k["n"]), zeros("i8", k["n"])
+    st.ctx.convert(cb, vals8)
+    st.ctx.rotate(cb, c(k["m"]))
+    st.ctx.convert(ref, cb)
+    r = st.multiply(S.BufferReader(vals8, 1_800_000), c(k["m"]))
+    buf = zeros("i8", k["n"])
+    assert S.read_full(r, buf) == k["n"]
+    assert bits_equal(buf, ref)
+    r.set_multiplier(1)  # SetMultiplier rebuilds the table
+    with pytest.raises(hz.ErrSampleFormatUnknown):
+        st.multiply(S.BufferReader(zeros("i16", 4), 1), 1j)
+
+
+def test_shifter_roundtrip(hz, S, st, orc, kats):
+    """stream/shifter_test.go:35-72."""
+    k = kats["shift_roundtrip"]
+    cw = orc.cw(k["n"], k["freq"], k["rate"], 0.0)
+    hi = st.shift_reader(S.BufferReader(cw, k["rate"], max_read=7000), k["shift"])
+    lo = st.shift_reader(hi, -k["shift"])
+    buf = zeros("c64", k["n"])
+    assert S.read_full(lo, buf) == k["n"]
+    assert in_epsilon(1 + cw.real, 1 + buf.real, k["eps"]) and in_epsilon(1 + cw.imag, 1 + buf.imag, k["eps"])
+    want = cw.copy()
+    a, b = orc.Shifter(k["rate"]), orc.Shifter(k["rate"])
+    a(k["shift"], want)
+    b(-k["shift"], want)
+    assert bits_equal(buf, want)  # state carried across the 7000-sample reads
+    with pytest.raises(hz.ErrSampleFormatUnknown):  # stream/shifter.go:90-95
+        st.shift_reader(S.BufferReader(zeros("u8", 4), 1), 1.0)
+
+
+def test_decimate_reader(hz, S, st, kats):
+    """stream/decimate_test.go:95-166."""
+    r = st.decimate_reader(S.BufferReader(zeros("u8", 16), 10000), 10)
+    assert r.sample_rate() == 1000 and r.sample_format() == hz.FMT_U8
+    k = kats["decimate_skippy"]
+    z = (np.arange(k["n"]) % 10).astype(np.uint8)
+    r = st.decimate_reader(S.BufferReader(np.stack([z, z], 1), 10000), k["factor"])
+    check_reader_contract(hz, S, r)
+    out = filled("u8", k["count"], [9, 9])
+    assert S.read_full(r, out) == k["count"]
+    assert np.all(out == 0)
+
+
+def test_downsample_reader(hz, S, st, kats):
+    """stream/downsample_test.go:34-93."""
+    k = kats["downsample_calc"]
+    e = (np.arange(k["n"]) % 4).astype(np.float32)
+    r = st.downsample_reader(S.BufferReader((e + 1j * e).astype(np.complex64), 10000), k["factor"])
+    assert r.sample_rate() == 2500 and r.sample_format() == hz.FMT_C64
+    out = zeros("c64", k["n"])
+    with pytest.raises(S.ErrUnexpectedEOF) as ex:  # the reference asserts an error here too
+        S.read_full(r, out)
+    assert ex.value.n == k["count"]
+    assert np.all(out[:k["count"]] == c(k["value"]))
+
+
+def test_convolution_reader(hz, S, st, orc):
+    """stream/convolution.go:36-82 (no reference test exists): vs the oracle's
+    float64-FFT restatement, relative L2 <= 2e-6."""
+    flen, nblk = 1024, 6
+    x = rand_c64(3, flen * nblk)
+    t = np.arange(flen) - (flen - 1) / 2
+    H = np.fft.fft((np.sinc(t / 8) / 8 * np.hamming(flen)) / flen).astype(np.complex64)
+    r = st.convolution_reader(S.BufferReader(x, 1_000_000, max_read=3000), H)
+    check_reader_contract(hz, S, r)
+    out = zeros("c64", flen * nblk)
+    assert S.read_full(r, out) == flen * nblk
+    want = zeros("c64", flen * nblk)
+    orc.convolution_reader(want, x, H)
+    err = np.linalg.norm(out.astype(np.complex128) - want) / np.linalg.norm(want.astype(np.complex128))
+    assert err < 2e-6
+    with pytest.raises(hz.ErrSampleFormatUnknown):
+        st.convolution_reader(S.BufferReader(zeros("u8", 8), 1), H)
+
+
+def test_read_beamform(hz, S, st, orc):
+    """stream/beamform.go:148-171 data path (the reference has no test for it):
+    four u8 channels, kerberos-style; bit-exact with convert -> rotate -> ordered add."""
+    n = 50_000
+    ch = [rand_u8(40 + i, n) for i in range(4)]
+    angles = S.beamform_angles(433e6, 30.0, [0.0, 0.1, 0.2, 0.3])
+    bf = st.read_beamform([S.BufferReader(x, 2_400_000, max_read=9000) for x in ch], angles)
+    assert bf.sample_format() == hz.FMT_C64 and bf.sample_rate() == 2_400_000
+    out = zeros("c64", n)
+    assert S.read_full(bf, out[:20_000]) == 20_000
+    chc = []
+    for x in ch:
+        y = zeros("c64", n)
+        orc.convert(y, x)
+        chc.append(y)
+    want = zeros("c64", n)
+    orc.beamform(want, chc, angles)
+    assert bits_equal(out[:20_000], want[:20_000])
+    # SetPhaseAngles applies between reads (stream/beamform.go:131-139)
+    new = S.beamform_angles(433e6, -10.0, [0.0, 0.1, 0.2, 0.3])
+    bf.set_phase_angles(new)
+    assert S.read_full(bf, out[20_000:]) == 30_000
+    want2 = zeros("c64", n)
+    orc.beamform(want2, chc, new)
+    assert bits_equal(out[20_000:], want2[20_000:])
+    with pytest.raises(hz.HzsdrError):
+        bf.set_phase_angles(new[:2])
+
+
+def test_fft_planner_conformance(hz, S, st, orc, kats):
+    """testutils.TestFFT run against the GPU Planner (testutils/fft.go:40-138)."""
+    k = kats["fft_forward_bins"]
+    for freq, idx in k["cases"]:
+        iq, out = orc.cw(k["n"], freq, k["rate"], 0.0), zeros("c64", k["n"])
+        plan = st.planner(iq, out, True)
+        plan.transform()
+        plan.close()
+        assert int(np.argmax(np.abs(out.astype(np.complex128)))) == idx
+    for a, b, _ in kats["fft_mismatch"]["cases"]:
+        with pytest.raises(hz.ErrDstTooSmall):
+            st.planner(zeros("c64", a), zeros("c64", b), True)
+
+
+def test_cxx_host_mirror_runs_reference_kats():
+    """The C++ host mirror (go-sdr_amd/cxx/hzsdr.hpp) over the C ABI: built with
+    g++ against libhzsdr_hip.so, runs the reference's KATs the way a cgo shim would."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "build", "test_host_mirror")
+    src = os.path.join(ROOT, "tests", "cxx", "test_host_mirror.cpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + ROOT, src, "-L" + os.path.join(ROOT, "go-sdr_amd"),
+                               "-lhzsdr_hip", "-L/opt/rocm/lib", "-Wl,-rpath," + os.path.join(ROOT, "go-sdr_amd"),
+                               "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "go-sdr_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    p = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "all host-mirror tests passed" in p.stdout
