@@ -66,6 +66,38 @@ __device__ __forceinline__ float2 ew_apply(const EwProgram &P, float2 v, uint64_
     return v;
 }
 
+// The same program over W consecutive samples j0 .. j0+W-1 at once: the op loop is
+// outside, the sample loop inside and unrolled, so the W independent Sincos /
+// multiply chains interleave (instruction-level parallelism within a lane; the
+// one-sample form serialises them behind the rolled op loop).
+template <int W>
+__device__ __forceinline__ void ew_apply_n(const EwProgram &P, float2 (&v)[W], uint64_t j0, NcoWin w) {
+    double ts[W];
+    bool have_ts = false;
+#pragma unroll 1
+    for (int i = 0; i < P.n; i++) {  // uniform
+        const EwOp &o = P.op[i];
+        if (o.kind == EW_SCALE) {
+#pragma unroll
+            for (int l = 0; l < W; l++) v[l] = make_float2(__fmul_rn(v[l].x, o.a), __fmul_rn(v[l].y, o.a));
+        } else if (o.kind == EW_ROTATE) {
+#pragma unroll
+            for (int l = 0; l < W; l++) v[l] = go_cmul(v[l], make_float2(o.a, o.b));
+        } else {
+            if (!have_ts) {
+#pragma unroll
+                for (int l = 0; l < W; l++) ts[l] = nco_ts(P.segs, w, j0 + l);
+                have_ts = true;
+            }
+            double s[W], c[W];
+#pragma unroll
+            for (int l = 0; l < W; l++) go_sincos(__dmul_rn(o.tau_shift, ts[l]), s[l], c[l]);
+#pragma unroll
+            for (int l = 0; l < W; l++) v[l] = go_cmul(v[l], make_float2((float)c[l], (float)s[l]));
+        }
+    }
+}
+
 template <int FMT> struct Raw;
 template <> struct Raw<HZSDR_FMT_C64> {
     using t = float2;
@@ -120,7 +152,8 @@ __global__ __launch_bounds__(kThreads) void chain_map_kernel(const void *__restr
             if (i < nvec) {
                 OV o;
 #pragma unroll
-                for (int l = 0; l < W; l++) o.v[l] = ew_apply(P, Raw<FMT>::cvt(x[u].v[l]), base + i * W + l, w);
+                for (int l = 0; l < W; l++) o.v[l] = Raw<FMT>::cvt(x[u].v[l]);
+                ew_apply_n<W>(P, o.v, base + i * W, w);
                 ((OV *)out)[i] = o;
             }
         }
@@ -202,8 +235,10 @@ __device__ __forceinline__ void stage_block(float2 *lds, const void *in, const E
         if (live) {
             if (vec_ok && p >= 0 && (size_t)(p + 2) <= n_in) {
                 RV x = *reinterpret_cast<const RV *>((const R *)in + p);
-                a = ew_apply(P, Raw<FMT>::cvt(x.v[0]), (uint64_t)p, w);
-                b = ew_apply(P, Raw<FMT>::cvt(x.v[1]), (uint64_t)p + 1, w);
+                float2 ab[2] = {Raw<FMT>::cvt(x.v[0]), Raw<FMT>::cvt(x.v[1])};
+                ew_apply_n<2>(P, ab, (uint64_t)p, w);
+                a = ab[0];
+                b = ab[1];
             } else {
                 if (p < 0) { if (hist) a = hist[p + off]; }
                 else if ((size_t)p < n_in) a = chain_sample<FMT>(in, P, (uint64_t)p);
@@ -366,8 +401,10 @@ __device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const
         if (live) {
             if (vec_ok && p >= 0 && (size_t)(p + 2) <= n_in) {
                 RV x = *reinterpret_cast<const RV *>((const R *)in + p);
-                a = ew_apply(P, Raw<FMT>::cvt(x.v[0]), (uint64_t)p, w);
-                b = ew_apply(P, Raw<FMT>::cvt(x.v[1]), (uint64_t)p + 1, w);
+                float2 ab[2] = {Raw<FMT>::cvt(x.v[0]), Raw<FMT>::cvt(x.v[1])};
+                ew_apply_n<2>(P, ab, (uint64_t)p, w);
+                a = ab[0];
+                b = ab[1];
             } else {
                 if (p < 0) { if (hist) a = hist[p + off]; }
                 else if ((size_t)p < n_in) a = chain_sample<FMT>(in, P, (uint64_t)p);

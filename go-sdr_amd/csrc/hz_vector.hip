@@ -205,16 +205,26 @@ __global__ __launch_bounds__(kThreads) void beamform_kernel(float2 *out, PtrList
 #pragma unroll
             for (int l = 0; l < W; l++) acc.v[l] = make_float2(0.0f, 0.0f);
         }
-        for (int c = 0; c < k; c++) {
-            RV x = ((const RV *)chans.p[c])[i];
-            const float2 w = wl.w[c];
-            const bool ident = wl.identity[c];
+        // channels in groups of four: the group's loads are issued together (four
+        // 16-byte requests in flight per lane), then consumed in channel order
+        for (int c0 = 0; c0 < k; c0 += 4) {
+            RV x[4];
 #pragma unroll
-            for (int l = 0; l < W; l++) {
-                float2 y = Chan<FMT>::cvt(x.v[l]);
-                if (!ident) y = go_cmul(y, w);
-                acc.v[l].x = __fadd_rn(acc.v[l].x, y.x);
-                acc.v[l].y = __fadd_rn(acc.v[l].y, y.y);
+            for (int g = 0; g < 4; g++)
+                if (c0 + g < k) x[g] = ((const RV *)chans.p[c0 + g])[i];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                if (c0 + g < k) {
+                    const float2 w = wl.w[c0 + g];
+                    const bool ident = wl.identity[c0 + g];
+#pragma unroll
+                    for (int l = 0; l < W; l++) {
+                        float2 y = Chan<FMT>::cvt(x[g].v[l]);
+                        if (!ident) y = go_cmul(y, w);
+                        acc.v[l].x = __fadd_rn(acc.v[l].x, y.x);
+                        acc.v[l].y = __fadd_rn(acc.v[l].y, y.y);
+                    }
+                }
             }
         }
         ((OV *)out)[i] = acc;
