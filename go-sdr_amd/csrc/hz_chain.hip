@@ -213,12 +213,24 @@ __device__ __forceinline__ void conv_store(float2 *out, size_t g, float2 v, unsi
 // ROLLED loop (two samples per lane per trip: one 16-B LDS store, the float64
 // sincos of the Shift stage instantiated twice, not N/TPT times -- the unrolled
 // register-direct form needs 256 VGPRs and drops to one wave per SIMD).
+// FIR history for the next run = the last `off` samples of (old history ++ this
+// run): every staged position p in [n_in - off, n_in) is written to
+// new_hist[p - (n_in - off)] by whichever block stages it (blocks overlap by
+// N - hop positions; both write the same value), so no second kernel is needed.
+__device__ __forceinline__ void keep_history(float2 *new_hist, int64_t p, size_t n_in, unsigned off,
+                                             bool live, float2 a, float2 b) {
+    if (!new_hist) return;  // uniform
+    const int64_t h0 = (int64_t)n_in - (int64_t)off;
+    if (live && p >= h0 && p < (int64_t)n_in) new_hist[p - h0] = a;
+    if (live && p + 1 >= h0 && p + 1 < (int64_t)n_in) new_hist[p + 1 - h0] = b;
+}
+
 // lds[i] = sample at stream position p0 + i; positions < 0 come from `hist`
 // (`off` entries, may be null = zeros), positions >= n_in are zero.
 template <int N, int FMT>
 __device__ __forceinline__ void stage_block(float2 *lds, const void *in, const EwProgram &P, int64_t p0,
                                             size_t n_in, const float2 *hist, unsigned off, int lane,
-                                            bool live) {
+                                            bool live, float2 *new_hist = nullptr) {
     using R = typename Raw<FMT>::t;
     constexpr int TPT = fft_tpt(N);
     struct alignas(sizeof(R) * 2) RV { R v[2]; };
@@ -246,6 +258,7 @@ __device__ __forceinline__ void stage_block(float2 *lds, const void *in, const E
                 else if ((size_t)(p + 1) < n_in) b = chain_sample<FMT>(in, P, (uint64_t)p + 1);
             }
         }
+        keep_history(new_hist, p, n_in, off, live, a, b);
         *reinterpret_cast<float4 *>(lds + i0) = make_float4(a.x, a.y, b.x, b.y);
     }
 }
@@ -314,7 +327,8 @@ __global__ __launch_bounds__(fft_block(N), fft_waves(N)) void conv_blocks_kernel
 // outputs picked on the decimation grid.
 template <int N, int FMT, int FOLD>
 __global__ __launch_bounds__(fft_block(N), fft_waves(N)) void fir_decimate_kernel(
-    const void *in, float2 *out, const float2 *__restrict__ hist, const float2 *__restrict__ hfreq,
+    const void *in, float2 *out, const float2 *__restrict__ hist, float2 *__restrict__ new_hist,
+    const float2 *__restrict__ hfreq,
     const float2 *__restrict__ tw, const float2 *__restrict__ tw_small, size_t nblocks, size_t n_in,
     unsigned hop, unsigned off, unsigned D, EwProgram P) {
     constexpr int TPT = fft_tpt(N), CNT = N / TPT;
@@ -325,7 +339,7 @@ __global__ __launch_bounds__(fft_block(N), fft_waves(N)) void fir_decimate_kerne
         const size_t b = blockIdx.x;
         FftRegs<N> R;
         __syncthreads();
-        stage_block<N, FMT>(lds, in, P, (int64_t)(b * hop) - (int64_t)off, n_in, hist, off, lane, true);
+        stage_block<N, FMT>(lds, in, P, (int64_t)(b * hop) - (int64_t)off, n_in, hist, off, lane, true, new_hist);
         __syncthreads();
         load_edge_from_lds<N>(R, lds, lane);
         fft_forward_regs<N, true>(R, lds, tw, lane);
@@ -385,7 +399,7 @@ __global__ __launch_bounds__(fft_block(N), fft_waves(N)) void fir_decimate_kerne
 template <int N, int FMT>
 __device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const EwProgram &P, int64_t p0,
                                               size_t n_in, const float2 *hist, unsigned off, int lane,
-                                              bool live) {
+                                              bool live, float2 *new_hist = nullptr) {
     using R = typename Raw<FMT>::t;
     constexpr int TPT = f16::tpt(N);
     struct alignas(sizeof(R) * 2) RV { R v[2]; };
@@ -412,6 +426,7 @@ __device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const
                 else if ((size_t)(p + 1) < n_in) b = chain_sample<FMT>(in, P, (uint64_t)p + 1);
             }
         }
+        keep_history(new_hist, p, n_in, off, live, a, b);
         const int q = f16::pad(i0);  // i0 even: i0 and i0+1 share a 16-element row
         lds[q] = a;
         lds[q + 1] = b;
@@ -459,7 +474,8 @@ __global__ __launch_bounds__(f16::block(N)) void conv_blocks_kernel16(const void
 // workgroup barriers stay uniform).  FOLD = 0: full backward transform + pick.
 template <int N, int FMT, int FOLD>
 __global__ __launch_bounds__(f16::block(N)) void fir_decimate_kernel16(
-    const void *in, float2 *out, const float2 *__restrict__ hist, const float2 *__restrict__ hfreq,
+    const void *in, float2 *out, const float2 *__restrict__ hist, float2 *__restrict__ new_hist,
+    const float2 *__restrict__ hfreq,
     const float2 *__restrict__ tw, const float2 *__restrict__ tw_small, size_t nblocks, size_t n_in,
     unsigned hop, unsigned off, unsigned D, EwProgram P) {
     constexpr int R0 = f16::first_radix(N), TPT = f16::tpt(N);
@@ -470,7 +486,7 @@ __global__ __launch_bounds__(f16::block(N)) void fir_decimate_kernel16(
     const size_t b = (size_t)blockIdx.x * f16::xpb(N) + sub;
     const bool live = b < nblocks;
     float2 v[16];
-    stage_block16<N, FMT>(lds, in, P, (int64_t)(b * hop) - (int64_t)off, n_in, hist, off, lane, live);
+    stage_block16<N, FMT>(lds, in, P, (int64_t)(b * hop) - (int64_t)off, n_in, hist, off, lane, live, new_hist);
     __syncthreads();
     f16::load_lds<N, R0>(v, lds, lane);
     f16::forward<N, true>(v, lds, tw, lane);
@@ -704,7 +720,7 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
         const unsigned D = c->factor;
 #define HZ_FIR(N, FOLD)                                                                                  \
     hipLaunchKernelGGL((fir_decimate_kernel<N, FMT, FOLD>), dim3(grid), dim3(fft_block(N)), 0,           \
-                       ctx->stream, in, (float2 *)out, hist, (const float2 *)c->hfreq, tw, tws, nblocks, \
+                       ctx->stream, in, (float2 *)out, hist, nhist, (const float2 *)c->hfreq, tw, tws, nblocks, \
                        n_cons, c->hop, c->off, D, P)
 #define HZ_FIR_N(N)                                                                      \
     do {                                                                                 \
@@ -722,7 +738,7 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
 #define HZ_FIR16(N, FOLD)                                                                               \
     hipLaunchKernelGGL((fir_decimate_kernel16<N, FMT, FOLD>),                                           \
                        dim3((unsigned)((nblocks + f16::xpb(N) - 1) / f16::xpb(N))), dim3(f16::block(N)), \
-                       0, ctx->stream, in, (float2 *)out, hist, (const float2 *)c->hfreq, tw, tws,      \
+                       0, ctx->stream, in, (float2 *)out, hist, nhist, (const float2 *)c->hfreq, tw, tws, \
                        nblocks, n_cons, c->hop, c->off, D, P)
 #define HZ_FIR16_FOLD(N, F)                                                            \
     if (D == F) {                                                                      \
@@ -754,9 +770,7 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
 #undef HZ_FIR16
 #undef HZ_FIR_N
 #undef HZ_FIR
-        hipLaunchKernelGGL((fir_history_kernel<FMT>), dim3(blocks_for(ctx, c->off)), dim3(kThreads), 0,
-                           ctx->stream, in, hist, nhist, n_cons, c->off, P);
-        c->hist_cur ^= 1;
+        c->hist_cur ^= 1;  // the kernel wrote the next run's history into nhist
         break;
     }
     }
