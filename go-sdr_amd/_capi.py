@@ -14,6 +14,36 @@ if not os.path.exists(LIB_PATH):
         "libhzsdr_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
         "or `make -C go-sdr_amd/csrc` (needs hipcc); there is no CPU fallback")
 
+
+
+def _one_hip_runtime():
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64
+    (same SONAME as /opt/rocm's).  If this library is loaded first it binds the
+    system copy, a later `import torch` maps the bundled copy as well, and the
+    second runtime to initialise finds no GPU ("No HIP GPUs are available").
+    So when torch is installed but not imported yet, map ITS runtime first: the
+    dynamic loader then satisfies our DT_NEEDED libamdhip64.so.7 with it, and
+    torch's own import later reuses the same mapping.  Without torch (the cgo /
+    C++ case) nothing happens and the system ROCm runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        with open("/proc/self/maps") as f:
+            if any("libamdhip64" in line for line in f):
+                return
+    except OSError:
+        pass
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
+_one_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
 FMT_C64, FMT_U8, FMT_I16, FMT_I8 = 1, 2, 3, 4

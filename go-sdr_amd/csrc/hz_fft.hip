@@ -182,11 +182,178 @@ static int fft_global(hzsdr_ctx *ctx, const float2 *in, float2 *out, size_t n, s
     return HZSDR_OK;
 }
 
+// ---- two-step path for N = N1 * N2 = 2^16 .. 2^24 (kerberos: 64 Ki, graft: 256 Ki) ----------
+//
+//   n = N2*n1 + n2,  k = k1 + N1*k2:
+//   X[k1 + N1*k2] = sum_n2 W_N2^(n2 k2) * [ W_N^(n2 k1) * sum_n1 x[N2*n1 + n2] W_N1^(n1 k1) ]
+//
+// Kernel 1 ("columns"): a workgroup takes C = 4096/N1 adjacent columns n2, runs their
+// N1-point transforms on the radix-16 core, applies the W_N^(n2 k1) twiddle and writes
+// A[k1][n2].  Lanes are mapped column-fastest, so both the strided input rows and the
+// A rows are touched in C*8-byte contiguous pieces.
+// Kernel 2 ("rows"): a workgroup takes C = 4096/N2 adjacent rows k1 of A (contiguous
+// reads), runs their N2-point transforms, transposes the C x N2 result through LDS and
+// writes X[k1 + N1*k2] in C*8-byte pieces.
+// The big twiddle W_N^m (m < N) is the product of two table entries, m = a*2^s + b:
+// two tables of 2^ceil(L/2) entries instead of one of N.
+
+struct BigTw {
+    const float2 *hi, *lo;  // hi[a] = exp(-2 pi i a 2^s / N), lo[b] = exp(-2 pi i b / N)
+    int s;
+};
+
+__device__ __forceinline__ float2 big_twiddle(const BigTw &t, uint32_t m, bool inv) {
+    const float2 a = t.hi[m >> t.s], b = t.lo[m & ((1u << t.s) - 1)];
+    float2 w = f16::cmul(a, b);
+    if (inv) w.y = -w.y;
+    return w;
+}
+
+template <int N1, bool FWD>
+__global__ __launch_bounds__(256) void fft2_cols_kernel(const float2 *__restrict__ in, float2 *__restrict__ a_out,
+                                                        const float2 *__restrict__ tw1, BigTw bt,
+                                                        uint32_t n2_total) {
+    constexpr int C = 4096 / N1, TPT = f16::tpt(N1), R0 = f16::first_radix(N1);
+    static_assert(C * TPT == 256, "one 256-lane workgroup per column tile");
+    __shared__ float2 lds_all[C * f16::lds_elems(N1)];
+    const int sub = threadIdx.x % C, lane = threadIdx.x / C;  // column-fastest
+    float2 *lds = lds_all + sub * f16::lds_elems(N1);
+    const uint32_t n2 = blockIdx.x * C + sub;
+    const size_t base = (size_t)blockIdx.y * N1 * n2_total;  // batch
+    float2 v[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int n1 = FWD ? f16::edge_index<N1, R0>(q, lane) : f16::edge_index<N1, 16>(q, lane);
+        v[q] = in[base + (size_t)n1 * n2_total + n2];
+    }
+    if constexpr (FWD) f16::forward<N1>(v, lds, tw1, lane); else f16::backward<N1>(v, lds, tw1, lane);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const uint32_t k1 = FWD ? f16::edge_index<N1, 16>(q, lane) : f16::edge_index<N1, R0>(q, lane);
+        const float2 w = big_twiddle(bt, n2 * k1, !FWD);
+        a_out[base + (size_t)k1 * n2_total + n2] = f16::cmul(v[q], w);
+    }
+}
+
+template <int N2, bool FWD>
+__global__ __launch_bounds__(256) void fft2_rows_kernel(const float2 *__restrict__ a_in, float2 *__restrict__ out,
+                                                        const float2 *__restrict__ tw2, uint32_t n1_total) {
+    constexpr int C = 4096 / N2, TPT = f16::tpt(N2), R0 = f16::first_radix(N2);
+    static_assert(C * TPT == 256, "one 256-lane workgroup per row tile");
+    __shared__ float2 lds_all[C * f16::lds_elems(N2)];
+    const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;  // lane-fastest: rows are contiguous
+    float2 *lds = lds_all + sub * f16::lds_elems(N2);
+    const uint32_t k1 = blockIdx.x * C + sub;
+    const size_t base = (size_t)blockIdx.y * N2 * n1_total;
+    float2 v[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int n2 = FWD ? f16::edge_index<N2, R0>(q, lane) : f16::edge_index<N2, 16>(q, lane);
+        v[q] = a_in[base + (size_t)k1 * N2 + n2];
+    }
+    if constexpr (FWD) f16::forward<N2>(v, lds, tw2, lane); else f16::backward<N2>(v, lds, tw2, lane);
+    __syncthreads();  // the transform's last LDS reads are done
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int k2 = FWD ? f16::edge_index<N2, 16>(q, lane) : f16::edge_index<N2, R0>(q, lane);
+        lds[f16::pad(k2)] = v[q];
+    }
+    __syncthreads();
+    // X[k1 + N1*k2]: C adjacent k1 per k2
+    for (int e = threadIdx.x; e < C * N2; e += 256) {
+        const int s2 = e % C, k2 = e / C;
+        out[base + (size_t)k2 * n1_total + blockIdx.x * C + s2] = lds_all[s2 * f16::lds_elems(N2) + f16::pad(k2)];
+    }
+}
+
+static int get_big_twiddles(hzsdr_ctx *ctx, size_t n, BigTw *bt) {
+    int L = 0;
+    while (((size_t)1 << L) < n) L++;
+    const int s = L / 2;
+    const size_t n_lo = (size_t)1 << s, n_hi = (size_t)1 << (L - s);
+    const size_t key = (n << 1) | 1;  // shares the cache with the per-N tables (even keys)
+    auto it = ctx->twiddles.find(key);
+    float2 *d = nullptr;
+    if (it != ctx->twiddles.end()) {
+        d = (float2 *)it->second;
+    } else {
+        std::vector<float2> h(n_hi + n_lo);
+        for (size_t a = 0; a < n_hi; a++) {
+            double ang = -2.0 * M_PI * (double)(a << s) / (double)n;
+            h[a] = make_float2((float)cos(ang), (float)sin(ang));
+        }
+        for (size_t b = 0; b < n_lo; b++) {
+            double ang = -2.0 * M_PI * (double)b / (double)n;
+            h[n_hi + b] = make_float2((float)cos(ang), (float)sin(ang));
+        }
+        HZ_HIP(ctx, hipMalloc((void **)&d, h.size() * sizeof(float2)));
+        hipError_t e = hipMemcpy(d, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(d);
+            return hip_fail(ctx, e, "twiddle upload", __FILE__, __LINE__);
+        }
+        ctx->twiddles[key] = d;
+    }
+    bt->hi = d;
+    bt->lo = d + n_hi;
+    bt->s = s;
+    return HZSDR_OK;
+}
+
+template <int N1> static void launch_cols(hzsdr_ctx *ctx, const float2 *in, float2 *a, const float2 *tw1,
+                                          const BigTw &bt, size_t n2, size_t batch, bool fwd) {
+    constexpr int C = 4096 / N1;
+    dim3 grid((unsigned)(n2 / C), (unsigned)batch);
+    if (fwd) hipLaunchKernelGGL((fft2_cols_kernel<N1, true>), grid, dim3(256), 0, ctx->stream, in, a, tw1, bt, (uint32_t)n2);
+    else hipLaunchKernelGGL((fft2_cols_kernel<N1, false>), grid, dim3(256), 0, ctx->stream, in, a, tw1, bt, (uint32_t)n2);
+}
+template <int N2> static void launch_rows(hzsdr_ctx *ctx, const float2 *a, float2 *out, const float2 *tw2,
+                                          size_t n1, size_t batch, bool fwd) {
+    constexpr int C = 4096 / N2;
+    dim3 grid((unsigned)(n1 / C), (unsigned)batch);
+    if (fwd) hipLaunchKernelGGL((fft2_rows_kernel<N2, true>), grid, dim3(256), 0, ctx->stream, a, out, tw2, (uint32_t)n1);
+    else hipLaunchKernelGGL((fft2_rows_kernel<N2, false>), grid, dim3(256), 0, ctx->stream, a, out, tw2, (uint32_t)n1);
+}
+
+static bool fft_two_step_ok(size_t n) { return n >= ((size_t)1 << 16) && n <= ((size_t)1 << 24) && (n & (n - 1)) == 0; }
+
+static int fft_two_step(hzsdr_ctx *ctx, const float2 *in, float2 *out, size_t n, size_t batch, bool fwd) {
+    int L = 0;
+    while (((size_t)1 << L) < n) L++;
+    // N1 as small as the radix-16 core allows (best column coalescing), N2 = N / N1 <= 4096
+    int l1 = 8;
+    while (L - l1 > 12) l1++;
+    const size_t n1 = (size_t)1 << l1, n2 = n >> l1;
+    const float2 *tw1, *tw2;
+    BigTw bt;
+    HZ_TRY(get_twiddles(ctx, n1, &tw1));
+    HZ_TRY(get_twiddles(ctx, n2, &tw2));
+    HZ_TRY(get_big_twiddles(ctx, n, &bt));
+    HZ_TRY(ensure_slot(ctx, 10, n * batch * sizeof(float2)));
+    float2 *a = (float2 *)ctx->slots[10].ptr;
+    switch (n1) {
+    case 256: launch_cols<256>(ctx, in, a, tw1, bt, n2, batch, fwd); break;
+    case 512: launch_cols<512>(ctx, in, a, tw1, bt, n2, batch, fwd); break;
+    case 1024: launch_cols<1024>(ctx, in, a, tw1, bt, n2, batch, fwd); break;
+    case 2048: launch_cols<2048>(ctx, in, a, tw1, bt, n2, batch, fwd); break;
+    default: launch_cols<4096>(ctx, in, a, tw1, bt, n2, batch, fwd); break;
+    }
+    switch (n2) {
+    case 256: launch_rows<256>(ctx, a, out, tw2, n1, batch, fwd); break;
+    case 512: launch_rows<512>(ctx, a, out, tw2, n1, batch, fwd); break;
+    case 1024: launch_rows<1024>(ctx, a, out, tw2, n1, batch, fwd); break;
+    case 2048: launch_rows<2048>(ctx, a, out, tw2, n1, batch, fwd); break;
+    default: launch_rows<4096>(ctx, a, out, tw2, n1, batch, fwd); break;
+    }
+    return HZSDR_OK;
+}
+
 // Transform `batch` consecutive length-n blocks of device memory.
 int fft_device(hzsdr_ctx *ctx, const void *in, void *out, size_t n, size_t batch, bool fwd) {
     if (batch == 0 || n == 0) return HZSDR_OK;
     const float2 *i = (const float2 *)in;
     float2 *o = (float2 *)out;
+    if (fft_two_step_ok(n)) return fft_two_step(ctx, i, o, n, batch, fwd);
     if (!fft_lds_ok(n)) return fft_global(ctx, i, o, n, batch, fwd);
     const float2 *tw;
     HZ_TRY(get_twiddles(ctx, n, &tw));

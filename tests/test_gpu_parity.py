@@ -475,12 +475,15 @@ def _rel_l2(got, want):
     return float(np.linalg.norm(got.astype(np.complex128) - want) / max(np.linalg.norm(want), 1e-30))
 
 
-@pytest.mark.parametrize("n", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536])
+@pytest.mark.parametrize("n", [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536,
+                               1 << 17, 1 << 18, 1 << 20, 1 << 22])
 def test_fft_against_float64(env, n):
     """Tolerance: relative L2 error <= 3e-7 * log2(N) + 1e-7 against numpy's
-    float64 FFT (float32 butterflies; the reference pins no values: SURVEY 2b)."""
+    float64 FFT (float32 butterflies; the reference pins no values: SURVEY 2b).
+    Sizes: radix-4 core (4..128, 8192), radix-16 core (256..4096), global radix-2
+    (1, 2, 2^14), two-step (2^16..2^24: kerberos 64 Ki, graft 256 Ki)."""
     tol = 3e-7 * max(1, math.log2(n)) + 1e-7
-    batch = 3 if n <= 8192 else 1
+    batch = 3 if n <= 8192 else (2 if n <= (1 << 18) else 1)
     x = rand_c64(n, n * batch)
     X = np.fft.fft(x.astype(np.complex128).reshape(batch, n), axis=1).reshape(-1)
     iq, fr = env.put(x), env.zeros("c64", n * batch)
