@@ -320,6 +320,17 @@ class Context:
             self._ck(lib.hzsdr_beamform_partial(self._h, _ptr(out), fmt, arr, wp, k, length(out),
                                                 1 if accumulate else 0))
 
+    # -- rtl/kerberos coherent sync reductions (align.go:128-149, 257-266) --
+    def peak_lag(self, corr):
+        lag = C.c_int64(0)
+        self._ck(lib.hzsdr_peak_lag(self._h, _ptr(corr), length(corr), C.byref(lag)))
+        return lag.value
+
+    def mean_phase(self, a, b):
+        v = C.c_double(0.0)
+        self._ck(lib.hzsdr_mean_phase(self._h, _ptr(a), _ptr(b), length(a), C.byref(v)))
+        return v.value
+
     def chain(self, src_fmt, sample_rate=0):
         return Chain(self, src_fmt, sample_rate)
 

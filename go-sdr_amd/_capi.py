@@ -122,6 +122,8 @@ SIGNATURES = {
     "hzsdr_beamform_angles": (i32, [f64, f64, C.POINTER(f64), i32, C.POINTER(f32)]),
     "hzsdr_beamform": (i32, [vp, vp, i32, pvp, C.POINTER(f32), i32, sz]),
     "hzsdr_beamform_partial": (i32, [vp, vp, i32, pvp, C.POINTER(f32), i32, sz, i32]),
+    "hzsdr_peak_lag": (i32, [vp, vp, sz, C.POINTER(i64)]),
+    "hzsdr_mean_phase": (i32, [vp, vp, vp, sz, C.POINTER(f64)]),
     "hzsdr_chain_create": (i32, [vp, i32, u64, pvp]),
     "hzsdr_chain_shift": (i32, [vp, f64]),
     "hzsdr_chain_gain": (i32, [vp, f32]),

@@ -1,0 +1,77 @@
+"""rtl/kerberos coherent-sync DSP on the GPU (a "next" row):
+the step right before Beamform.  Mirrors rtl/kerberos/internal/align.go:
+
+    CrossCorrelater.Correlate   two forward FFTs, bins1 * conj(bins2), backward FFT
+    checkAlignment              peak of |corr|^2 -> sample lag per channel
+    PhaseOffsets                mean phase of a * conj(b) -> unit rotation per channel
+
+Hardware I/O (the four RTL dongles) is out of scope; buffers come from Readers.
+"""
+import math
+
+import numpy as np
+
+from . import FMT_C64, ErrDstTooSmall, length, make_samples
+from .stream import read_full
+
+SYNC_LENGTH = 1024 * 64  # align.go:248, :278
+
+
+class CrossCorrelater:
+    """align.go:36-106.  Owns its buffers like the reference (bufIn1/2, bufOut)."""
+
+    def __init__(self, ctx, fft_length):
+        self.ctx, self.n = ctx, fft_length
+        self.in1 = make_samples(FMT_C64, fft_length)
+        self.in2 = make_samples(FMT_C64, fft_length)
+        self.out = make_samples(FMT_C64, fft_length)
+        self._cc = ctx.cross_correlate(self.out, self.in1, self.in2)
+
+    def correlate(self, buf1, buf2):
+        if length(buf1) != self.n or length(buf2) != self.n:  # align.go:63-65
+            raise ErrDstTooSmall("sdr: destination sample buffer is too small")
+        self.in1[:] = buf1
+        self.in2[:] = buf2
+        self._cc()
+        return self.out.copy()
+
+    def close(self):
+        self._cc.close()
+
+
+def read_buffers(readers, bufs):
+    for r, b in zip(readers, bufs):
+        read_full(r, b)
+
+
+def check_alignment(ctx, readers, bufs, reference_quirk=False):
+    """align.go:112-153.  Lag of each channel against channel 0.  The reference
+    correlates bufs[0] with bufs[1] for EVERY i (align.go:125 passes bufs[1], not
+    bufs[i]); reference_quirk=True reproduces that, the default correlates with
+    bufs[i] as the surrounding code intends."""
+    ccr = CrossCorrelater(ctx, length(bufs[0]))
+    try:
+        read_buffers(readers, bufs)
+        ret = [0] * len(readers)
+        for i in range(1, len(bufs)):
+            cc = ccr.correlate(bufs[0], bufs[1] if reference_quirk else bufs[i])
+            ret[i] = ctx.peak_lag(cc)
+        return ret
+    finally:
+        ccr.close()
+
+
+def phase_offsets(ctx, readers, n=SYNC_LENGTH):
+    """align.go:244-271: per-channel rotation that cancels its mean phase against
+    channel 0.  phases[0] = 1 before the division is the reference's own quirk."""
+    bufs = [make_samples(FMT_C64, n) for _ in readers]
+    read_buffers(readers, bufs)
+    phases = [0.0] * len(readers)
+    for j in range(1, len(bufs)):
+        phases[j] = ctx.mean_phase(bufs[0], bufs[j]) * n  # the reference divides below
+    phases[0] = 1.0
+    ret = np.zeros(len(readers), np.complex64)
+    for i, p in enumerate(phases):
+        p /= float(n)
+        ret[i] = np.complex64(complex(math.cos(p), math.sin(p)))  # cmplx.Rect(1, p)
+    return ret

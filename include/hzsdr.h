@@ -268,6 +268,20 @@ int hzsdr_beamform_partial(hzsdr_ctx *ctx, void *out_c64, int format,
                            const void *const *channels, const float *weights_c64, int count,
                            size_t n, int accumulate);
 
+/* ---- rtl/kerberos coherent sync reductions (a "next" row) -- */
+
+/* The peak search of checkAlignment, rtl/kerberos/internal/align.go:128-149, over
+ * a cross-correlation (fft.CrossCorrelate / hzsdr_convolve_create with
+ * HZSDR_CONV_CROSS_CORRELATE): index of the largest float64(re*re + im*im)
+ * (float32 products), exact zeros skipped, first maximum wins, indices above n/2
+ * folded to negative lags.  *lag = -1 when every element is zero. */
+int hzsdr_peak_lag(hzsdr_ctx *ctx, const void *corr_c64, size_t n, int64_t *lag);
+/* The inner loop of PhaseOffsets for one channel pair, align.go:257-266: the
+ * mean over i of Phase(a[i] * conj(b[i])) in float64 (radians).  The caller
+ * finishes with cmplx.Rect(1, mean) as the reference does. */
+int hzsdr_mean_phase(hzsdr_ctx *ctx, const void *a_c64, const void *b_c64, size_t n,
+                     double *mean_phase);
+
 /* ---- fused operator chains (north_star: one kernel per buffer) ----------- */
 
 /* A chain is the GPU form of nested stream.* Readers over one source

@@ -802,3 +802,45 @@ void orc_cw(float *buf, long n, double freq, long sample_rate, double phase) {
         buf[2 * i + 1] = (float)sin(tau * freq * now + phase);
     }
 }
+
+/* ------------------------------------------------------------------ */
+/* rtl/kerberos coherent sync ("next" row)        */
+/* ------------------------------------------------------------------ */
+
+/* rtl/kerberos/internal/align.go:128-149 (checkAlignment): index of the largest
+ * float64(re*re + im*im) (float32 products and sum, un-fused), exact zeros
+ * skipped, first maximum wins; indices above n/2 fold to negative lags.
+ * Returns 0 and *lag = -1 when every element is zero (maxPowI stays -1). */
+int orc_peak_lag(const float *corr, long n, long *lag) {
+    double max_pow = -INFINITY;
+    long max_i = -1;
+    for (long i = 0; i < n; i++) {
+        float re = corr[2 * i], im = corr[2 * i + 1];
+        if (re == 0.0f && im == 0.0f)
+            continue;
+        float rr = re * re, ii = im * im;
+        double pow = (double)(rr + ii);
+        if (pow > max_pow) {
+            max_pow = pow;
+            max_i = i;
+        }
+    }
+    if (max_i > n / 2)
+        max_i -= n;
+    *lag = max_i;
+    return ORC_OK;
+}
+
+/* rtl/kerberos/internal/align.go:257-262 (PhaseOffsets inner loop for one pair):
+ * sum over i of cmplx.Phase(complex128(a[i] * conj(b[i]))) = atan2(im, re) in
+ * float64, accumulated in order, divided by n.  math.Atan2 is Go's own (Cephes);
+ * libm's atan2 is used here: last-bit parity UNPINNED, like Sincos. */
+double orc_mean_phase(const float *a, const float *b, long n) {
+    double acc = 0.0;
+    for (long i = 0; i < n; i++) {
+        float re, im;
+        go_cmul(a[2 * i], a[2 * i + 1], b[2 * i], -b[2 * i + 1], &re, &im);
+        acc += atan2((double)im, (double)re);
+    }
+    return acc / (double)n;
+}

@@ -256,3 +256,15 @@ def par_shift_gain(ts, sample_rate, freq_hz, gain, buf, threads):
     lib().orc_par_shift_gain(C.byref(t), C.c_ulong(int(sample_rate)), C.c_double(freq_hz),
                              C.c_float(gain), _p(buf), C.c_long(length(buf)), C.c_int(threads))
     return t.value
+
+
+def peak_lag(corr):
+    lag = C.c_long(0)
+    lib().orc_peak_lag(_p(corr), C.c_long(length(corr)), C.byref(lag))
+    return lag.value
+
+
+def mean_phase(a, b):
+    fn = lib().orc_mean_phase
+    fn.restype = C.c_double
+    return fn(_p(a), _p(b), C.c_long(length(a)))
