@@ -100,11 +100,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # Debug aid for 1-GPU boxes: HZ_BENCH_SAME_DEVICE=1 HZ_BENCH_BACKEND=gloo runs every
+    # rank on cuda:0 over gloo so the multi-rank code path can be exercised without N GPUs.
+    if os.environ.get("HZ_BENCH_SAME_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("HZ_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     hz = importlib.import_module("go-sdr_amd")
     # one non-default HIP stream carries torch's work, the library's kernels and
@@ -145,7 +153,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))

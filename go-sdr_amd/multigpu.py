@@ -15,7 +15,9 @@ the GPU box, "gloo" in the CPU tests):
                    the final sum lands on the LAST rank.
 
 Nothing here touches sample values on the host; `partial_fn` is the only thing
-that computes, and on the GPU box it is the HIP kernel.
+that computes, and on the GPU box it is the HIP kernel.  (Only when the backend
+is gloo AND the tensors live on a GPU -- a 1-GPU debugging set-up -- are the
+messages staged through host memory, because gloo has no device p2p.)
 """
 import time
 
@@ -29,9 +31,19 @@ def shard_channels(n_channels, world, rank):
     return lo, hi
 
 
+def _staged(dist, t):
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
 def reduce_fast(dist, torch, partial, dst=0):
     """Sum complex64 partials elementwise onto rank `dst` (float32 lanes)."""
-    dist.reduce(torch.view_as_real(partial), dst=dst, op=dist.ReduceOp.SUM)
+    view = torch.view_as_real(partial)
+    if _staged(dist, view):
+        h = view.cpu()
+        dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM)
+        view.copy_(h)
+    else:
+        dist.reduce(view, dst=dst, op=dist.ReduceOp.SUM)
     return partial
 
 
@@ -48,11 +60,21 @@ def ordered_pipeline(dist, rank, world, out, partial_fn, n_slices=8):
         if hi == lo:
             continue
         view = torch.view_as_real(out[lo:hi])
+        staged = _staged(dist, view)
         if rank > 0:
-            dist.recv(view, src=rank - 1)
+            if staged:
+                h = torch.empty(view.shape, dtype=view.dtype)
+                dist.recv(h, src=rank - 1)
+                view.copy_(h)
+            else:
+                dist.recv(view, src=rank - 1)
         partial_fn(lo, hi, rank > 0)
         if rank < world - 1:
-            reqs.append(dist.isend(view, dst=rank + 1))
+            if staged:
+                torch.cuda.current_stream().synchronize()
+                dist.send(view.cpu(), dst=rank + 1)
+            else:
+                reqs.append(dist.isend(view, dst=rank + 1))
     for r in reqs:
         r.wait()
     return out
@@ -68,6 +90,7 @@ def bench_beamform(hz, ctx, torch, dist, rank, world, n, steps, warmup, synth):
     weights = hz.beamform_angles(433e6, 30.0, dists)
     my_w = weights[lo:hi]
     out = torch.zeros(n, dtype=torch.complex64, device="cuda")
+    gpu_barrier = dist.get_backend() == "nccl"
 
     def fast():
         if chans:
@@ -97,7 +120,8 @@ def bench_beamform(hz, ctx, torch, dist, rank, world, n, steps, warmup, synth):
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
-        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64,
+                          device="cuda" if gpu_barrier else "cpu")
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         ms = float(el.item()) / steps * 1e3
         res[name] = {"ms_per_buffer": round(ms, 4),
