@@ -245,18 +245,22 @@ __device__ __forceinline__ void stage_block(float2 *lds, const void *in, const E
                                     span_lo + TPT * 2 <= 0 ? 0 : (uint64_t)(span_lo + TPT * 2 - 1));
         float2 a = make_float2(0.f, 0.f), b = a;
         if (live) {
-            if (vec_ok && p >= 0 && (size_t)(p + 2) <= n_in) {
-                RV x = *reinterpret_cast<const RV *>((const R *)in + p);
-                float2 ab[2] = {Raw<FMT>::cvt(x.v[0]), Raw<FMT>::cvt(x.v[1])};
-                ew_apply_n<2>(P, ab, (uint64_t)p, w);
-                a = ab[0];
-                b = ab[1];
+            // ONE instantiation of the elementwise program for the pair (p, p+1):
+            // lanes whose position lies outside [0, n_in) run it on a dummy value and
+            // are overridden afterwards (history or zero), instead of a second and
+            // third inlined copy of the float64 Sincos on a divergent path.
+            const bool in0 = p >= 0 && (size_t)p < n_in, in1 = p + 1 >= 0 && (size_t)(p + 1) < n_in;
+            RV x{};
+            if (vec_ok && in0 && in1) {
+                x = *reinterpret_cast<const RV *>((const R *)in + p);
             } else {
-                if (p < 0) { if (hist) a = hist[p + off]; }
-                else if ((size_t)p < n_in) a = chain_sample<FMT>(in, P, (uint64_t)p);
-                if (p + 1 < 0) { if (hist) b = hist[p + 1 + off]; }
-                else if ((size_t)(p + 1) < n_in) b = chain_sample<FMT>(in, P, (uint64_t)p + 1);
+                if (in0) x.v[0] = ((const R *)in)[p];
+                if (in1) x.v[1] = ((const R *)in)[p + 1];
             }
+            float2 ab[2] = {Raw<FMT>::cvt(x.v[0]), Raw<FMT>::cvt(x.v[1])};
+            ew_apply_n<2>(P, ab, (uint64_t)p, w);  // (uint64)(-1) + 1 wraps to sample 0
+            if (in0) a = ab[0]; else if (p < 0 && hist) a = hist[p + off];
+            if (in1) b = ab[1]; else if (p + 1 < 0 && hist) b = hist[p + 1 + off];
         }
         keep_history(new_hist, p, n_in, off, live, a, b);
         *reinterpret_cast<float4 *>(lds + i0) = make_float4(a.x, a.y, b.x, b.y);
@@ -413,18 +417,22 @@ __device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const
                                     span_lo + TPT * 2 <= 0 ? 0 : (uint64_t)(span_lo + TPT * 2 - 1));
         float2 a = make_float2(0.f, 0.f), b = a;
         if (live) {
-            if (vec_ok && p >= 0 && (size_t)(p + 2) <= n_in) {
-                RV x = *reinterpret_cast<const RV *>((const R *)in + p);
-                float2 ab[2] = {Raw<FMT>::cvt(x.v[0]), Raw<FMT>::cvt(x.v[1])};
-                ew_apply_n<2>(P, ab, (uint64_t)p, w);
-                a = ab[0];
-                b = ab[1];
+            // ONE instantiation of the elementwise program for the pair (p, p+1):
+            // lanes whose position lies outside [0, n_in) run it on a dummy value and
+            // are overridden afterwards (history or zero), instead of a second and
+            // third inlined copy of the float64 Sincos on a divergent path.
+            const bool in0 = p >= 0 && (size_t)p < n_in, in1 = p + 1 >= 0 && (size_t)(p + 1) < n_in;
+            RV x{};
+            if (vec_ok && in0 && in1) {
+                x = *reinterpret_cast<const RV *>((const R *)in + p);
             } else {
-                if (p < 0) { if (hist) a = hist[p + off]; }
-                else if ((size_t)p < n_in) a = chain_sample<FMT>(in, P, (uint64_t)p);
-                if (p + 1 < 0) { if (hist) b = hist[p + 1 + off]; }
-                else if ((size_t)(p + 1) < n_in) b = chain_sample<FMT>(in, P, (uint64_t)p + 1);
+                if (in0) x.v[0] = ((const R *)in)[p];
+                if (in1) x.v[1] = ((const R *)in)[p + 1];
             }
+            float2 ab[2] = {Raw<FMT>::cvt(x.v[0]), Raw<FMT>::cvt(x.v[1])};
+            ew_apply_n<2>(P, ab, (uint64_t)p, w);  // (uint64)(-1) + 1 wraps to sample 0
+            if (in0) a = ab[0]; else if (p < 0 && hist) a = hist[p + off];
+            if (in1) b = ab[1]; else if (p + 1 < 0 && hist) b = hist[p + 1 + off];
         }
         keep_history(new_hist, p, n_in, off, live, a, b);
         const int q = f16::pad(i0);  // i0 even: i0 and i0+1 share a 16-element row

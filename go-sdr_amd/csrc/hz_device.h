@@ -122,36 +122,10 @@ __device__ __noinline__ void go_trig_reduce(double x, uint32_t &j_out, double &z
     z_out = __dmul_rn(z, 0.78539816339744830961566084581987572);
 }
 
-// math.Sincos(x) -> (sin, cos)
-__device__ __forceinline__ void go_sincos(double x, double &sn, double &cs) {
-    const double PI4A = 7.85398125648498535156e-1;
-    const double PI4B = 3.77489470793079817668e-8;
-    const double PI4C = 2.69515142907905952645e-15;
-    const double M4PI = 1.27323954473516268615107010698;
-    // Straight-line common path (|x| < 2^29): the special cases of the Go source
-    // (x == 0 returns (x, 1); NaN / Inf return NaN) are folded into selects at the
-    // end, and j fits an int32 (|x| * 4/pi < 2^31), so the float64 <-> uint64
-    // conversion sequences become single instructions with identical values.
-    const double x_in = x;
-    bool sin_sign = x < 0, cos_sign = false;
-    x = fabs(x);
-    uint32_t j;
-    double z;
-    if (x >= 536870912.0) {  // also Inf; NaN takes the other side and stays NaN
-        if (x > 1.7976931348623157e308) {
-            sn = __longlong_as_double(0x7FF8000000000001LL);
-            cs = sn;
-            return;
-        }
-        go_trig_reduce(x, j, z);
-    } else {
-        int32_t ji = __double2int_rz(__dmul_rn(x, M4PI));
-        ji += ji & 1;  // map zeros to origin: j++, y++ (y + 1 is exact)
-        const double y = (double)ji;
-        j = (uint32_t)ji & 7;
-        z = __dsub_rn(__dsub_rn(__dsub_rn(x, __dmul_rn(y, PI4A)), __dmul_rn(y, PI4B)),
-                      __dmul_rn(y, PI4C));
-    }
+// The shared tail of math.Sincos: octant bookkeeping and the two polynomials on
+// the reduced argument z of octant j.
+__device__ __forceinline__ void go_sincos_tail(uint32_t j, double z, bool sin_sign, double &sn, double &cs) {
+    bool cos_sign = false;
     if (j > 3) {
         j -= 4;
         sin_sign = !sin_sign;
@@ -182,7 +156,47 @@ __device__ __forceinline__ void go_sincos(double x, double &sn, double &cs) {
     }
     sn = sin_sign ? -s : s;
     cs = cos_sign ? -c : c;
-    if (x_in == 0.0) sn = x_in;  // +-0 in, +-0 out (cs is already exactly 1)
+}
+
+// |x| >= 2^29, Inf or NaN.  Inlined on purpose: making THIS an out-of-line call
+// (measured) slows the hot loops by 15-35 % -- a call in the loop body forces the
+// register allocator to keep the whole live state call-safe; only the integer
+// Payne-Hanek core (go_trig_reduce) stays out of line.
+__device__ __forceinline__ void go_sincos_large(double x, double &sn, double &cs) {
+    const double ax = fabs(x);
+    if (!(ax <= 1.7976931348623157e308)) {  // NaN or Inf
+        sn = __longlong_as_double(0x7FF8000000000001LL);
+        cs = sn;
+        return;
+    }
+    uint32_t j;
+    double z;
+    go_trig_reduce(ax, j, z);
+    go_sincos_tail(j, z, x < 0, sn, cs);
+}
+
+// math.Sincos(x) -> (sin, cos)
+__device__ __forceinline__ void go_sincos(double x, double &sn, double &cs) {
+    const double PI4A = 7.85398125648498535156e-1;
+    const double PI4B = 3.77489470793079817668e-8;
+    const double PI4C = 2.69515142907905952645e-15;
+    const double M4PI = 1.27323954473516268615107010698;
+    // Straight-line common path (|x| < 2^29): x == 0 returns (x, 1) through a select
+    // at the end, and j fits an int32 (|x| * 4/pi < 2^31), so the float64 <-> uint64
+    // conversion sequences of the Go source become single instructions with
+    // identical values.
+    const double ax = fabs(x);
+    if (!(ax < 536870912.0)) {  // large, Inf, NaN
+        go_sincos_large(x, sn, cs);
+        return;
+    }
+    int32_t ji = __double2int_rz(__dmul_rn(ax, M4PI));
+    ji += ji & 1;  // map zeros to origin: j++, y++ (y + 1 is exact)
+    const double y = (double)ji;
+    const double z = __dsub_rn(__dsub_rn(__dsub_rn(ax, __dmul_rn(y, PI4A)), __dmul_rn(y, PI4B)),
+                               __dmul_rn(y, PI4C));
+    go_sincos_tail((uint32_t)ji & 7, z, x < 0, sn, cs);
+    if (x == 0.0) sn = x;  // +-0 in, +-0 out (cs is already exactly 1)
 }
 
 }  // namespace hz

@@ -1,7 +1,14 @@
 // ewbench.hip -- where does the Shift kernel's time go?  Times, on 2^24 c64 samples:
-//   copy (out of place), scale in place / out of place, and the NCO rotate
-//   (exact Sincos vs FMA fast path) with and without memory traffic.
+//   copy / scale (memory only), the NCO rotate with the library's exact Sincos
+//   restatement in place and out of place, and the same arithmetic with NO memory
+//   traffic (the kernel's compute floor).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/ewbench.hip -o build/ewbench
+//
+// Round-1 findings (MI355X): copy 34 us (buffers fit the Infinity Cache when run back
+// to back), NCO compute floor 44-46 us, NCO with memory 49-51 us.  Two variants that
+// were tried here and NOT kept in the library because they changed nothing: FMA-Horner
+// polynomials with an exactness guard (16 fma instead of 37 mul/add: floor 46 us) and
+// replacing 7 of the 11 conversion instructions per sample (floor 47 us).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -11,7 +18,14 @@
 using namespace hz;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
-template <int MODE, int U>  // MODE 0 copy, 1 scale, 2 nco exact, 3 nco fast
+__device__ __forceinline__ float2 nco_one(float2 v, size_t j, double t0, double step, double tau_shift) {
+    const double ts = __fma_rn((double)(uint32_t)j, step, t0);
+    double s, c;
+    go_sincos(__dmul_rn(tau_shift, ts), s, c);
+    return go_cmul(v, make_float2((float)c, (float)s));
+}
+
+template <int MODE, int U>  // MODE 0 copy, 1 scale, 2 nco
 __global__ __launch_bounds__(256) void k(const float4 *in, float4 *out, size_t nvec, double t0, double step, double tau_shift) {
     const size_t tile = (size_t)256 * U;
     for (size_t b = (size_t)blockIdx.x * tile; b < nvec; b += (size_t)gridDim.x * tile) {
@@ -23,23 +37,10 @@ __global__ __launch_bounds__(256) void k(const float4 *in, float4 *out, size_t n
             const size_t i = b + u * 256 + threadIdx.x;
             float4 r = a[u];
             if (MODE == 1) r = make_float4(r.x * 0.5f, r.y * 0.5f, r.z * 0.5f, r.w * 0.5f);
-            if (MODE >= 2) {
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    float2 v = h ? make_float2(r.z, r.w) : make_float2(r.x, r.y);
-                    if (MODE == 4) {
-                        double ts = __fma_rn(u32_to_f64((uint32_t)(2 * i + h)), step, t0);
-                        v = go_rotate_by_phase(v, __dmul_rn(tau_shift, ts));
-                    } else {
-                    double ts = __fma_rn((double)(uint32_t)(2 * i + h), step, t0);
-                    double ph = __dmul_rn(tau_shift, ts);
-                    float s, c;
-                    if (MODE == 2) { double sd, cd; go_sincos(ph, sd, cd); s = (float)sd; c = (float)cd; }
-                    else go_sincos_f32(ph, s, c);
-                    v = go_cmul(v, make_float2(c, s));
-                    }
-                    if (h) { r.z = v.x; r.w = v.y; } else { r.x = v.x; r.y = v.y; }
-                }
+            if (MODE == 2) {
+                float2 l = nco_one(make_float2(r.x, r.y), 2 * i, t0, step, tau_shift);
+                float2 h = nco_one(make_float2(r.z, r.w), 2 * i + 1, t0, step, tau_shift);
+                r = make_float4(l.x, l.y, h.x, h.y);
             }
             out[i] = r;
         }
@@ -47,26 +48,15 @@ __global__ __launch_bounds__(256) void k(const float4 *in, float4 *out, size_t n
 }
 
 // compute only: no loads, one store per lane at the end
-template <int MODE>
 __global__ __launch_bounds__(256) void kc(float4 *out, size_t nvec, double t0, double step, double tau_shift) {
     float4 acc = make_float4(0, 0, 0, 0);
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            float2 v;
-            if (MODE == 4) {
-                double ts = __fma_rn(u32_to_f64((uint32_t)(2 * i + h)), step, t0);
-                v = go_rotate_by_phase(make_float2(acc.x + 1.0f, acc.y), __dmul_rn(tau_shift, ts));
-            } else {
-            double ts = __fma_rn((double)(uint32_t)(2 * i + h), step, t0);
-            double ph = __dmul_rn(tau_shift, ts);
-            float s, c;
-            if (MODE == 2) { double sd, cd; go_sincos(ph, sd, cd); s = (float)sd; c = (float)cd; }
-            else go_sincos_f32(ph, s, c);
-            v = go_cmul(make_float2(acc.x + 1.0f, acc.y), make_float2(c, s));
-            }
-            acc.x += v.x; acc.y += v.y;
+            float2 v = nco_one(make_float2(acc.x + 1.0f, acc.y), 2 * i + h, t0, step, tau_shift);
+            acc.x += v.x;
+            acc.y += v.y;
         }
     }
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
@@ -88,38 +78,21 @@ template <class F> static void timeit(const char *name, size_t bytes, F f) {
 
 int main() {
     const size_t n = (size_t)1 << 24, nvec = n / 2;
-    float4 *a, *b, *big;
-    CK(hipMalloc(&a, n * 8)); CK(hipMalloc(&b, n * 8)); CK(hipMalloc(&big, (size_t)1 << 30));
+    float4 *a, *b;
+    CK(hipMalloc(&a, n * 8)); CK(hipMalloc(&b, n * 8));
     CK(hipMemset(a, 0, n * 8)); CK(hipMemset(b, 0, n * 8));
     const double t0 = 4.5, step = 5e-8, tau_shift = 6.283185307179586 * 2.5e6;
     const size_t bytes = n * 16;
-    auto flush = [&] { CK(hipMemsetAsync(big, 1, (size_t)1 << 30, 0)); };  // evict the 256 MiB Infinity Cache
-    for (int cold = 0; cold < 2; cold++) {
-        printf("---- %s ----\n", cold ? "cache flushed before every launch (timed incl. flush? no: see below)" : "back to back (Infinity-Cache warm)");
-#define RUN(name, MODE, U, IN, OUT, G)                                                                      \
-    timeit(name, bytes, [&] { if (cold) { flush(); } hipLaunchKernelGGL((k<MODE, U>), dim3(G), dim3(256), 0, 0, IN, OUT, nvec, t0, step, tau_shift); })
-        if (!cold) {
-            RUN("copy out-of-place U=4 grid 2048", 0, 4, a, b, 2048);
-            RUN("copy out-of-place U=4 grid 8192", 0, 4, a, b, 8192);
-            RUN("scale in-place U=1 grid 2048", 1, 1, a, a, 2048);
-            RUN("scale in-place U=4 grid 2048", 1, 4, a, a, 2048);
-            RUN("scale in-place U=4 grid 8192", 1, 4, a, a, 8192);
-            RUN("scale out-of-place U=4 grid 2048", 1, 4, a, b, 2048);
-            RUN("nco exact in-place U=1 grid 2048", 2, 1, a, a, 2048);
-            RUN("nco exact in-place U=4 grid 2048", 2, 4, a, a, 2048);
-            RUN("nco fast in-place U=1 grid 2048", 3, 1, a, a, 2048);
-            RUN("nco fast in-place U=2 grid 2048", 3, 2, a, a, 2048);
-            RUN("nco fast in-place U=4 grid 2048", 3, 4, a, a, 2048);
-            RUN("nco fast in-place U=4 grid 8192", 3, 4, a, a, 8192);
-            RUN("nco fast out-of-place U=4 grid 2048", 3, 4, a, b, 2048);
-            RUN("nco q in-place U=1 grid 2048", 4, 1, a, a, 2048);
-            RUN("nco q in-place U=2 grid 2048", 4, 2, a, a, 2048);
-            RUN("nco q in-place U=4 grid 2048", 4, 4, a, a, 2048);
-            RUN("nco q out-of-place U=4 grid 2048", 4, 4, a, b, 2048);
-            timeit("nco q compute only", bytes, [&] { hipLaunchKernelGGL((kc<4>), dim3(2048), dim3(256), 0, 0, b, nvec, t0, step, tau_shift); });
-            timeit("nco exact compute only", bytes, [&] { hipLaunchKernelGGL((kc<2>), dim3(2048), dim3(256), 0, 0, b, nvec, t0, step, tau_shift); });
-            timeit("nco fast compute only", bytes, [&] { hipLaunchKernelGGL((kc<3>), dim3(2048), dim3(256), 0, 0, b, nvec, t0, step, tau_shift); });
-        }
-    }
+#define RUN(name, MODE, U, IN, OUT, G) \
+    timeit(name, bytes, [&] { hipLaunchKernelGGL((k<MODE, U>), dim3(G), dim3(256), 0, 0, IN, OUT, nvec, t0, step, tau_shift); })
+    RUN("copy out-of-place U=4 grid 2048", 0, 4, a, b, 2048);
+    RUN("scale in-place U=1 grid 2048", 1, 1, a, a, 2048);
+    RUN("scale in-place U=4 grid 2048", 1, 4, a, a, 2048);
+    RUN("scale out-of-place U=4 grid 2048", 1, 4, a, b, 2048);
+    RUN("nco in-place U=1 grid 2048", 2, 1, a, a, 2048);
+    RUN("nco in-place U=2 grid 2048", 2, 2, a, a, 2048);
+    RUN("nco in-place U=4 grid 2048", 2, 4, a, a, 2048);
+    RUN("nco out-of-place U=4 grid 2048", 2, 4, a, b, 2048);
+    timeit("nco compute only (no memory)", bytes, [&] { hipLaunchKernelGGL(kc, dim3(2048), dim3(256), 0, 0, b, nvec, t0, step, tau_shift); });
     return 0;
 }
