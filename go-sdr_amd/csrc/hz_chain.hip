@@ -405,16 +405,38 @@ __device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const
                                               size_t n_in, const float2 *hist, unsigned off, int lane,
                                               bool live, float2 *new_hist = nullptr) {
     using R = typename Raw<FMT>::t;
-    constexpr int TPT = f16::tpt(N);
+    constexpr int TPT = f16::tpt(N), STEP = TPT * 2;
     struct alignas(sizeof(R) * 2) RV { R v[2]; };
     const bool vec_ok = ((((uintptr_t)in / sizeof(R)) + (uint64_t)p0) & 1) == 0;
+    // raw pair at block offset ib (zeros outside [0, n_in)): the only memory access of a trip
+    auto load_raw = [&](int ib) {
+        RV x{};
+        const int64_t p = p0 + ib + lane * 2;
+        if (live && ib < N) {
+            const bool in0 = p >= 0 && (size_t)p < n_in, in1 = p + 1 >= 0 && (size_t)(p + 1) < n_in;
+            if (vec_ok && in0 && in1) {
+                x = *reinterpret_cast<const RV *>((const R *)in + p);
+            } else {
+                if (in0) x.v[0] = ((const R *)in)[p];
+                if (in1) x.v[1] = ((const R *)in)[p + 1];
+            }
+        }
+        return x;
+    };
+    // Software prefetch two trips ahead (named registers, no indexed array): the
+    // ~1-2 us HBM/L2 latency of a trip's load hides behind the ~600-cycle Sincos work
+    // of the two trips before it instead of being paid eight times per block.
+    RV x0 = load_raw(0), x1 = load_raw(STEP);
 #pragma unroll 1
-    for (int ib = 0; ib < N; ib += TPT * 2) {
+    for (int ib = 0; ib < N; ib += STEP) {
+        const RV x = x0;
+        x0 = x1;
+        x1 = load_raw(ib + 2 * STEP);
         const int i0 = ib + lane * 2;
         const int64_t p = p0 + i0;
-        const int64_t span_lo = p0 + ib;  // uniform: the TPT*2 samples this trip covers
+        const int64_t span_lo = p0 + ib;  // uniform: the STEP samples this trip covers
         const NcoWin w = nco_window(P.segs, span_lo < 0 ? 0 : (uint64_t)span_lo,
-                                    span_lo + TPT * 2 <= 0 ? 0 : (uint64_t)(span_lo + TPT * 2 - 1));
+                                    span_lo + STEP <= 0 ? 0 : (uint64_t)(span_lo + STEP - 1));
         float2 a = make_float2(0.f, 0.f), b = a;
         if (live) {
             // ONE instantiation of the elementwise program for the pair (p, p+1):
@@ -422,13 +444,6 @@ __device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const
             // are overridden afterwards (history or zero), instead of a second and
             // third inlined copy of the float64 Sincos on a divergent path.
             const bool in0 = p >= 0 && (size_t)p < n_in, in1 = p + 1 >= 0 && (size_t)(p + 1) < n_in;
-            RV x{};
-            if (vec_ok && in0 && in1) {
-                x = *reinterpret_cast<const RV *>((const R *)in + p);
-            } else {
-                if (in0) x.v[0] = ((const R *)in)[p];
-                if (in1) x.v[1] = ((const R *)in)[p + 1];
-            }
             float2 ab[2] = {Raw<FMT>::cvt(x.v[0]), Raw<FMT>::cvt(x.v[1])};
             ew_apply_n<2>(P, ab, (uint64_t)p, w);  // (uint64)(-1) + 1 wraps to sample 0
             if (in0) a = ab[0]; else if (p < 0 && hist) a = hist[p + off];
@@ -545,17 +560,6 @@ __global__ __launch_bounds__(f16::block(N)) void fir_decimate_kernel16(
                 }
             }
         }
-    }
-}
-
-// New history = the last `off` samples of (old history ++ this run's samples).
-template <int FMT>
-__global__ void fir_history_kernel(const void *in, const float2 *__restrict__ old_hist,
-                                   float2 *__restrict__ new_hist, size_t n_in, unsigned off, EwProgram P) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < off; i += stride) {
-        const int64_t p = (int64_t)n_in - (int64_t)off + (int64_t)i;  // position in this run
-        new_hist[i] = p >= 0 ? chain_sample<FMT>(in, P, (uint64_t)p) : old_hist[p + off];
     }
 }
 

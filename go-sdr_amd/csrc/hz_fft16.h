@@ -152,18 +152,39 @@ template <int N, int R> __device__ __forceinline__ void store_lds(const float2 *
     }
 }
 
-// multiply inputs by w^(r k); Ns > 1
-template <int N, int R, bool INV>
-__device__ __forceinline__ void twiddle(float2 *v, const float2 *__restrict__ tw, int lane, int Ns) {
+// Inter-pass twiddles in two phases so the table loads (L2 latency) can be issued
+// BEFORE the workgroup barrier and the LDS reads of the pass they belong to.
+template <int R> struct TwRegs {
+    static constexpr int CNT = R == 16 ? 6 : (R - 1) * (16 / R);
+    float2 w[CNT];
+};
+
+template <int N, int R>
+__device__ __forceinline__ void twiddle_load(TwRegs<R> &t, const float2 *__restrict__ tw, int lane, int Ns) {
 #pragma unroll
     for (int b = 0; b < 16 / R; b++) {
         const int j = b * tpt(N) + lane;
         const int k = j & (Ns - 1);
         const int base = k * (N / (Ns * R));
+        if constexpr (R == 16) {
+            t.w[0] = tw[base]; t.w[1] = tw[2 * base]; t.w[2] = tw[3 * base];
+            t.w[3] = tw[4 * base]; t.w[4] = tw[8 * base]; t.w[5] = tw[12 * base];
+        } else {
+#pragma unroll
+            for (int r = 1; r < R; r++) t.w[b * (R - 1) + r - 1] = tw[base * r];
+        }
+    }
+}
+
+// multiply inputs by w^(r k); Ns > 1
+template <int N, int R, bool INV>
+__device__ __forceinline__ void twiddle_apply(float2 *v, const TwRegs<R> &t) {
+#pragma unroll
+    for (int b = 0; b < 16 / R; b++) {
         float2 *x = v + b * R;
         if constexpr (R == 16) {
-            const float2 w1 = cj<INV>(tw[base]), w2 = cj<INV>(tw[2 * base]), w3 = cj<INV>(tw[3 * base]);
-            const float2 w4 = cj<INV>(tw[4 * base]), w8 = cj<INV>(tw[8 * base]), w12 = cj<INV>(tw[12 * base]);
+            const float2 w1 = cj<INV>(t.w[0]), w2 = cj<INV>(t.w[1]), w3 = cj<INV>(t.w[2]);
+            const float2 w4 = cj<INV>(t.w[3]), w8 = cj<INV>(t.w[4]), w12 = cj<INV>(t.w[5]);
             x[1] = cmul(x[1], w1);
             x[2] = cmul(x[2], w2);
             x[3] = cmul(x[3], w3);
@@ -181,7 +202,7 @@ __device__ __forceinline__ void twiddle(float2 *v, const float2 *__restrict__ tw
             x[15] = cmul(x[15], cmul(w12, w3));
         } else {
 #pragma unroll
-            for (int r = 1; r < R; r++) x[r] = cmul(x[r], cj<INV>(tw[base * r]));
+            for (int r = 1; r < R; r++) x[r] = cmul(x[r], cj<INV>(t.w[b * (R - 1) + r - 1]));
         }
     }
 }
@@ -207,9 +228,11 @@ __device__ __forceinline__ void forward(float2 *v, float2 *lds, const float2 *tw
     store_lds<N, R0>(v, lds, lane, 1);
     int Ns = R0;
     for (;;) {
+        TwRegs<16> t;
+        twiddle_load<N, 16>(t, tw, lane, Ns);  // in flight across the barrier and the LDS reads
         __syncthreads();
         load_lds<N, 16>(v, lds, lane);
-        twiddle<N, 16, false>(v, tw, lane, Ns);
+        twiddle_apply<N, 16, false>(v, t);
         butterflies<16, false>(v);
         if (Ns * 16 >= N) break;  // results stay in registers: radix-16 edge layout
         __syncthreads();
@@ -230,20 +253,24 @@ __device__ __forceinline__ void backward(float2 *v, float2 *lds, const float2 *t
     if (active) store_lds<N, 16>(v, lds, lane, 1);
     int Ns = 16;
     while (Ns * R0 < N) {
+        TwRegs<16> t;
+        if (active) twiddle_load<N, 16>(t, tw, lane, Ns);
         __syncthreads();
         if (active) {
             load_lds<N, 16>(v, lds, lane);
-            twiddle<N, 16, true>(v, tw, lane, Ns);
+            twiddle_apply<N, 16, true>(v, t);
             butterflies<16, true>(v);
         }
         __syncthreads();
         if (active) store_lds<N, 16>(v, lds, lane, Ns);
         Ns *= 16;
     }
+    TwRegs<R0> t0;
+    if (active) twiddle_load<N, R0>(t0, tw, lane, Ns);  // Ns = N / R0
     __syncthreads();
     if (active) {
         load_lds<N, R0>(v, lds, lane);
-        twiddle<N, R0, true>(v, tw, lane, Ns);  // Ns = N / R0
+        twiddle_apply<N, R0, true>(v, t0);
         butterflies<R0, true>(v);
     }
 }
