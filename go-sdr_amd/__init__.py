@@ -331,6 +331,19 @@ class Context:
         self._ck(lib.hzsdr_mean_phase(self._h, _ptr(a), _ptr(b), length(a), C.byref(v)))
         return v.value
 
+    def fftshift_scale(self, data, scale):
+        self._ck(lib.hzsdr_fftshift_scale(self._h, _ptr(data), length(data), float(scale)))
+
+    # -- one block of GraftReaders (rtl/kerberos/internal/graft.go:63-122) --
+    def graft(self, out, channels):
+        k = len(channels)
+        arr = (C.c_void_p * k)(*[_ptr(c) for c in channels])
+        self._ck(lib.hzsdr_graft(self._h, _ptr(out), length(out), arr, k, length(channels[0])))
+
+    # -- foreign-endian ByteReader / ByteWriter payloads (bytes_io.go) --
+    def byteswap(self, buf):
+        self._ck(lib.hzsdr_byteswap(self._h, fmt_of(buf), _ptr(buf), length(buf)))
+
     def chain(self, src_fmt, sample_rate=0):
         return Chain(self, src_fmt, sample_rate)
 

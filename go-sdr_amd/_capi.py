@@ -124,6 +124,9 @@ SIGNATURES = {
     "hzsdr_beamform_partial": (i32, [vp, vp, i32, pvp, C.POINTER(f32), i32, sz, i32]),
     "hzsdr_peak_lag": (i32, [vp, vp, sz, C.POINTER(i64)]),
     "hzsdr_mean_phase": (i32, [vp, vp, vp, sz, C.POINTER(f64)]),
+    "hzsdr_fftshift_scale": (i32, [vp, vp, sz, f32]),
+    "hzsdr_graft": (i32, [vp, vp, sz, pvp, i32, sz]),
+    "hzsdr_byteswap": (i32, [vp, i32, vp, sz]),
     "hzsdr_chain_create": (i32, [vp, i32, u64, pvp]),
     "hzsdr_chain_shift": (i32, [vp, f64]),
     "hzsdr_chain_gain": (i32, [vp, f32]),

@@ -11,8 +11,9 @@ import math
 
 import numpy as np
 
-from . import FMT_C64, ErrDstTooSmall, length, make_samples
-from .stream import read_full
+from . import (FMT_C64, ErrDstTooSmall, ErrSampleFormatMismatch, HzsdrError, fmt_of, length,
+               make_samples)
+from .stream import EOF, ErrUnexpectedEOF, Reader, read_full
 
 SYNC_LENGTH = 1024 * 64  # align.go:248, :278
 
@@ -42,6 +43,53 @@ class CrossCorrelater:
 def read_buffers(readers, bufs):
     for r, b in zip(readers, bufs):
         read_full(r, b)
+
+
+GRAFT_LENGTH = 1024 * 64  # graft.go:128
+
+
+class GraftReader(Reader):
+    """GraftReaders (rtl/kerberos/internal/graft.go:124-159): adjacent bands from
+    len(readers) tuners stitched in frequency space into ONE reader at len(readers)
+    times the rate.  Each trip ReadFulls `fft_size` samples per band and hands out
+    len(readers) * fft_size output samples (graft.go:85-120); a read error on any
+    band ends the stream."""
+
+    def __init__(self, ctx, readers, fft_size=GRAFT_LENGTH):
+        self.ctx, self.readers, self.n = ctx, list(readers), fft_size
+        self.bufs = [make_samples(FMT_C64, fft_size) for _ in self.readers]
+        self.out = make_samples(FMT_C64, fft_size * len(self.readers))
+        self.rate = len(self.readers) * self.readers[0].sample_rate()  # graft.go:132
+        self.avail, self.off, self.err = 0, 0, None
+
+    def sample_format(self):
+        return FMT_C64
+
+    def sample_rate(self):
+        return self.rate
+
+    def read(self, samples):
+        if fmt_of(samples) != FMT_C64:
+            raise ErrSampleFormatMismatch("sdr: iq sample formats do not match")
+        if self.avail == 0:
+            if self.err is not None:
+                raise self.err
+            try:
+                read_buffers(self.readers, self.bufs)
+            except (EOF, HzsdrError) as e:
+                self.err = EOF() if isinstance(e, ErrUnexpectedEOF) else e
+                raise self.err
+            self.ctx.graft(self.out, self.bufs)
+            self.avail, self.off = length(self.out), 0
+        n = min(self.avail, length(samples))
+        samples[:n] = self.out[self.off:self.off + n]
+        self.off += n
+        self.avail -= n
+        return n
+
+
+def graft_readers(ctx, readers, fft_size=GRAFT_LENGTH):
+    return GraftReader(ctx, readers, fft_size)
 
 
 def check_alignment(ctx, readers, bufs, reference_quirk=False):

@@ -282,6 +282,23 @@ int hzsdr_peak_lag(hzsdr_ctx *ctx, const void *corr_c64, size_t n, int64_t *lag)
 int hzsdr_mean_phase(hzsdr_ctx *ctx, const void *a_c64, const void *b_c64, size_t n,
                      double *mean_phase);
 
+/* FFTShiftAndScale(data, scale), rtl/kerberos/internal/reader.go:47-64: swap the
+ * two halves of a spectrum and divide every component by `scale`.  In place. */
+int hzsdr_fftshift_scale(hzsdr_ctx *ctx, void *data_c64, size_t n, float scale);
+/* One block of GraftReaders, rtl/kerberos/internal/graft.go:63-122 (SURVEY 8f rank
+ * 3): forward-transform `count` adjacent bands of n samples each, fftshift + scale
+ * by 1/n, concatenate the spectra and run ONE backward transform of count*n points:
+ * count*n samples at count times the rate.  n and count*n must be powers of two. */
+int hzsdr_graft(hzsdr_ctx *ctx, void *out_c64, size_t out_len, const void *const *channels_c64,
+                int count, size_t n);
+
+/* ---- foreign-endian wire / disk formats ----------------- */
+
+/* What sdr.ByteReader / ByteWriter do for a byte order that is not the host's
+ * (bytes_io.go:30-64, :150-197): every int16 component (i16) or float32 component
+ * (c64) has its bytes reversed; u8 / i8 are untouched.  In place over n samples. */
+int hzsdr_byteswap(hzsdr_ctx *ctx, int format, void *buf, size_t n);
+
 /* ---- fused operator chains (north_star: one kernel per buffer) ----------- */
 
 /* A chain is the GPU form of nested stream.* Readers over one source

@@ -844,3 +844,52 @@ double orc_mean_phase(const float *a, const float *b, long n) {
     }
     return acc / (double)n;
 }
+
+/* ------------------------------------------------------------------ */
+/* rtl/kerberos graft + foreign-endian payloads */
+/* ------------------------------------------------------------------ */
+
+/* rtl/kerberos/internal/reader.go:47-64 FFTShiftAndScale: data[i], data[half+i] =
+ * data[half+i]/scale, data[i]/scale component-wise in float32; an odd tail element
+ * is left alone. */
+void orc_fftshift_scale(float *data, long n, float scale) {
+    long half = n / 2;
+    for (long i = 0; i < half; i++) {
+        float lr = data[2 * i], li = data[2 * i + 1];
+        float hr = data[2 * (half + i)], hi = data[2 * (half + i) + 1];
+        data[2 * i] = hr / scale;
+        data[2 * i + 1] = hi / scale;
+        data[2 * (half + i)] = lr / scale;
+        data[2 * (half + i) + 1] = li / scale;
+    }
+}
+
+/* One trip of graftReader.do's loop, rtl/kerberos/internal/graft.go:97-114: band i is
+ * forward-transformed into freq[i*n:(i+1)*n], FFTShiftAndScale(.., float32(n)), then
+ * one backward transform of all count*n bins into out. */
+int orc_graft(float *out, const float *const *bands, int count, long n) {
+    long total = n * count;
+    float *freq = malloc(sizeof(float) * 2 * total);
+    int rc = ORC_OK;
+    for (int c = 0; c < count && rc == ORC_OK; c++) {
+        rc = orc_fft(bands[c], n, freq + 2 * c * n, n, 1);
+        if (rc == ORC_OK)
+            orc_fftshift_scale(freq + 2 * c * n, n, (float)n);
+    }
+    if (rc == ORC_OK)
+        rc = orc_fft(freq, total, out, total, 0);
+    free(freq);
+    return rc;
+}
+
+/* bytes_io.go:30-64 / :150-197: the foreign-order ByteReader / ByteWriter move every
+ * int16 (width 2) or float32 (width 4) component through binary.Read/Write with the
+ * other byte order, i.e. reverse each component's bytes. */
+void orc_byteswap(unsigned char *buf, long ncomp, int width) {
+    for (long i = 0; i < ncomp; i++)
+        for (int b = 0; b < width / 2; b++) {
+            unsigned char t = buf[i * width + b];
+            buf[i * width + b] = buf[i * width + width - 1 - b];
+            buf[i * width + width - 1 - b] = t;
+        }
+}

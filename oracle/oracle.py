@@ -268,3 +268,21 @@ def mean_phase(a, b):
     fn = lib().orc_mean_phase
     fn.restype = C.c_double
     return fn(_p(a), _p(b), C.c_long(length(a)))
+
+
+def fftshift_scale(data, scale):
+    lib().orc_fftshift_scale(_p(data), C.c_long(length(data)), C.c_float(scale))
+
+
+def graft(out, bands):
+    k = len(bands)
+    arr = (C.c_void_p * k)(*[b.ctypes.data for b in bands])
+    return lib().orc_graft(_p(out), arr, C.c_int(k), C.c_long(length(bands[0])))
+
+
+def byteswap(buf):
+    """In place over a c64 (4-byte components) or i16 (2-byte components) buffer."""
+    width = 4 if buf.dtype == np.complex64 else buf.dtype.itemsize
+    if width == 1:
+        return
+    lib().orc_byteswap(_p(buf), C.c_long(buf.nbytes // width), C.c_int(width))

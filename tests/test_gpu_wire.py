@@ -1,0 +1,158 @@
+"""SURVEY.md 8f rank 3/4 "next" rows on the GPU: foreign-endian payload swap
+(bytes_io.go), FFTShiftAndScale (rtl/kerberos/internal/reader.go:47-64) and one
+block of GraftReaders (rtl/kerberos/internal/graft.go:63-122) against the oracle.
+Byte and division work is bit-exact; graft goes through three FFT stages and is
+held to a relative L2 bound written in the test."""
+import importlib
+
+import numpy as np
+import pytest
+
+from util import bits_equal, rand_c64, rand_i16, rand_i8, rand_u8, zeros
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hz():
+    return importlib.import_module("go-sdr_amd")
+
+
+class Env:
+    def __init__(self, hz, kind):
+        import torch
+        self.kind, self.torch = kind, torch
+        if kind == "host":
+            self.ctx = hz.Context(0, hz.MEM_HOST)
+        else:
+            self.ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+
+    def put(self, a):
+        if self.kind == "host":
+            return np.ascontiguousarray(a).copy()
+        return self.torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def get(self, x):
+        if self.kind == "host":
+            return x
+        self.ctx.synchronize()
+        return x.cpu().numpy()
+
+
+@pytest.fixture(scope="module", params=["host", "device"])
+def env(request, hz):
+    e = Env(hz, request.param)
+    yield e
+    e.ctx.close()
+
+
+@pytest.mark.parametrize("fmt,gen", [("i16", rand_i16), ("c64", rand_c64)])
+@pytest.mark.parametrize("n,skip", [(0, 0), (1, 0), (7, 0), (4096, 0), (100_003, 0), (100_003, 1),
+                                    (1 << 20, 3)])
+def test_byteswap_bit_exact(env, orc, fmt, gen, n, skip):
+    """Odd lengths and slices that start off a 16-byte boundary take the scalar tail."""
+    x = gen(31, n + skip)
+    want = x[skip:].copy()
+    orc.byteswap(want)
+    if n:  # the oracle against numpy's own byteswap
+        comp = want.view(np.float32 if fmt == "c64" else np.int16)
+        assert np.array_equal(comp.view(np.uint8), x[skip:].view(comp.dtype).byteswap().view(np.uint8))
+    d = env.put(x)
+    env.ctx.byteswap(d[skip:])
+    got = env.get(d)
+    assert bits_equal(got[skip:], want)
+    assert bits_equal(got[:skip], x[:skip])
+    env.ctx.byteswap(d[skip:])  # an involution
+    assert bits_equal(env.get(d), x)
+
+
+@pytest.mark.parametrize("gen", [rand_u8, rand_i8])
+def test_byteswap_bytes_have_no_order(env, gen):
+    x = gen(5, 1000)
+    d = env.put(x)
+    env.ctx.byteswap(d)
+    assert bits_equal(env.get(d), x)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 9, 1024, 65536, (1 << 20) + 1])
+@pytest.mark.parametrize("scale", [1.0, 3.0, 65536.0])
+def test_fftshift_scale_bit_exact(env, orc, n, scale):
+    x = rand_c64(n + 17, n)
+    want = x.copy()
+    orc.fftshift_scale(want, scale)
+    d = env.put(x)
+    env.ctx.fftshift_scale(d, scale)
+    assert bits_equal(env.get(d), want)
+
+
+@pytest.mark.parametrize("count,n", [(1, 1024), (2, 512), (4, 4096), (2, 65536), (4, 65536),
+                                     (8, 65536)])
+def test_graft_matches_oracle(env, orc, count, n):
+    bands = [rand_c64(100 + k, n) for k in range(count)]
+    want = zeros("c64", count * n)
+    assert orc.graft(want, bands) == 0
+    out = env.put(zeros("c64", count * n))
+    env.ctx.graft(out, [env.put(b) for b in bands])
+    got = env.get(out)
+    err = np.linalg.norm(got.astype(np.complex128) - want) / np.linalg.norm(want)
+    # float32 FFTs of 2^10..2^19 points, twice in series, against a float64 one
+    assert err < 2e-6, err
+
+
+def test_graft_of_one_band_is_a_sign_flip(env):
+    """fftshift in frequency is (-1)^k in time: with one band the stitched output is
+    the input with every odd sample negated (size-independent property)."""
+    n = 1 << 20
+    x = rand_c64(77, n)
+    out = env.put(zeros("c64", n))
+    env.ctx.graft(out, [env.put(x)])
+    got = env.get(out)
+    want = x * np.where(np.arange(n) % 2 == 0, 1, -1).astype(np.float32)
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 2e-6
+
+
+def test_graft_places_each_band_in_its_own_slice(env):
+    """A tone at +f in band c comes out at ((c + 1/2) n + f n/fs ... ) of the wide
+    spectrum: the forward FFT of the output peaks inside slice c."""
+    n, count = 4096, 4
+    k0 = 37  # bin of the tone inside its band
+    t = np.arange(n)
+    for c in range(count):
+        bands = [zeros("c64", n) for _ in range(count)]
+        bands[c] = np.exp(2j * np.pi * k0 * t / n).astype(np.complex64)
+        out = env.put(zeros("c64", count * n))
+        env.ctx.graft(out, [env.put(b) for b in bands])
+        spec = np.abs(np.fft.fft(env.get(out).astype(np.complex128)))
+        peak = int(np.argmax(spec))
+        assert peak == c * n + (k0 + n // 2) % n
+
+
+def test_graft_argument_errors(hz, env):
+    out = env.put(zeros("c64", 4096))
+    with pytest.raises(hz.ErrDstTooSmall):
+        env.ctx.graft(out, [env.put(zeros("c64", 4096)) for _ in range(2)])
+    with pytest.raises(hz.HzsdrError):  # 3 bands: count * n is not a power of two
+        env.ctx.graft(env.put(zeros("c64", 3 * 1024)), [env.put(zeros("c64", 1024)) for _ in range(3)])
+
+
+def test_graft_reader_stream(hz, orc):
+    """GraftReaders end to end over BufferReaders: two trips, then EOF."""
+    K = importlib.import_module("go-sdr_amd.kerberos")
+    S = importlib.import_module("go-sdr_amd.stream")
+    ctx = hz.Context(0, hz.MEM_HOST)
+    n, count, trips = 8192, 2, 2
+    data = [rand_c64(200 + k, n * trips + 100) for k in range(count)]  # the ragged tail is dropped
+    r = K.graft_readers(ctx, [S.BufferReader(d, 2_048_000, max_read=5000) for d in data], fft_size=n)
+    assert r.sample_rate() == count * 2_048_000 and r.sample_format() == hz.FMT_C64
+    got = zeros("c64", count * n * trips)
+    assert S.read_full(r, got) == len(got)
+    for t in range(trips):
+        want = zeros("c64", count * n)
+        orc.graft(want, [d[t * n:(t + 1) * n].copy() for d in data])
+        g = got[t * count * n:(t + 1) * count * n]
+        assert np.linalg.norm(g - want) / np.linalg.norm(want) < 2e-6
+    with pytest.raises(S.EOF):
+        r.read(zeros("c64", 16))
+    with pytest.raises(hz.ErrSampleFormatMismatch):
+        r.read(zeros("u8", 16))
+    ctx.close()

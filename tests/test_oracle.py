@@ -495,3 +495,30 @@ def test_beamform_data_path(orc):
         acc = t
     assert bits_equal(out, acc)
     assert all(bits_equal(a, b) for a, b in zip(ch, [rand_c64(20 + i, n) for i in range(4)]))
+
+
+def test_graft_and_wire_restatements(orc):
+    """The reference holds no tests for rtl/kerberos/internal or for the foreign
+    byte order; the restatements are checked against their definitions instead."""
+    from util import rand_i16
+    x = rand_c64(3, 9)
+    y = x.copy()
+    orc.fftshift_scale(y, 4.0)
+    assert bits_equal(y[:4], (x[4:8] / np.float32(4)).astype(np.complex64))
+    assert bits_equal(y[4:8], (x[:4] / np.float32(4)).astype(np.complex64))
+    assert bits_equal(y[8:], x[8:])  # reader.go:58: half = len/2, an odd tail is untouched
+    for buf, comp in ((rand_i16(1, 33), np.int16), (rand_c64(2, 33), np.float32)):
+        want = buf.view(comp).byteswap().view(np.uint8)
+        orc.byteswap(buf)
+        assert np.array_equal(buf.view(np.uint8), want)
+    n = 1024
+    x = rand_c64(4, n)
+    out = zeros("c64", n)
+    assert orc.graft(out, [x]) == 0  # one band: fftshift in frequency = (-1)^k in time
+    want = x * np.where(np.arange(n) % 2 == 0, 1, -1).astype(np.float32)
+    assert np.linalg.norm(out - want) / np.linalg.norm(want) < 1e-6
+    t = np.arange(n)
+    bands = [zeros("c64", n), np.exp(2j * np.pi * 5 * t / n).astype(np.complex64)]
+    out = zeros("c64", 2 * n)
+    assert orc.graft(out, bands) == 0
+    assert int(np.argmax(np.abs(np.fft.fft(out.astype(np.complex128))))) == n + 5 + n // 2
