@@ -5,17 +5,22 @@
 //
 // Names follow the reference: sdr::Reader (reader.go:39-51), sdr::ReadFull
 // (reader.go:72), stream::ReadTransformer (stream/read_transformer.go:45-137),
-// stream::ConvertReader / DecimateReader / DownsampleReader / ShiftReader / Gain
-// (stream/*.go).  Errors are the reference's sentinels, thrown as hzsdr::Error
+// stream::ConvertReader / DecimateReader / DownsampleReader / ShiftReader / Gain /
+// Multiply / Add / ConvolutionReader / ReadBeamform (stream/*.go), sdr::LookupTable
+// (iq_lookup_table.go), fft::Planner / Plan / TransformOnce / Convolve / CrossCorrelate /
+// ConvolveFreq (fft/*.go), plus stream::Chain, the fused form the north star adds.
+// Errors are the reference's sentinels, thrown as hzsdr::Error
 // carrying the status code.  Buffers are host memory (a HZSDR_MEM_HOST context),
 // as Go slices would be.
 #pragma once
+#include <complex>
 #include <cstdint>
 #include <cstring>
 #include <functional>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/hzsdr.h"
@@ -258,6 +263,280 @@ private:
     float v_;
 };
 inline ReaderPtr Gain(const Context &x, ReaderPtr r, float v) { return std::make_shared<GainReader>(x, std::move(r), v); }
+
+}  // namespace stream
+
+// sdr.LookupTable (iq_lookup_table.go:98-150)
+class LookupTable {
+public:
+    // NewLookupTable(inputFormat, lookup): `lookup` holds 65536 samples of the output format
+    LookupTable(const Context &x, int input_format, Samples lookup) : x_(x), in_(input_format), out_(lookup.format) {
+        check(x_.raw(), hzsdr_lut_create(x_.raw(), input_format, lookup.format, lookup.data, lookup.length, &t_));
+    }
+    ~LookupTable() { if (t_) hzsdr_lut_free(t_); }
+    LookupTable(const LookupTable &) = delete;
+    size_t Lookup(Samples dst, Samples src) const {
+        size_t n = 0;
+        check(x_.raw(), hzsdr_lut_lookup(t_, dst.format, dst.data, dst.length, src.format, src.data, src.length, &n));
+        return n;
+    }
+    int InputFormat() const { return in_; }
+    int OutputFormat() const { return out_; }
+
+private:
+    const Context &x_;
+    int in_, out_;
+    hzsdr_lut *t_ = nullptr;
+};
+// LookupTableIdentityU8 / I8 (iq_lookup_table.go:69-90): same bytes, two views
+inline Buffer LookupTableIdentity(int format) {
+    Buffer b(format, 65536);
+    hzsdr_lut_identity(b.bytes.data());
+    return b;
+}
+
+namespace fft {
+
+enum Direction { Backward = HZSDR_FFT_BACKWARD, Forward = HZSDR_FFT_FORWARD };  // fft/fft.go:30-37
+
+// fft.Plan (fft/fft.go:50-59): aliases the two buffers for its whole life
+class Plan {
+public:
+    Plan(const Context &x, Samples iq, Samples frequency, Direction d) : x_(x) {
+        check(x_.raw(), hzsdr_fft_plan(x_.raw(), iq.data, iq.length, frequency.data, frequency.length, (int)d, &p_));
+    }
+    ~Plan() { Close(); }
+    Plan(const Plan &) = delete;
+    void Transform() { check(x_.raw(), hzsdr_fft_transform(p_)); }
+    void Close() { if (p_) { hzsdr_fft_free(p_); p_ = nullptr; } }
+
+private:
+    const Context &x_;
+    hzsdr_fft *p_ = nullptr;
+};
+using PlanPtr = std::unique_ptr<Plan>;
+// fft.Planner (fft/fft.go:45-48)
+using Planner = std::function<PlanPtr(Samples iq, Samples frequency, Direction)>;
+inline Planner NewPlanner(const Context &x) {
+    return [&x](Samples iq, Samples f, Direction d) { return PlanPtr(new Plan(x, iq, f, d)); };
+}
+// fft.TransformOnce (fft/fft.go:64-75)
+inline void TransformOnce(const Planner &planner, Samples iq, Samples frequency, Direction d) {
+    auto p = planner(iq, frequency, d);
+    p->Transform();
+    p->Close();
+}
+
+// the "func() error" closures of fft/convolution.go as an object
+class Closure {
+public:
+    Closure(const Context &x, hzsdr_conv *c) : x_(x), c_(c) {}
+    ~Closure() { if (c_) hzsdr_conv_free(c_); }
+    Closure(const Closure &) = delete;
+    void operator()() { check(x_.raw(), hzsdr_conv_exec(c_)); }
+
+private:
+    const Context &x_;
+    hzsdr_conv *c_;
+};
+using ClosurePtr = std::unique_ptr<Closure>;
+
+inline ClosurePtr two_input(const Context &x, Samples dst, Samples iq1, Samples iq2, int mode) {
+    hzsdr_conv *c = nullptr;
+    check(x.raw(), hzsdr_convolve_create(x.raw(), dst.data, dst.length, iq1.data, iq1.length, iq2.data, iq2.length, mode, &c));
+    return ClosurePtr(new Closure(x, c));
+}
+// fft.Convolve (fft/convolution.go:97-113) / fft.CrossCorrelate (:119-138).  The
+// planner argument of the reference is the context here: the plans live in the library.
+inline ClosurePtr Convolve(const Context &x, Samples dst, Samples iq1, Samples iq2) {
+    return two_input(x, dst, iq1, iq2, HZSDR_CONV_CONVOLVE);
+}
+inline ClosurePtr CrossCorrelate(const Context &x, Samples dst, Samples iq1, Samples iq2) {
+    return two_input(x, dst, iq1, iq2, HZSDR_CONV_CROSS_CORRELATE);
+}
+// fft.ConvolveFreq (fft/convolution.go:150-192)
+inline ClosurePtr ConvolveFreq(const Context &x, Samples dst, Samples src, Samples freq) {
+    hzsdr_conv *c = nullptr;
+    check(x.raw(), hzsdr_convolve_freq_create(x.raw(), dst.data, dst.length, src.data, src.length, freq.data, freq.length, &c));
+    return ClosurePtr(new Closure(x, c));
+}
+
+}  // namespace fft
+
+namespace stream {
+
+// stream.Multiply (stream/multiply.go:27-238): c64 in place, u8 / i8 through the
+// rotation table; SetMultiplier is the reference's undocumented setter (:34-36)
+class MultiplyReader : public Reader {
+public:
+    MultiplyReader(const Context &x, ReaderPtr r, float re, float im) : x_(x), r_(std::move(r)), re_(re), im_(im) {
+        const int f = r_->SampleFormat();
+        if (f == HZSDR_FMT_U8 || f == HZSDR_FMT_I8) check(x_.raw(), hzsdr_rotlut_create(x_.raw(), f, re, im, &t_));
+        else if (f != HZSDR_FMT_C64) throw Error(HZSDR_ERR_FORMAT_UNKNOWN, hzsdr_strerror(HZSDR_ERR_FORMAT_UNKNOWN));
+    }
+    ~MultiplyReader() override { if (t_) hzsdr_rotlut_free(t_); }
+    void SetMultiplier(float re, float im) {
+        re_ = re;
+        im_ = im;
+        if (t_) check(x_.raw(), hzsdr_rotlut_set_multiplier(t_, re, im));
+    }
+    size_t Read(Samples s) override {
+        if (s.format != r_->SampleFormat()) throw Error(HZSDR_ERR_FORMAT_MISMATCH, hzsdr_strerror(HZSDR_ERR_FORMAT_MISMATCH));
+        size_t n = r_->Read(s);
+        if (t_) check(x_.raw(), hzsdr_rotlut_apply(t_, s.data, n));
+        else if (!(re_ == 1.0f && im_ == 0.0f)) x_.Multiply(s.slice(0, n), re_, im_);  // multiply.go:59-62
+        return n;
+    }
+    int SampleFormat() const override { return r_->SampleFormat(); }
+    unsigned SampleRate() const override { return r_->SampleRate(); }
+
+private:
+    const Context &x_;
+    ReaderPtr r_;
+    float re_, im_;
+    hzsdr_rotlut *t_ = nullptr;
+};
+inline std::shared_ptr<MultiplyReader> Multiply(const Context &x, ReaderPtr r, float re, float im) {
+    return std::make_shared<MultiplyReader>(x, std::move(r), re, im);
+}
+
+// stream.Add (stream/add.go:41-185)
+class AddReader : public Reader {
+public:
+    AddReader(const Context &x, std::vector<ReaderPtr> rs) : x_(x), rs_(std::move(rs)) {}
+    size_t Read(Samples s) override {
+        if (failed_) throw Error(failed_, hzsdr_strerror(failed_));
+        if (s.format != HZSDR_FMT_C64 && s.format != HZSDR_FMT_I16 && s.format != HZSDR_FMT_I8)
+            throw Error(HZSDR_ERR_FORMAT_UNKNOWN, hzsdr_strerror(HZSDR_ERR_FORMAT_UNKNOWN));
+        std::vector<Buffer> bufs;
+        std::vector<const void *> ptrs;
+        bufs.reserve(rs_.size());
+        for (auto &r : rs_) {
+            bufs.emplace_back(s.format, s.length);
+            try {
+                ReadFull(*r, bufs.back().view);  // add.go:147: short input poisons the reader
+            } catch (const Eof &) { failed_ = -1; throw; }
+            catch (const Error &e) { failed_ = e.status; throw; }
+            ptrs.push_back(bufs.back().view.data);
+        }
+        check(x_.raw(), hzsdr_sum(x_.raw(), s.format, s.data, ptrs.data(), (int)ptrs.size(), s.length));
+        return s.length;
+    }
+    int SampleFormat() const override { return rs_[0]->SampleFormat(); }
+    unsigned SampleRate() const override { return rs_[0]->SampleRate(); }
+
+private:
+    const Context &x_;
+    std::vector<ReaderPtr> rs_;
+    int failed_ = 0;
+};
+inline ReaderPtr Add(const Context &x, std::vector<ReaderPtr> rs) {
+    if (rs.empty()) throw Error(HZSDR_ERR_INVALID_ARGUMENT, "stream.Add: No readers passed");
+    if (rs.size() == 1) return rs[0];
+    const int f = rs[0]->SampleFormat();
+    if (f != HZSDR_FMT_C64 && f != HZSDR_FMT_I16 && f != HZSDR_FMT_I8)
+        throw Error(HZSDR_ERR_FORMAT_UNKNOWN, hzsdr_strerror(HZSDR_ERR_FORMAT_UNKNOWN));
+    for (auto &r : rs) {
+        if (r->SampleFormat() != f) throw Error(HZSDR_ERR_INVALID_ARGUMENT, "stream.Add: Readers are not all the same format");
+        if (r->SampleRate() != rs[0]->SampleRate()) throw Error(HZSDR_ERR_INVALID_ARGUMENT, "stream.Add: Readers are not all the same rate");
+    }
+    return std::make_shared<AddReader>(x, std::move(rs));
+}
+
+// stream.ConvolutionReader (stream/convolution.go:36-82): `filter` is in the frequency domain
+inline ReaderPtr ConvolutionReader(const Context &x, ReaderPtr r, Samples filter) {
+    if (r->SampleFormat() != HZSDR_FMT_C64) throw Error(HZSDR_ERR_FORMAT_UNKNOWN, hzsdr_strerror(HZSDR_ERR_FORMAT_UNKNOWN));
+    const size_t n = filter.length;
+    auto iq = std::make_shared<Buffer>(HZSDR_FMT_C64, n);
+    std::shared_ptr<fft::Closure> conv = fft::ConvolveFreq(x, iq->view, iq->view, filter);
+    unsigned rate = r->SampleRate();
+    return std::make_shared<ReadTransformer>(std::move(r), n, n, HZSDR_FMT_C64, rate, [iq, conv](Samples in, Samples out) {
+        std::memcpy(iq->view.data, in.data, in.size());
+        (*conv)();
+        std::memcpy(out.data, iq->view.data, in.size());
+        return in.length;
+    });
+}
+
+// stream.ReadBeamform / Beamform (stream/beamform.go:131-171).  One fused kernel per
+// Read instead of K convert + K multiply + K+1 add passes; same arithmetic order.
+class Beamform : public Reader {
+public:
+    Beamform(const Context &x, std::vector<ReaderPtr> rs, std::vector<std::complex<float>> angles)
+        : x_(x), rs_(std::move(rs)), w_(rs_.size(), {1.0f, 0.0f}) {
+        for (auto &r : rs_)
+            if (r->SampleFormat() != rs_[0]->SampleFormat() || r->SampleRate() != rs_[0]->SampleRate())
+                throw Error(HZSDR_ERR_INVALID_ARGUMENT, "stream.Add: Readers are not all the same format / rate");
+        SetPhaseAngles(angles);
+    }
+    // returns false where the reference returns its length error (beamform.go:132-134)
+    bool SetPhaseAngles(const std::vector<std::complex<float>> &angles) {
+        if (angles.size() != rs_.size()) return false;
+        w_ = angles;
+        return true;
+    }
+    size_t Read(Samples s) override {
+        if (s.format != HZSDR_FMT_C64) throw Error(HZSDR_ERR_FORMAT_MISMATCH, hzsdr_strerror(HZSDR_ERR_FORMAT_MISMATCH));
+        const int f = rs_[0]->SampleFormat();
+        std::vector<Buffer> bufs;
+        std::vector<const void *> ptrs;
+        bufs.reserve(rs_.size());
+        for (auto &r : rs_) {
+            bufs.emplace_back(f, s.length);
+            ReadFull(*r, bufs.back().view);
+            ptrs.push_back(bufs.back().view.data);
+        }
+        check(x_.raw(), hzsdr_beamform(x_.raw(), s.data, f, ptrs.data(), reinterpret_cast<const float *>(w_.data()),
+                                       (int)ptrs.size(), s.length));
+        return s.length;
+    }
+    int SampleFormat() const override { return HZSDR_FMT_C64; }
+    unsigned SampleRate() const override { return rs_[0]->SampleRate(); }
+
+private:
+    const Context &x_;
+    std::vector<ReaderPtr> rs_;
+    std::vector<std::complex<float>> w_;
+};
+inline std::shared_ptr<Beamform> ReadBeamform(const Context &x, std::vector<ReaderPtr> rs, std::vector<std::complex<float>> angles) {
+    return std::make_shared<Beamform>(x, std::move(rs), std::move(angles));
+}
+// stream.BeamformAngles (stream/beamform.go:104-128)
+inline std::vector<std::complex<float>> BeamformAngles(double frequency_hz, double angle_deg, const std::vector<double> &distances) {
+    std::vector<std::complex<float>> out(distances.size());
+    hzsdr_beamform_angles(frequency_hz, angle_deg, distances.data(), (int)distances.size(), reinterpret_cast<float *>(out.data()));
+    return out;
+}
+
+// The fused form of a reader chain (north_star): ops are appended in reader order,
+// Run consumes one resident buffer per call; NCO time and FIR history persist.
+class Chain {
+public:
+    Chain(const Context &x, int src_format, uint64_t sample_rate) : x_(x) { check(x_.raw(), hzsdr_chain_create(x_.raw(), src_format, sample_rate, &c_)); }
+    ~Chain() { if (c_) hzsdr_chain_free(c_); }
+    Chain(const Chain &) = delete;
+    Chain &Shift(double hz) { check(x_.raw(), hzsdr_chain_shift(c_, hz)); return *this; }
+    Chain &Gain(float r) { check(x_.raw(), hzsdr_chain_gain(c_, r)); return *this; }
+    Chain &Multiply(float re, float im) { check(x_.raw(), hzsdr_chain_rotate(c_, re, im)); return *this; }
+    Chain &Decimate(unsigned f) { check(x_.raw(), hzsdr_chain_decimate(c_, f)); return *this; }
+    Chain &Downsample(unsigned f) { check(x_.raw(), hzsdr_chain_downsample(c_, f)); return *this; }
+    Chain &Convolution(Samples filter, unsigned decimate = 1) { check(x_.raw(), hzsdr_chain_convolution(c_, filter.data, filter.length, decimate)); return *this; }
+    Chain &FirDecimate(const std::vector<std::complex<float>> &taps, unsigned d) {
+        check(x_.raw(), hzsdr_chain_fir_decimate(c_, reinterpret_cast<const float *>(taps.data()), taps.size(), d));
+        return *this;
+    }
+    // -> (consumed, produced)
+    std::pair<size_t, size_t> Run(Samples in, Samples out) {
+        size_t used = 0, made = 0;
+        check(x_.raw(), hzsdr_chain_run(c_, in.data, in.length, out.data, out.length, &used, &made));
+        return {used, made};
+    }
+    void Reset() { check(x_.raw(), hzsdr_chain_reset(c_)); }
+
+private:
+    const Context &x_;
+    hzsdr_chain *c_ = nullptr;
+};
 
 }  // namespace stream
 }  // namespace hzsdr

@@ -118,6 +118,218 @@ int main() {
                  std::fabs((1 + cw[i].imag()) - (1 + buf[i].imag())) <= 1e-4 * std::fabs(1 + cw[i].imag()) + 1e-7;
         EXPECT(ok);
     }
+    {  // stream/multiply_test.go:36-69 TestRotate: CW(phase pi/2) * (0-1i) == CW(phase 0)
+        const size_t n = 1024 * 60;
+        std::vector<c64> cw0(n), cw90(n), buf(n);
+        for (size_t i = 0; i < n; i++) {
+            double now = double(i) / 1.8e6, a = 2 * M_PI * 10.0 * now;
+            cw0[i] = c64((float)std::cos(a), (float)std::sin(a));
+            cw90[i] = c64((float)std::cos(a + M_PI / 2), (float)std::sin(a + M_PI / 2));
+        }
+        auto r = stream::Multiply(ctx, std::make_shared<BufferReader>(view(HZSDR_FMT_C64, cw90, 1), 1800000u, 9000), 0.f, -1.f);
+        EXPECT(ReadFull(*r, view(HZSDR_FMT_C64, buf, 1)) == n);
+        bool ok = true;
+        for (size_t i = 0; i < n && ok; i++)
+            ok = std::fabs(cw0[i].real() - buf[i].real()) <= 1e-4 * std::fabs(1 + cw0[i].real()) + 1e-7 &&
+                 std::fabs(cw0[i].imag() - buf[i].imag()) <= 1e-4 * std::fabs(1 + cw0[i].imag()) + 1e-7;
+        EXPECT(ok);
+        std::vector<uint8_t> wrong(32);  // multiply.go:47-52
+        try {
+            r->Read(view(HZSDR_FMT_U8, wrong, 2));
+            EXPECT(!"no error");
+        } catch (const Error &e) { EXPECT(e.status == HZSDR_ERR_FORMAT_MISMATCH); }
+        std::vector<int16_t> i16(32);  // multiply.go:85-87: no int16 variant
+        try {
+            stream::Multiply(ctx, std::make_shared<BufferReader>(view(HZSDR_FMT_I16, i16, 2), 1u), 0.f, -1.f);
+            EXPECT(!"no error");
+        } catch (const Error &e) { EXPECT(e.status == HZSDR_ERR_FORMAT_UNKNOWN); }
+    }
+    {  // stream/multiply_test.go:71-112 TestRotateU8 and :189-230 TestRotateI8: the table
+       // reader equals ConvertBuffer -> Multiply(0-1i) -> ConvertBuffer exactly
+        const size_t n = 1024 * 60;
+        std::vector<uint8_t> u8(2 * n), refu(2 * n), gotu(2 * n);
+        std::vector<int8_t> i8(2 * n), refi(2 * n), goti(2 * n);
+        std::vector<c64> c(n);
+        uint16_t counter = 0;
+        for (size_t i = 0; i < n; i++, counter++) {
+            u8[2 * i] = (uint8_t)(counter & 0xFF);
+            u8[2 * i + 1] = (uint8_t)((counter & 0xFF00) >> 8);
+            i8[2 * i] = (int8_t)(counter & 0xFF);
+            i8[2 * i + 1] = (int8_t)(((counter & 0xFF00) >> 8) - 127);
+        }
+        ctx.ConvertBuffer(view(HZSDR_FMT_C64, c, 1), view(HZSDR_FMT_U8, u8, 2));
+        ctx.Multiply(view(HZSDR_FMT_C64, c, 1), 0.f, -1.f);
+        ctx.ConvertBuffer(view(HZSDR_FMT_U8, refu, 2), view(HZSDR_FMT_C64, c, 1));
+        auto ru = stream::Multiply(ctx, std::make_shared<BufferReader>(view(HZSDR_FMT_U8, u8, 2), 1800000u), 0.f, -1.f);
+        EXPECT(ReadFull(*ru, view(HZSDR_FMT_U8, gotu, 2)) == n);
+        EXPECT(gotu == refu);
+        ctx.ConvertBuffer(view(HZSDR_FMT_C64, c, 1), view(HZSDR_FMT_I8, i8, 2));
+        ctx.Multiply(view(HZSDR_FMT_C64, c, 1), 0.f, -1.f);
+        ctx.ConvertBuffer(view(HZSDR_FMT_I8, refi, 2), view(HZSDR_FMT_C64, c, 1));
+        auto ri = stream::Multiply(ctx, std::make_shared<BufferReader>(view(HZSDR_FMT_I8, i8, 2), 1800000u), 0.f, -1.f);
+        EXPECT(ReadFull(*ri, view(HZSDR_FMT_I8, goti, 2)) == n);
+        EXPECT(goti == refi);
+    }
+    {  // stream/add_test.go:34-75 (3 x 10+20i = 30+60i), :77-135 (i8 / i16 10+10 = 20)
+        std::vector<c64> in(1000, {10.f, 20.f}), out(1000);
+        std::vector<ReaderPtr> rs;
+        for (int k = 0; k < 3; k++) rs.push_back(std::make_shared<BufferReader>(view(HZSDR_FMT_C64, in, 1), 10000u, 300));
+        auto mix = stream::Add(ctx, rs);
+        EXPECT(ReadFull(*mix, view(HZSDR_FMT_C64, out, 1)) == 1000);
+        for (auto &v : out) EXPECT(v == c64(30.f, 60.f));
+        const size_t n = 1024 * 32;
+        std::vector<int8_t> a8(2 * n, 10), o8(2 * n);
+        auto m8 = stream::Add(ctx, {std::make_shared<BufferReader>(view(HZSDR_FMT_I8, a8, 2), 0u),
+                                    std::make_shared<BufferReader>(view(HZSDR_FMT_I8, a8, 2), 0u)});
+        EXPECT(ReadFull(*m8, view(HZSDR_FMT_I8, o8, 2)) == n);
+        for (auto v : o8) EXPECT(v == 20);
+        std::vector<int16_t> a16(2 * n, 10), o16(2 * n);
+        auto m16 = stream::Add(ctx, {std::make_shared<BufferReader>(view(HZSDR_FMT_I16, a16, 2), 0u),
+                                     std::make_shared<BufferReader>(view(HZSDR_FMT_I16, a16, 2), 0u)});
+        EXPECT(ReadFull(*m16, view(HZSDR_FMT_I16, o16, 2)) == n);
+        for (auto v : o16) EXPECT(v == 20);
+        std::vector<uint8_t> u(64);  // add.go:55-61: no uint8 adder
+        try {
+            stream::Add(ctx, {std::make_shared<BufferReader>(view(HZSDR_FMT_U8, u, 2), 0u),
+                              std::make_shared<BufferReader>(view(HZSDR_FMT_U8, u, 2), 0u)});
+            EXPECT(!"no error");
+        } catch (const Error &e) { EXPECT(e.status == HZSDR_ERR_FORMAT_UNKNOWN); }
+    }
+    {  // testutils/fft.go:54-138, the conformance suite every fft.Planner must pass
+        auto planner = fft::NewPlanner(ctx);
+        const size_t n = 1024;
+        const double rate = 1.8e6;
+        const double tones[4][2] = {{10.0, 0}, {900000.0, 512}, {450000.0, 256}, {225000.0, 128}};
+        auto peak = [](const std::vector<c64> &f) {
+            size_t best = 0;
+            for (size_t i = 1; i < f.size(); i++)
+                if (std::abs(f[i]) > std::abs(f[best])) best = i;
+            return best;
+        };
+        for (auto &t : tones) {
+            std::vector<c64> iq(n), freq(n);
+            for (size_t i = 0; i < n; i++) {
+                double a = 2 * M_PI * t[0] * (double(i) / rate);
+                iq[i] = c64((float)std::cos(a), (float)std::sin(a));
+            }
+            fft::TransformOnce(planner, view(HZSDR_FMT_C64, iq, 1), view(HZSDR_FMT_C64, freq, 1), fft::Forward);
+            EXPECT(peak(freq) == (size_t)t[1]);
+        }
+        for (size_t bin : {5, 10, 127, 522, 242, 415, 825}) {
+            std::vector<c64> iq(n), freq(n), back(n);
+            freq[bin] = c64(1.f, 1.f);
+            fft::TransformOnce(planner, view(HZSDR_FMT_C64, iq, 1), view(HZSDR_FMT_C64, freq, 1), fft::Backward);
+            fft::TransformOnce(planner, view(HZSDR_FMT_C64, iq, 1), view(HZSDR_FMT_C64, back, 1), fft::Forward);
+            EXPECT(peak(back) == bin);
+        }
+        std::vector<c64> big(1024), small(128);
+        try {
+            planner(view(HZSDR_FMT_C64, big, 1), view(HZSDR_FMT_C64, small, 1), fft::Forward);
+            EXPECT(!"no error");
+        } catch (const Error &e) { EXPECT(e.status == HZSDR_ERR_DST_TOO_SMALL); }
+        try {
+            planner(view(HZSDR_FMT_C64, small, 1), view(HZSDR_FMT_C64, big, 1), fft::Backward);
+            EXPECT(!"no error");
+        } catch (const Error &e) { EXPECT(e.status == HZSDR_ERR_DST_TOO_SMALL); }
+    }
+    {  // stream/convolution.go:36-82: an all-ones filter in the frequency domain is the
+       // identity up to the unnormalised round trip (x N); a ragged last block is dropped
+        const size_t n = 1024, blocks = 5;
+        std::vector<c64> ones(n, {1.f, 0.f}), in(n * blocks + 100), out(n * blocks);
+        for (size_t i = 0; i < in.size(); i++) in[i] = c64(float(int(i % 37) - 18) / 32.f, float(int(i % 11) - 5) / 8.f);
+        auto r = stream::ConvolutionReader(ctx, std::make_shared<BufferReader>(view(HZSDR_FMT_C64, in, 1), 2000000u, 700),
+                                           view(HZSDR_FMT_C64, ones, 1));
+        EXPECT(r->SampleRate() == 2000000u);
+        EXPECT(ReadFull(*r, view(HZSDR_FMT_C64, out, 1)) == n * blocks);
+        bool ok = true;
+        for (size_t i = 0; i < out.size() && ok; i++) ok = std::abs(out[i] - in[i] * float(n)) <= 1e-3f * float(n);
+        EXPECT(ok);
+        std::vector<c64> one(1);
+        try {
+            r->Read(view(HZSDR_FMT_C64, one, 1));
+            EXPECT(!"no EOF");
+        } catch (const Eof &) {}
+    }
+    {  // fft/convolution.go:97-138: delta convolved with x is x (x N^0: forward-forward-backward
+       // is unnormalised by N); cross-correlation of x with itself peaks at lag 0
+        const size_t n = 4096;
+        std::vector<c64> x(n), d(n), out(n);
+        for (size_t i = 0; i < n; i++) x[i] = c64(float(int(i * 7919 % 101) - 50) / 64.f, float(int(i * 104729 % 89) - 44) / 64.f);
+        d[3] = c64(1.f, 0.f);
+        auto conv = fft::Convolve(ctx, view(HZSDR_FMT_C64, out, 1), view(HZSDR_FMT_C64, x, 1), view(HZSDR_FMT_C64, d, 1));
+        (*conv)();
+        bool ok = true;
+        for (size_t i = 0; i < n && ok; i++) ok = std::abs(out[i] - x[(i + n - 3) % n] * float(n)) <= 2e-3f * float(n);
+        EXPECT(ok);
+        auto xc = fft::CrossCorrelate(ctx, view(HZSDR_FMT_C64, out, 1), view(HZSDR_FMT_C64, x, 1), view(HZSDR_FMT_C64, x, 1));
+        (*xc)();
+        int64_t lag = 99;
+        check(ctx.raw(), hzsdr_peak_lag(ctx.raw(), out.data(), n, &lag));
+        EXPECT(lag == 0);
+        std::vector<c64> shorter(n / 2);
+        try {
+            fft::Convolve(ctx, view(HZSDR_FMT_C64, out, 1), view(HZSDR_FMT_C64, x, 1), view(HZSDR_FMT_C64, shorter, 1));
+            EXPECT(!"no error");
+        } catch (const Error &e) { EXPECT(e.status == HZSDR_ERR_LENGTH_MISMATCH || e.status == HZSDR_ERR_DST_TOO_SMALL); }
+    }
+    {  // stream/beamform.go:148-171 over u8 channels: ConvertReader -> Multiply(w) -> Add,
+       // checked against the same three steps made one at a time
+        const size_t n = 40000;
+        const int K = 4;
+        auto w = stream::BeamformAngles(433e6, 30.0, {0.0, 0.1, 0.2, 0.3});
+        EXPECT(w[0] == c64(1.f, 0.f));
+        std::vector<std::vector<uint8_t>> ch(K, std::vector<uint8_t>(2 * n));
+        for (int k = 0; k < K; k++)
+            for (size_t i = 0; i < 2 * n; i++) ch[k][i] = (uint8_t)((i * 2654435761u + k * 40503u) >> 13);
+        std::vector<ReaderPtr> rs;
+        for (int k = 0; k < K; k++) rs.push_back(std::make_shared<BufferReader>(view(HZSDR_FMT_U8, ch[k], 2), 2400000u, 5000));
+        auto bf = stream::ReadBeamform(ctx, rs, w);
+        EXPECT(bf->SampleFormat() == HZSDR_FMT_C64 && bf->SampleRate() == 2400000u);
+        EXPECT(!bf->SetPhaseAngles({c64(1.f, 0.f)}));  // beamform.go:132-134
+        std::vector<c64> got(n), acc(n, c64(0.f, 0.f)), tmp(n);
+        EXPECT(ReadFull(*bf, view(HZSDR_FMT_C64, got, 1)) == n);
+        for (int k = 0; k < K; k++) {
+            ctx.ConvertBuffer(view(HZSDR_FMT_C64, tmp, 1), view(HZSDR_FMT_U8, ch[k], 2));
+            if (w[k] != c64(1.f, 0.f)) ctx.Multiply(view(HZSDR_FMT_C64, tmp, 1), w[k].real(), w[k].imag());
+            ctx.Add(view(HZSDR_FMT_C64, acc, 1), view(HZSDR_FMT_C64, tmp, 1));
+        }
+        EXPECT(std::memcmp(got.data(), acc.data(), n * sizeof(c64)) == 0);
+    }
+    {  // sdr.LookupTable (iq_lookup_table.go:98-150): identity table u8 -> u8, then a
+       // u8 -> c64 table built with ConvertBuffer equals ConvertBuffer
+        Buffer ident = LookupTableIdentity(HZSDR_FMT_U8);
+        LookupTable t(ctx, HZSDR_FMT_U8, ident.view);
+        std::vector<uint8_t> in(2 * 5000), out(2 * 5000);
+        for (size_t i = 0; i < in.size(); i++) in[i] = (uint8_t)(i * 2246822519u >> 11);
+        EXPECT(t.Lookup(view(HZSDR_FMT_U8, out, 2), view(HZSDR_FMT_U8, in, 2)) == 5000);
+        EXPECT(in == out);
+        Buffer tab(HZSDR_FMT_C64, 65536);
+        ctx.ConvertBuffer(tab.view, ident.view);
+        LookupTable tc(ctx, HZSDR_FMT_U8, tab.view);
+        std::vector<c64> a(5000), b(5000);
+        tc.Lookup(view(HZSDR_FMT_C64, a, 1), view(HZSDR_FMT_U8, in, 2));
+        ctx.ConvertBuffer(view(HZSDR_FMT_C64, b, 1), view(HZSDR_FMT_U8, in, 2));
+        EXPECT(std::memcmp(a.data(), b.data(), a.size() * sizeof(c64)) == 0);
+        std::vector<c64> tiny(10);
+        try {
+            tc.Lookup(view(HZSDR_FMT_C64, tiny, 1), view(HZSDR_FMT_U8, in, 2));
+            EXPECT(!"no error");
+        } catch (const Error &e) { EXPECT(e.status == HZSDR_ERR_DST_TOO_SMALL); }
+    }
+    {  // the fused chain against the same readers run one by one: u8 -> c64 -> Shift -> Gain
+        const size_t n = 1 << 18;
+        std::vector<uint8_t> u8(2 * n);
+        for (size_t i = 0; i < 2 * n; i++) u8[i] = (uint8_t)(i * 2654435761u >> 17);
+        auto src = std::make_shared<BufferReader>(view(HZSDR_FMT_U8, u8, 2), 2400000u);
+        auto r = stream::Gain(ctx, stream::ShiftReader(ctx, stream::ConvertReader(ctx, src, HZSDR_FMT_C64), 250000.0), 0.25f);
+        std::vector<c64> want(n), got(n);
+        EXPECT(ReadFull(*r, view(HZSDR_FMT_C64, want, 1)) == n);
+        stream::Chain chain(ctx, HZSDR_FMT_U8, 2400000u);
+        chain.Shift(250000.0).Gain(0.25f);
+        auto res = chain.Run(view(HZSDR_FMT_U8, u8, 2), view(HZSDR_FMT_C64, got, 1));
+        EXPECT(res.first == n && res.second == n);
+        EXPECT(std::memcmp(got.data(), want.data(), n * sizeof(c64)) == 0);
+    }
     std::printf(failures ? "%d FAILED\n" : "all host-mirror tests passed\n", failures);
     return failures ? 1 : 0;
 }

@@ -260,7 +260,8 @@ def test_cxx_host_mirror_runs_reference_kats():
     from conftest import ROOT
     exe = os.path.join(ROOT, "build", "test_host_mirror")
     src = os.path.join(ROOT, "tests", "cxx", "test_host_mirror.cpp")
-    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+    deps = [src, os.path.join(ROOT, "go-sdr_amd", "cxx", "hzsdr.hpp"), os.path.join(ROOT, "include", "hzsdr.h")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(exe), exist_ok=True)
         subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + ROOT, src, "-L" + os.path.join(ROOT, "go-sdr_amd"),
                                "-lhzsdr_hip", "-L/opt/rocm/lib", "-Wl,-rpath," + os.path.join(ROOT, "go-sdr_amd"),
