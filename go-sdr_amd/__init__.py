@@ -532,7 +532,57 @@ class Chain:
     def reset(self):
         self.ctx._ck(lib.hzsdr_chain_reset(self._h))
 
+    def ring(self, slot_length, slots=4):
+        return Ring(self, slot_length, slots)
+
     def close(self):
         if self._h:
             lib.hzsdr_chain_free(self._h)
+            self._h = C.c_void_p()
+
+
+def _view(ptr, fmt, n):
+    """yikes.Samples(base, len, fmt) (yikes/bytes.go:50-71): numpy over foreign memory."""
+    dt = {FMT_C64: np.complex64, FMT_U8: np.uint8, FMT_I16: np.int16, FMT_I8: np.int8}[fmt]
+    nbytes = n * format_size(fmt)
+    raw = np.frombuffer((C.c_ubyte * nbytes).from_address(ptr), np.uint8) if nbytes else np.zeros(0, np.uint8)
+    a = raw.view(dt)
+    return a if fmt == FMT_C64 else a.reshape(n, 2)
+
+
+class Ring:
+    """hzsdr_ring_*: the pinned stream.RingBuffer in front of a chain (stream/ring.go:48-69).
+    `iq` is the whole IQBufferAllocator region; acquire() -> (slot, samples view),
+    submit(slot, n), pop() -> complex64 view of that slot's output."""
+
+    def __init__(self, chain, slot_length, slots=4):
+        self.chain, self.ctx = chain, chain.ctx
+        self._h = C.c_void_p()
+        self.ctx._ck(lib.hzsdr_ring_create(chain._h, slot_length, slots, C.byref(self._h)))
+        base, n, sl = C.c_void_p(), C.c_size_t(0), C.c_size_t(0)
+        self.ctx._ck(lib.hzsdr_ring_iq_buffer(self._h, C.byref(base), C.byref(n), C.byref(sl)))
+        self.slot_length, self.slots, self.fmt = sl.value, slots, chain.src_fmt
+        self.iq = _view(base.value, self.fmt, n.value)
+
+    def acquire(self):
+        slot, p = C.c_int(-1), C.c_void_p()
+        self.ctx._ck(lib.hzsdr_ring_acquire(self._h, C.byref(slot), C.byref(p)))
+        return slot.value, self.iq[slot.value * self.slot_length:(slot.value + 1) * self.slot_length]
+
+    def submit(self, slot, n=None):
+        self.ctx._ck(lib.hzsdr_ring_submit(self._h, slot, self.slot_length if n is None else n))
+
+    def pop(self):
+        p, n = C.c_void_p(), C.c_size_t(0)
+        self.ctx._ck(lib.hzsdr_ring_pop(self._h, C.byref(p), C.byref(n)))
+        return _view(p.value, FMT_C64, n.value)
+
+    @property
+    def in_flight(self):
+        return lib.hzsdr_ring_in_flight(self._h)
+
+    def close(self):
+        if self._h:
+            self.iq = None
+            lib.hzsdr_ring_free(self._h)
             self._h = C.c_void_p()

@@ -139,6 +139,13 @@ SIGNATURES = {
     "hzsdr_chain_run": (i32, [vp, vp, sz, vp, sz, psz, psz]),
     "hzsdr_chain_reset": (i32, [vp]),
     "hzsdr_chain_free": (i32, [vp]),
+    "hzsdr_ring_create": (i32, [vp, sz, i32, pvp]),
+    "hzsdr_ring_iq_buffer": (i32, [vp, pvp, psz, psz]),
+    "hzsdr_ring_acquire": (i32, [vp, C.POINTER(i32), pvp]),
+    "hzsdr_ring_submit": (i32, [vp, i32, sz]),
+    "hzsdr_ring_pop": (i32, [vp, pvp, psz]),
+    "hzsdr_ring_in_flight": (i32, [vp]),
+    "hzsdr_ring_free": (i32, [vp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

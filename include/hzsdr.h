@@ -337,6 +337,37 @@ int hzsdr_chain_run(hzsdr_chain *c, const void *in, size_t n_in, void *out, size
 int hzsdr_chain_reset(hzsdr_chain *c);
 int hzsdr_chain_free(hzsdr_chain *c);
 
+/* ---- pinned ring in front of a chain -------------------- */
+
+/* The streaming form of a chain for live input: what stream.RingBuffer
+ * (stream/ring.go:48-69, :337-392) is to a driver callback.  The ring owns ONE
+ * pinned (hipHostMalloc) region of slots * slot_length samples of the chain's
+ * source format -- the memory RingBufferOptions.IQBufferAllocator returns
+ * (stream/ring.go:60-68), wrapped as sdr.Samples with yikes.Samples
+ * (yikes/bytes.go:50-71) -- so driver callbacks (rtl/rx.go:49-68) land IQ where
+ * the copy engine reads it.  A submitted slot goes upload -> chain kernel ->
+ * download on three HIP streams chained by events: the PCIe transfers of
+ * neighbouring slots overlap the kernel.  Slots are used in order; chain state
+ * (NCO clock, FIR history) advances in submit order.  slot_length must be a whole
+ * number of the chain's blocks (hzsdr_chain_plan consumes all of it).  One
+ * producer / one consumer; calls on one ring must not overlap. */
+typedef struct hzsdr_ring hzsdr_ring;
+int hzsdr_ring_create(hzsdr_chain *c, size_t slot_length, int slots, hzsdr_ring **out);
+/* The whole pinned IQ region (slot i starts at i * slot_length samples). */
+int hzsdr_ring_iq_buffer(const hzsdr_ring *r, void **base, size_t *n_samples, size_t *slot_length);
+/* Write cursor: the next slot and its pinned memory.  DST_TOO_SMALL when every
+ * slot is still in flight (the overrun case: pop first). */
+int hzsdr_ring_acquire(hzsdr_ring *r, int *slot, void **iq);
+/* The acquired slot holds n samples: enqueue its upload, kernel and download.
+ * Returns without waiting. */
+int hzsdr_ring_submit(hzsdr_ring *r, int slot, size_t n);
+/* Read cursor: wait for the oldest submitted slot; *out (pinned, complex64,
+ * *n_out samples) stays valid until that slot is submitted again.
+ * INVALID_ARGUMENT when nothing is in flight (the underrun case). */
+int hzsdr_ring_pop(hzsdr_ring *r, const void **out, size_t *n_out);
+int hzsdr_ring_in_flight(const hzsdr_ring *r);
+int hzsdr_ring_free(hzsdr_ring *r);
+
 #ifdef __cplusplus
 }
 #endif

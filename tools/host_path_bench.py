@@ -43,8 +43,35 @@ def main():
     ch = ctx.chain(hz.FMT_U8, 20_000_000).shift(-2.5e6).fir_decimate(taps, 8)
     t = best(lambda: ch.run(xu8, o8))
     rows.append(("north-star chain u8 in, c64/8 out", n, t, 3))
+    # the same chain behind the pinned ring: the producer's copy into the slot is NOT
+    # timed when fill=False (a driver callback writes there directly, rtl/rx.go:49-68)
+    for slot_log2, slots in ((20, 4), (22, 4), (22, 8)):
+        sl = 1 << slot_log2
+        ch2 = ctx.chain(hz.FMT_U8, 20_000_000).shift(-2.5e6).fir_decimate(taps, 8)
+        ring = ch2.ring(sl, slots)
+        for fill in (False, True):
+            total = 1 << 27
+
+            def run():
+                done = 0
+                sink = 0.0
+                for k in range(total // sl):
+                    if ring.in_flight == slots:
+                        sink += float(ring.pop()[0].real)
+                    slot, iq = ring.acquire()
+                    if fill:
+                        iq[:] = xu8[(k * sl) % n:(k * sl) % n + sl]
+                    ring.submit(slot)
+                    done += sl
+                while ring.in_flight:
+                    sink += float(ring.pop()[0].real)
+                return done
+            t = best(run, reps=3)
+            rows.append((f"chain via ring, slot 2^{slot_log2} x{slots}{', memcpy into slot' if fill else ''}", total, t, 3))
+        ring.close()
+        ch2.close()
     for name, n_, t, bps in rows:
-        print(f"{name:36s} {t * 1e3:8.2f} ms  {n_ / t / 1e6:9.1f} Msamples/s  {bps * n_ / t / 1e9:6.1f} GB/s over PCIe")
+        print(f"{name:46s} {t * 1e3:8.2f} ms  {n_ / t / 1e6:9.1f} Msamples/s  {bps * n_ / t / 1e9:6.1f} GB/s over PCIe")
     ctx.close()
 
 
