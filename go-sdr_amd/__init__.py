@@ -344,6 +344,14 @@ class Context:
     def byteswap(self, buf):
         self._ck(lib.hzsdr_byteswap(self._h, fmt_of(buf), _ptr(buf), length(buf)))
 
+    def convert_foreign(self, dst, src, dst_foreign=False, src_foreign=False):
+        """ConvertBuffer with a foreign-order ByteReader / ByteWriter payload on either side."""
+        n = C.c_size_t(0)
+        self._ck(lib.hzsdr_convert_foreign(self._h, fmt_of(dst), _ptr(dst), length(dst), int(dst_foreign),
+                                           fmt_of(src), _ptr(src), length(src), int(src_foreign),
+                                           C.byref(n)))
+        return n.value
+
     def chain(self, src_fmt, sample_rate=0):
         return Chain(self, src_fmt, sample_rate)
 

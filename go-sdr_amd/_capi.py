@@ -127,6 +127,7 @@ SIGNATURES = {
     "hzsdr_fftshift_scale": (i32, [vp, vp, sz, f32]),
     "hzsdr_graft": (i32, [vp, vp, sz, pvp, i32, sz]),
     "hzsdr_byteswap": (i32, [vp, i32, vp, sz]),
+    "hzsdr_convert_foreign": (i32, [vp, i32, vp, sz, i32, i32, vp, sz, i32, psz]),
     "hzsdr_chain_create": (i32, [vp, i32, u64, pvp]),
     "hzsdr_chain_shift": (i32, [vp, f64]),
     "hzsdr_chain_gain": (i32, [vp, f32]),

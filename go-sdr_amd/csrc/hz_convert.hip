@@ -52,6 +52,26 @@ __device__ __forceinline__ typename ConvTraits<C>::dst_t conv1(typename ConvTrai
     if constexpr (C == I16_SHL) return (int16_t)((uint32_t)(uint16_t)v << arg);    // iq_i16.go:106-109
 }
 
+// Foreign byte order on either side (bytes_io.go:30-64, :150-197): SW bit 0 = the
+// source components arrive byte-swapped, bit 1 = the destination wants them swapped.
+template <class T> __device__ __forceinline__ T swap_bytes(T v) {
+    if constexpr (sizeof(T) == 2) {
+        const uint16_t u = (uint16_t)v;
+        return (T)(uint16_t)((u << 8) | (u >> 8));
+    } else if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, __builtin_bswap32(__builtin_bit_cast(uint32_t, v)));
+    } else {
+        return v;
+    }
+}
+template <int C, int SW>
+__device__ __forceinline__ typename ConvTraits<C>::dst_t conv1s(typename ConvTraits<C>::src_t v, int arg) {
+    if constexpr ((SW & 1) != 0) v = swap_bytes(v);
+    auto r = conv1<C>(v, arg);
+    if constexpr ((SW & 2) != 0) r = swap_bytes(r);
+    return r;
+}
+
 template <class T, int N> struct alignas(sizeof(T) * N) Vec {
     T v[N];
 };
@@ -64,7 +84,7 @@ template <int C> struct ConvGeom {
     static constexpr int K = 16 / wide;
 };
 
-template <int C>
+template <int C, int SW>
 __global__ __launch_bounds__(kThreads) void convert_vec_kernel(
     const typename ConvTraits<C>::src_t *__restrict__ src,
     typename ConvTraits<C>::dst_t *__restrict__ dst, size_t nvec, int arg) {
@@ -81,10 +101,10 @@ __global__ __launch_bounds__(kThreads) void convert_vec_kernel(
         DV r0, r1, r2, r3;
 #pragma unroll
         for (int k = 0; k < G::K; k++) {
-            r0.v[k] = conv1<C>(a0.v[k], arg);
-            r1.v[k] = conv1<C>(a1.v[k], arg);
-            r2.v[k] = conv1<C>(a2.v[k], arg);
-            r3.v[k] = conv1<C>(a3.v[k], arg);
+            r0.v[k] = conv1s<C, SW>(a0.v[k], arg);
+            r1.v[k] = conv1s<C, SW>(a1.v[k], arg);
+            r2.v[k] = conv1s<C, SW>(a2.v[k], arg);
+            r3.v[k] = conv1s<C, SW>(a3.v[k], arg);
         }
         d[i] = r0;
         d[i + stride] = r1;
@@ -95,23 +115,23 @@ __global__ __launch_bounds__(kThreads) void convert_vec_kernel(
         SV a = s[i];
         DV r;
 #pragma unroll
-        for (int k = 0; k < G::K; k++) r.v[k] = conv1<C>(a.v[k], arg);
+        for (int k = 0; k < G::K; k++) r.v[k] = conv1s<C, SW>(a.v[k], arg);
         d[i] = r;
     }
 }
 
-template <int C>
+template <int C, int SW>
 __global__ __launch_bounds__(kThreads) void convert_scalar_kernel(
     const typename ConvTraits<C>::src_t *__restrict__ src,
     typename ConvTraits<C>::dst_t *__restrict__ dst, size_t ncomp, int arg) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncomp; i += stride)
-        dst[i] = conv1<C>(src[i], arg);
+        dst[i] = conv1s<C, SW>(src[i], arg);
 }
 
 // Launch one converter over ncomp components: vector body where both pointers
 // are 16 B / K-aligned, scalar kernel for the tail or for unaligned slices.
-template <int C>
+template <int C, int SW = 0>
 static void launch_convert(hzsdr_ctx *ctx, const void *src, void *dst, size_t ncomp, int arg = 0) {
     using G = ConvGeom<C>;
     using S = typename G::S;
@@ -122,32 +142,42 @@ static void launch_convert(hzsdr_ctx *ctx, const void *src, void *dst, size_t nc
     const bool aligned = ((uintptr_t)s % (sizeof(S) * G::K) == 0) && ((uintptr_t)d % (sizeof(D) * G::K) == 0);
     size_t nvec = aligned ? ncomp / G::K : 0;
     if (nvec) {
-        hipLaunchKernelGGL(convert_vec_kernel<C>, dim3(blocks_for(ctx, (nvec + 3) / 4)), dim3(kThreads),
+        hipLaunchKernelGGL((convert_vec_kernel<C, SW>), dim3(blocks_for(ctx, (nvec + 3) / 4)), dim3(kThreads),
                            0, ctx->stream, s, d, nvec, arg);
     }
     size_t done = nvec * G::K;
     if (done < ncomp) {
-        hipLaunchKernelGGL(convert_scalar_kernel<C>, dim3(blocks_for(ctx, ncomp - done)),
+        hipLaunchKernelGGL((convert_scalar_kernel<C, SW>), dim3(blocks_for(ctx, ncomp - done)),
                            dim3(kThreads), 0, ctx->stream, s + done, d + done, ncomp - done, arg);
     }
 }
 
-// Dispatch (src_format, dst_format) -> kernel; formats already validated.
-int convert_device(hzsdr_ctx *ctx, int dst_fmt, void *dst, int src_fmt, const void *src, size_t n) {
+// Dispatch (src_format, dst_format) -> kernel; formats already validated.  `sw`: see conv1s.
+template <int C>
+static void launch_convert_sw(hzsdr_ctx *ctx, const void *src, void *dst, size_t nc, int sw) {
+    switch (sw & 3) {
+    case 0: launch_convert<C, 0>(ctx, src, dst, nc); break;
+    case 1: launch_convert<C, 1>(ctx, src, dst, nc); break;
+    case 2: launch_convert<C, 2>(ctx, src, dst, nc); break;
+    default: launch_convert<C, 3>(ctx, src, dst, nc); break;
+    }
+}
+
+int convert_device(hzsdr_ctx *ctx, int dst_fmt, void *dst, int src_fmt, const void *src, size_t n, int sw = 0) {
     const size_t nc = 2 * n;
     switch (src_fmt * 8 + dst_fmt) {
-    case HZSDR_FMT_U8 * 8 + HZSDR_FMT_C64: launch_convert<U8_C64>(ctx, src, dst, nc); break;
-    case HZSDR_FMT_U8 * 8 + HZSDR_FMT_I8: launch_convert<U8_I8>(ctx, src, dst, nc); break;
-    case HZSDR_FMT_U8 * 8 + HZSDR_FMT_I16: launch_convert<U8_I16>(ctx, src, dst, nc); break;
-    case HZSDR_FMT_I8 * 8 + HZSDR_FMT_C64: launch_convert<I8_C64>(ctx, src, dst, nc); break;
-    case HZSDR_FMT_I8 * 8 + HZSDR_FMT_U8: launch_convert<I8_U8>(ctx, src, dst, nc); break;
-    case HZSDR_FMT_I8 * 8 + HZSDR_FMT_I16: launch_convert<I8_I16>(ctx, src, dst, nc); break;
-    case HZSDR_FMT_I16 * 8 + HZSDR_FMT_C64: launch_convert<I16_C64>(ctx, src, dst, nc); break;
-    case HZSDR_FMT_I16 * 8 + HZSDR_FMT_U8: launch_convert<I16_U8>(ctx, src, dst, nc); break;
-    case HZSDR_FMT_I16 * 8 + HZSDR_FMT_I8: launch_convert<I16_I8>(ctx, src, dst, nc); break;
-    case HZSDR_FMT_C64 * 8 + HZSDR_FMT_U8: launch_convert<C64_U8>(ctx, src, dst, nc); break;
-    case HZSDR_FMT_C64 * 8 + HZSDR_FMT_I16: launch_convert<C64_I16>(ctx, src, dst, nc); break;
-    case HZSDR_FMT_C64 * 8 + HZSDR_FMT_I8: launch_convert<C64_I8>(ctx, src, dst, nc); break;
+    case HZSDR_FMT_U8 * 8 + HZSDR_FMT_C64: launch_convert_sw<U8_C64>(ctx, src, dst, nc, sw); break;
+    case HZSDR_FMT_U8 * 8 + HZSDR_FMT_I8: launch_convert_sw<U8_I8>(ctx, src, dst, nc, 0); break;
+    case HZSDR_FMT_U8 * 8 + HZSDR_FMT_I16: launch_convert_sw<U8_I16>(ctx, src, dst, nc, sw); break;
+    case HZSDR_FMT_I8 * 8 + HZSDR_FMT_C64: launch_convert_sw<I8_C64>(ctx, src, dst, nc, sw); break;
+    case HZSDR_FMT_I8 * 8 + HZSDR_FMT_U8: launch_convert_sw<I8_U8>(ctx, src, dst, nc, 0); break;
+    case HZSDR_FMT_I8 * 8 + HZSDR_FMT_I16: launch_convert_sw<I8_I16>(ctx, src, dst, nc, sw); break;
+    case HZSDR_FMT_I16 * 8 + HZSDR_FMT_C64: launch_convert_sw<I16_C64>(ctx, src, dst, nc, sw); break;
+    case HZSDR_FMT_I16 * 8 + HZSDR_FMT_U8: launch_convert_sw<I16_U8>(ctx, src, dst, nc, sw); break;
+    case HZSDR_FMT_I16 * 8 + HZSDR_FMT_I8: launch_convert_sw<I16_I8>(ctx, src, dst, nc, sw); break;
+    case HZSDR_FMT_C64 * 8 + HZSDR_FMT_U8: launch_convert_sw<C64_U8>(ctx, src, dst, nc, sw); break;
+    case HZSDR_FMT_C64 * 8 + HZSDR_FMT_I16: launch_convert_sw<C64_I16>(ctx, src, dst, nc, sw); break;
+    case HZSDR_FMT_C64 * 8 + HZSDR_FMT_I8: launch_convert_sw<C64_I8>(ctx, src, dst, nc, sw); break;
     default: return HZSDR_ERR_CONVERSION_NOT_IMPLEMENTED;
     }
     return HZSDR_OK;
@@ -368,6 +398,32 @@ int hzsdr_convert(hzsdr_ctx *ctx, int dst_format, void *dst, size_t dst_len, int
     HZ_TRY(st.in(0, src, n * ss, &dsrc));
     HZ_TRY(st.out(1, dst, n * ds, &ddst));
     HZ_TRY(convert_device(ctx, dst_format, ddst, src_format, dsrc, n));
+    HZ_TRY(st.finish());
+    if (n_out) *n_out = n;
+    return HZSDR_OK;
+}
+
+int hzsdr_convert_foreign(hzsdr_ctx *ctx, int dst_format, void *dst, size_t dst_len, int dst_foreign,
+                          int src_format, const void *src, size_t src_len, int src_foreign, size_t *n_out) {
+    using namespace hz;
+    if (n_out) *n_out = 0;
+    if (!ctx) return HZSDR_ERR_INVALID_ARGUMENT;
+    const int ss = format_size(src_format), ds = format_size(dst_format);
+    if (ss == 0 || ds == 0) return fail(ctx, HZSDR_ERR_FORMAT_UNKNOWN, "convert: unknown format");
+    if (src_format == dst_format)
+        return fail(ctx, HZSDR_ERR_CONVERSION_NOT_IMPLEMENTED,
+                    "convert_foreign: same format on both sides is a copy (+ hzsdr_byteswap)");
+    if (src_len > dst_len) return fail(ctx, HZSDR_ERR_DST_TOO_SMALL, "convert: dst shorter than src");
+    const size_t n = src_len;
+    if (n && (!src || !dst)) return HZSDR_ERR_INVALID_ARGUMENT;
+    HZ_TRY(enter(ctx));
+    if (n == 0) return HZSDR_OK;
+    Stage st(ctx);
+    const void *dsrc;
+    void *ddst;
+    HZ_TRY(st.in(0, src, n * ss, &dsrc));
+    HZ_TRY(st.out(1, dst, n * ds, &ddst));
+    HZ_TRY(convert_device(ctx, dst_format, ddst, src_format, dsrc, n, (src_foreign ? 1 : 0) | (dst_foreign ? 2 : 0)));
     HZ_TRY(st.finish());
     if (n_out) *n_out = n;
     return HZSDR_OK;

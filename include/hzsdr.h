@@ -298,6 +298,14 @@ int hzsdr_graft(hzsdr_ctx *ctx, void *out_c64, size_t out_len, const void *const
  * (bytes_io.go:30-64, :150-197): every int16 component (i16) or float32 component
  * (c64) has its bytes reversed; u8 / i8 are untouched.  In place over n samples. */
 int hzsdr_byteswap(hzsdr_ctx *ctx, int format, void *buf, size_t n);
+/* hzsdr_convert with the swap fused into the converter's load and/or store: one
+ * pass instead of three when a foreign-order capture (ByteReader, bytes_io.go:150-197)
+ * feeds a ConvertBuffer, or a ConvertBuffer feeds a foreign-order ByteWriter
+ * (bytes_io.go:30-64).  *_foreign != 0: that side's int16 / float32 components are
+ * in the byte order that is not the host's.  Formats must differ. */
+int hzsdr_convert_foreign(hzsdr_ctx *ctx, int dst_format, void *dst, size_t dst_len,
+                          int dst_foreign, int src_format, const void *src, size_t src_len,
+                          int src_foreign, size_t *n_out);
 
 /* ---- fused operator chains (north_star: one kernel per buffer) ----------- */
 

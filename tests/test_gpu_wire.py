@@ -66,6 +66,39 @@ def test_byteswap_bit_exact(env, orc, fmt, gen, n, skip):
     assert bits_equal(env.get(d), x)
 
 
+GENS = {"u8": rand_u8, "i8": rand_i8, "i16": rand_i16, "c64": rand_c64}
+
+
+@pytest.mark.parametrize("src_fmt,dst_fmt", [(s, d) for s in GENS for d in GENS if s != d])
+@pytest.mark.parametrize("src_foreign,dst_foreign", [(True, False), (False, True), (True, True)])
+def test_convert_foreign_is_swap_convert_swap(env, orc, src_fmt, dst_fmt, src_foreign, dst_foreign):
+    """The fused converter equals byteswap -> ConvertBuffer -> byteswap done by the
+    oracle one pass at a time; n = 100 003 leaves a scalar tail, skip = 1 an unaligned slice."""
+    n, skip = 100_003, 1
+    native = GENS[src_fmt](51, n + skip)
+    if src_fmt == "c64":
+        native *= np.float32(0.99)  # in-range for the float -> int converters
+    wire = native.copy()
+    if src_foreign:
+        orc.byteswap(wire)
+    want = zeros(dst_fmt, n)
+    orc.convert(want, native[skip:].copy())
+    if dst_foreign:
+        orc.byteswap(want)
+    d_src, d_dst = env.put(wire), env.put(zeros(dst_fmt, n + skip))
+    assert env.ctx.convert_foreign(d_dst[skip:], d_src[skip:], dst_foreign, src_foreign) == n
+    got = env.get(d_dst)
+    assert bits_equal(got[skip:], want)
+    assert not got[:skip].any()
+
+
+def test_convert_foreign_errors(hz, env):
+    with pytest.raises(hz.ErrDstTooSmall):
+        env.ctx.convert_foreign(env.put(zeros("c64", 10)), env.put(zeros("i16", 11)), False, True)
+    with pytest.raises(hz.ErrConversionNotImplemented):
+        env.ctx.convert_foreign(env.put(zeros("i16", 10)), env.put(zeros("i16", 10)), False, True)
+
+
 @pytest.mark.parametrize("gen", [rand_u8, rand_i8])
 def test_byteswap_bytes_have_no_order(env, gen):
     x = gen(5, 1000)
