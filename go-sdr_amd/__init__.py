@@ -525,6 +525,10 @@ class Chain:
                                                   t.size, factor))
         return self
 
+    def mix_in_order(self, in_order=True):
+        self.ctx._ck(lib.hzsdr_chain_mix_in_order(self._h, int(in_order)))
+        return self
+
     def plan(self, n_in):
         a, b = C.c_size_t(0), C.c_size_t(0)
         self.ctx._ck(lib.hzsdr_chain_plan(self._h, n_in, C.byref(a), C.byref(b)))

@@ -136,6 +136,7 @@ SIGNATURES = {
     "hzsdr_chain_downsample": (i32, [vp, u32]),
     "hzsdr_chain_convolution": (i32, [vp, vp, sz, u32]),
     "hzsdr_chain_fir_decimate": (i32, [vp, C.POINTER(f32), sz, u32]),
+    "hzsdr_chain_mix_in_order": (i32, [vp, i32]),
     "hzsdr_chain_plan": (i32, [vp, sz, psz, psz]),
     "hzsdr_chain_run": (i32, [vp, vp, sz, vp, sz, psz, psz]),
     "hzsdr_chain_reset": (i32, [vp]),

@@ -403,7 +403,9 @@ __global__ __launch_bounds__(fft_block(N), fft_waves(N)) void fir_decimate_kerne
 template <int N, int FMT>
 __device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const EwProgram &P, int64_t p0,
                                               size_t n_in, const float2 *hist, unsigned off, int lane,
-                                              bool live, float2 *new_hist = nullptr) {
+                                              bool live, float2 *new_hist = nullptr, bool apply = true) {
+    // apply == false (workgroup-uniform): converted samples only, the elementwise
+    // program runs after the filter instead (fir_decimate_kernel16, LATE blocks)
     using R = typename Raw<FMT>::t;
     constexpr int TPT = f16::tpt(N), STEP = TPT * 2;
     struct alignas(sizeof(R) * 2) RV { R v[2]; };
@@ -445,7 +447,7 @@ __device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const
             // third inlined copy of the float64 Sincos on a divergent path.
             const bool in0 = p >= 0 && (size_t)p < n_in, in1 = p + 1 >= 0 && (size_t)(p + 1) < n_in;
             float2 ab[2] = {Raw<FMT>::cvt(x.v[0]), Raw<FMT>::cvt(x.v[1])};
-            ew_apply_n<2>(P, ab, (uint64_t)p, w);  // (uint64)(-1) + 1 wraps to sample 0
+            if (apply) ew_apply_n<2>(P, ab, (uint64_t)p, w);  // (uint64)(-1) + 1 wraps to sample 0
             if (in0) a = ab[0]; else if (p < 0 && hist) a = hist[p + off];
             if (in1) b = ab[1]; else if (p + 1 < 0 && hist) b = hist[p + 1 + off];
         }
@@ -453,6 +455,28 @@ __device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const
         const int q = f16::pad(i0);  // i0 even: i0 and i0+1 share a 16-element row
         lds[q] = a;
         lds[q + 1] = b;
+    }
+}
+
+// Conversion-only staging of a block that lies wholly inside the buffer (LATE blocks):
+// every lane issues all of its 16-byte loads first (8 u8 / 4 i16 / 2 c64 samples each),
+// then converts and writes its rows -- no per-sample arithmetic to hide the load latency
+// behind, so the loads must all be in flight at once.  `src` = in + p0 samples, 16-B aligned.
+template <int N, int FMT>
+__device__ __forceinline__ void stage_block16_raw(float2 *lds, const void *src, int lane) {
+    using R = typename Raw<FMT>::t;
+    constexpr int TPT = f16::tpt(N), SPL = 16 / (int)sizeof(R), TRIPS = N / (TPT * SPL);
+    static_assert(TRIPS >= 1 && N % (TPT * SPL) == 0, "raw staging geometry");
+    struct alignas(16) RV { R v[SPL]; };
+    RV x[TRIPS];
+#pragma unroll
+    for (int t = 0; t < TRIPS; t++) x[t] = ((const RV *)src)[t * TPT + lane];
+#pragma unroll
+    for (int t = 0; t < TRIPS; t++) {
+        const int i0 = (t * TPT + lane) * SPL;  // SPL divides 16: one padded row
+        const int q = f16::pad(i0);
+#pragma unroll
+        for (int s = 0; s < SPL; s++) lds[q + s] = Raw<FMT>::cvt(x[t].v[s]);
     }
 }
 
@@ -495,26 +519,62 @@ __global__ __launch_bounds__(f16::block(N)) void conv_blocks_kernel16(const void
 // backward transform of M = N/D points run by groups of M/16 lanes (group 0's
 // result is kept; the others run the same program on their own LDS slices so the
 // workgroup barriers stay uniform).  FOLD = 0: full backward transform + pick.
-template <int N, int FMT, int FOLD>
-__global__ __launch_bounds__(f16::block(N)) void fir_decimate_kernel16(
+//
+// LATE: the mixer commutes with the filter.  Inside one exactly-linear run of the NCO
+// clock ts[n-k] = ts[n] - k*step, so with every elementwise stage a multiplication by a
+// complex scalar (Gain, Multiply) or by exp(i*tau_s*ts[n]) (Shift),
+//     sum_k h[k] * ew(x, n-k)  =  ew( sum_k (h[k] * exp(-i*Omega*k*step)) * x[n-k], n ),
+// Omega = sum of the Shift stages' tau_s: filter the CONVERTED samples with the run's
+// modulated taps (late.h[run], prepared by the host per distinct step) and run the
+// unchanged elementwise program on the hop/D outputs instead of the N inputs -- the
+// float64 Sincos at the decimated rate.  A block takes this path only when its whole
+// input span lies in one run, inside [0, n_in - off) (no history read or written);
+// every other block -- the first, the last, any block across a run boundary or a
+// 2*pi wrap of the clock -- mixes in reference order before the filter, as before.
+struct LateFilters {
+    const float2 *h[kNcoMaxSegs];
+};
+
+template <int N, int FMT, int FOLD, bool LATE>
+__global__ __launch_bounds__(f16::block(N), LATE ? 4 : 1) void fir_decimate_kernel16(
     const void *in, float2 *out, const float2 *__restrict__ hist, float2 *__restrict__ new_hist,
     const float2 *__restrict__ hfreq,
     const float2 *__restrict__ tw, const float2 *__restrict__ tw_small, size_t nblocks, size_t n_in,
-    unsigned hop, unsigned off, unsigned D, EwProgram P) {
+    unsigned hop, unsigned off, unsigned D, EwProgram P, LateFilters late) {
     constexpr int R0 = f16::first_radix(N), TPT = f16::tpt(N);
     static_assert(f16::xpb(N) == 1 || FOLD == 0, "fold path assumes one block per workgroup");
+    static_assert(!LATE || FOLD != 0, "the late mixer is written for the folded inverse");
     __shared__ float2 lds_all[f16::xpb(N) * f16::lds_elems(N)];
     const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
     float2 *lds = lds_all + sub * f16::lds_elems(N);
     const size_t b = (size_t)blockIdx.x * f16::xpb(N) + sub;
     const bool live = b < nblocks;
+    const int64_t p0 = (int64_t)(b * hop) - (int64_t)off;
+    bool mix_late = false;  // workgroup-uniform
+    NcoWin run{0, 0};
+    if constexpr (LATE) {
+        if (p0 >= 0 && (uint64_t)p0 + N + off <= n_in) {
+            run = nco_window(P.segs, (uint64_t)p0, (uint64_t)p0 + N - 1);
+            mix_late = run.lo == run.hi && late.h[run.lo] != nullptr;
+        }
+    }
+    const float2 *__restrict__ hf = mix_late ? late.h[run.lo] : hfreq;
     float2 v[16];
-    stage_block16<N, FMT>(lds, in, P, (int64_t)(b * hop) - (int64_t)off, n_in, hist, off, lane, live, new_hist);
+    bool staged = false;
+    if constexpr (LATE) {
+        using R = typename Raw<FMT>::t;
+        const R *src = (const R *)in + p0;
+        if (mix_late && ((uintptr_t)src % 16) == 0) {
+            stage_block16_raw<N, FMT>(lds, src, lane);
+            staged = true;
+        }
+    }
+    if (!staged) stage_block16<N, FMT>(lds, in, P, p0, n_in, hist, off, lane, live, new_hist, !mix_late);
     __syncthreads();
     f16::load_lds<N, R0>(v, lds, lane);
     f16::forward<N, true>(v, lds, tw, lane);
 #pragma unroll
-    for (int q = 0; q < 16; q++) v[q] = f16::cmul(v[q], hfreq[f16::edge_index<N, 16>(q, lane)]);
+    for (int q = 0; q < 16; q++) v[q] = f16::cmul(v[q], hf[f16::edge_index<N, 16>(q, lane)]);
     if constexpr (FOLD == 0) {
         f16::backward<N>(v, lds, tw, lane);
         if (live) {
@@ -549,15 +609,30 @@ __global__ __launch_bounds__(f16::block(N)) void fir_decimate_kernel16(
             for (int q = 0; q < 16; q++) w[q] = lds[f16::edge_index<M, 16>(q, l2)];
         }
         f16::backward<M>(w, lds, tw_small, l2, g == 0);
-        if (g == 0) {
-            const unsigned i_lo = off / FOLD, i_hi = (off + hop) / FOLD;
+        const unsigned i_lo = off / FOLD, i_hi = (off + hop) / FOLD;
+        if (!mix_late) {
+            if (g == 0) {
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const unsigned i = f16::edge_index<M, RM>(q, l2);
-                if (i >= i_lo && i < i_hi) {
-                    const size_t m_out = b * (hop / FOLD) + (i - i_lo);
-                    if (m_out * FOLD < n_in) out[m_out] = w[q];
+                for (int q = 0; q < 16; q++) {
+                    const unsigned i = f16::edge_index<M, RM>(q, l2);
+                    if (i >= i_lo && i < i_hi) {
+                        const size_t m_out = b * (hop / FOLD) + (i - i_lo);
+                        if (m_out * FOLD < n_in) out[m_out] = w[q];
+                    }
                 }
+            }
+        } else if constexpr (LATE) {
+            // hop/D filtered samples back to LDS, then the elementwise program over them
+            // on every lane of the workgroup: output m sits at stream position D*m
+            if (g == 0) {  // the lanes that read the last pass's inputs are the ones that write
+#pragma unroll
+                for (int q = 0; q < 16; q++) lds[f16::edge_index<M, RM>(q, l2)] = w[q];
+            }
+            __syncthreads();
+            const unsigned per = hop / FOLD;
+            for (unsigned t = lane; t < per; t += TPT) {
+                const uint64_t j = (uint64_t)b * hop + (uint64_t)t * FOLD;
+                out[b * per + t] = ew_apply(P, lds[i_lo + t], j, run);
             }
         }
     }
@@ -596,6 +671,11 @@ struct hzsdr_chain {
     int hist_cur = 0;
     size_t ntaps = 0;
     unsigned nfft = 0, hop = 0, off = 0;
+    // late mixer (see fir_decimate_kernel16): the taps, and FFT(taps * exp(-i*Omega*k*step))/N
+    // per distinct clock step seen so far (one per binade of the NCO clock)
+    std::vector<float> taps_host;
+    std::map<uint64_t, void *> late_cache;
+    bool mix_in_order = false;
 };
 
 struct hzsdr_conv {
@@ -704,6 +784,62 @@ static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, cons
                            (uint64_t)done, P);
 }
 
+// H' = FFT(taps[k] * exp(-i * omega * k * step), zero-padded to N) / N for one clock step.
+static int late_filter_for(hzsdr_chain *c, double step, double omega, void **dev) {
+    hzsdr_ctx *ctx = c->ctx;
+    uint64_t key;
+    memcpy(&key, &step, 8);
+    auto it = c->late_cache.find(key);
+    if (it != c->late_cache.end()) {
+        *dev = it->second;
+        return HZSDR_OK;
+    }
+    if (c->late_cache.size() >= 64) {  // a clock that keeps changing binade: start over
+        HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (auto &kv : c->late_cache) (void)hipFree(kv.second);
+        c->late_cache.clear();
+    }
+    const unsigned nfft = c->nfft;
+    std::vector<float> padded(2 * (size_t)nfft, 0.0f);
+    for (size_t k = 0; k < c->ntaps; k++) {
+        const double ph = -omega * ((double)k * step);
+        const double cr = cos(ph), ci = sin(ph);
+        const double hr = c->taps_host[2 * k], hi = c->taps_host[2 * k + 1];
+        padded[2 * k] = (float)(hr * cr - hi * ci);
+        padded[2 * k + 1] = (float)(hr * ci + hi * cr);
+    }
+    void *h = nullptr;
+    HZ_HIP(ctx, hipMalloc(&h, (size_t)nfft * 8));
+    HZ_TRY(ensure_slot(ctx, 8, (size_t)nfft * 8));
+    HZ_HIP(ctx, hipMemcpyAsync(ctx->slots[8].ptr, padded.data(), (size_t)nfft * 8, hipMemcpyHostToDevice, ctx->stream));
+    HZ_TRY(fft_device(ctx, ctx->slots[8].ptr, h, nfft, 1, true));
+    hipLaunchKernelGGL(scale_c64_kernel, dim3(blocks_for(ctx, nfft)), dim3(kThreads), 0, ctx->stream,
+                       (float2 *)h, (size_t)nfft, 1.0f / (float)nfft);
+    HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `padded` and slot 8 are reused
+    c->late_cache[key] = h;
+    *dev = h;
+    return HZSDR_OK;
+}
+
+// The modulated filter of every clock run long enough to hold a whole block.
+static int late_filters(hzsdr_chain *c, const EwProgram &P, size_t n, LateFilters *out, bool *any) {
+    *any = false;
+    memset(out, 0, sizeof *out);
+    if (c->mix_in_order || !c->has_shift || P.segs.big_n != 0 || c->taps_host.empty()) return HZSDR_OK;
+    double omega = 0.0;
+    for (int i = 0; i < P.n; i++)
+        if (P.op[i].kind == EW_SHIFT) omega += P.op[i].tau_shift;
+    for (int r = 0; r < P.segs.n; r++) {
+        const uint64_t first = P.segs.first[r], end = r + 1 < P.segs.n ? P.segs.first[r + 1] : (uint64_t)n;
+        if (end - first < 2 * (uint64_t)c->nfft) continue;
+        void *dev;
+        HZ_TRY(late_filter_for(c, P.segs.step[r], omega, &dev));
+        out->h[r] = (const float2 *)dev;
+        *any = true;
+    }
+    return HZSDR_OK;
+}
+
 template <int FMT>
 static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, size_t n_out,
                    const EwProgram &P) {
@@ -747,16 +883,20 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
         else HZ_FIR(N, 0);                                                               \
     } while (0)
 // radix-16 core: fold when D is a power of two <= 16 and N/D is itself a radix-16 size
-#define HZ_FIR16(N, FOLD)                                                                               \
-    hipLaunchKernelGGL((fir_decimate_kernel16<N, FMT, FOLD>),                                           \
+#define HZ_FIR16_L(N, FOLD, LATE)                                                                       \
+    hipLaunchKernelGGL((fir_decimate_kernel16<N, FMT, FOLD, LATE>),                                     \
                        dim3((unsigned)((nblocks + f16::xpb(N) - 1) / f16::xpb(N))), dim3(f16::block(N)), \
                        0, ctx->stream, in, (float2 *)out, hist, nhist, (const float2 *)c->hfreq, tw, tws, \
-                       nblocks, n_cons, c->hop, c->off, D, P)
+                       nblocks, n_cons, c->hop, c->off, D, P, late)
+#define HZ_FIR16(N, FOLD) HZ_FIR16_L(N, FOLD, false)
 #define HZ_FIR16_FOLD(N, F)                                                            \
     if (D == F) {                                                                      \
         if constexpr (f16::xpb(N) == 1 && f16::ok(N / F)) {                            \
             HZ_TRY(get_twiddles(ctx, N / F, &tws));                                    \
-            HZ_FIR16(N, F);                                                            \
+            bool any_late = false;                                                     \
+            HZ_TRY(late_filters(c, P, n_cons, &late, &any_late));                      \
+            if (any_late) HZ_FIR16_L(N, F, true);                                      \
+            else HZ_FIR16(N, F);                                                       \
             break;                                                                     \
         }                                                                              \
     }
@@ -768,6 +908,7 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
         HZ_FIR16_FOLD(N, 16)     \
         HZ_FIR16(N, 0);          \
     } while (0)
+        LateFilters late{};
         switch (c->nfft) {
         case 256: HZ_FIR16_N(256); break;
         case 512: HZ_FIR16_N(512); break;
@@ -780,6 +921,7 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
 #undef HZ_FIR16_N
 #undef HZ_FIR16_FOLD
 #undef HZ_FIR16
+#undef HZ_FIR16_L
 #undef HZ_FIR_N
 #undef HZ_FIR
         c->hist_cur ^= 1;  // the kernel wrote the next run's history into nhist
@@ -931,6 +1073,7 @@ int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps, size_t n_taps, u
     hipLaunchKernelGGL(scale_c64_kernel, dim3(blocks_for(ctx, nfft)), dim3(kThreads), 0, ctx->stream,
                        (float2 *)c->hfreq, (size_t)nfft, 1.0f / (float)nfft);
     HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    c->taps_host.assign(taps, taps + 2 * n_taps);
     c->ntaps = n_taps;
     c->nfft = nfft;
     c->hop = hop;
@@ -1015,7 +1158,14 @@ int hzsdr_chain_free(hzsdr_chain *c) {
     if (c->hfreq) (void)hipFree(c->hfreq);
     if (c->hist[0]) (void)hipFree(c->hist[0]);
     if (c->hist[1]) (void)hipFree(c->hist[1]);
+    for (auto &kv : c->late_cache) (void)hipFree(kv.second);
     delete c;
+    return HZSDR_OK;
+}
+
+int hzsdr_chain_mix_in_order(hzsdr_chain *c, int in_order) {
+    if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
+    c->mix_in_order = in_order != 0;
     return HZSDR_OK;
 }
 

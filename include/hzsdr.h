@@ -335,6 +335,17 @@ int hzsdr_chain_convolution(hzsdr_chain *c, const void *filter_freq, size_t filt
  * history carried across runs.  taps: n_taps complex64 in HOST memory. */
 int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps_c64, size_t n_taps,
                              unsigned factor);
+/* Where the elementwise stages run relative to the FIR-decimate terminal.
+ * Default (in_order = 0): Shift / Gain / Multiply are multiplications by a complex
+ * scalar or by exp(i*tau*ts[n]), and the NCO clock (stream/shifter.go:76-79) is exactly
+ * linear inside one binade, so they commute with the filter: blocks whose input lies
+ * in one such run are filtered with taps modulated by exp(-i*tau*k*step) and mixed at
+ * the DECIMATED rate, with the same Sincos, clock and multiply order; blocks at the
+ * stream edges, across a run boundary or across the clock's 2*pi wrap keep reference
+ * order.  The two orders agree to float32 rounding (the FIR itself is held to an error
+ * bound, not to bits).  in_order = 1: every block mixes each input sample before the
+ * filter, exactly as nested stream.ShiftReader -> filter Readers would. */
+int hzsdr_chain_mix_in_order(hzsdr_chain *c, int in_order);
 /* Samples the chain would produce for n_in input samples, and how many input
  * samples it consumes (whole blocks only for block-structured terminals). */
 int hzsdr_chain_plan(const hzsdr_chain *c, size_t n_in, size_t *n_consumed, size_t *n_out);
