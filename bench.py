@@ -4,8 +4,8 @@
     python bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the north-star chain (u8 -> c64 -> Shift(-fs/8) -> 1024-tap
-FIR -> decimate-by-8, one fused kernel) over one 2^24-sample synthetic buffer
-already resident in HBM.  With N > 1 every rank runs its own independent stream
+FIR -> decimate-by-8: one hzsdr_chain_run, no full-rate c64 intermediate in HBM)
+over one 2^24-sample synthetic buffer already resident in HBM.  With N > 1 every rank runs its own independent stream
 ("single-stream chains stay on one GPU": replicas, weak scaling, no data-path
 collective) and the line also carries the 4-channel Beamform measurement sharded
 over the ranks with its RCCL exchange (the other half of the metric).
@@ -140,13 +140,14 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(args.steps)]
+    # one HIP-event pair around the whole timed loop, on the stream the kernels run on:
+    # per-step pairs put two marker packets between consecutive launches and cost ~15 %
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    for a, b in evs:
-        a.record()
+    ev0.record()
+    for _ in range(args.steps):
         step()
-        b.record()
+    ev1.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -156,12 +157,13 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # device time per step, launch gaps included
     value = world * n * args.steps / elapsed / 1e6  # Msamples/s, whole job
     alg_bytes = (2 + 8 / D) * n                     # 2 B read + 8/D B written per input sample
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     nfft, valid = 4096, 3072
-    flops = (5 * nfft * 12 * 2 + 6 * nfft) / valid * n  # fwd + bwd FFT + bin multiply per input sample
+    # per 3072-sample hop: forward 4096-point FFT, 4096 bin multiplies, 512-point inverse
+    flops = (5 * nfft * 12 + 6 * nfft + 5 * (nfft // D) * 9) / valid * n
     result = {
         "metric": "Msamples/s: u8->c64->Shift->FIR-decimate chain @1 GPU; 4-ch Beamform @1/2/4 GPU",
         "value": round(value, 1),
@@ -176,17 +178,23 @@ def main():
         "dtype": "u8->c64(f32), NCO phase f64",
         "data": "synthetic (splitmix64 u8 IQ, seed 9+rank); windowed-sinc taps",
         "config": {
-            "workload": "north-star chain: u8->c64->Shift(-fs/8)->1024-tap FIR->decimate-by-8, "
-                        "fused in one kernel (overlap-save N_fft=4096), input resident in HBM",
+            "workload": "north-star chain: u8->c64->Shift(-fs/8)->1024-tap FIR->decimate-by-8, one "
+                        "chain_run per buffer = analysis kernel (convert, 4096-point overlap-save "
+                        "FFT, filter, fold by 8) + synthesis kernel (512-point inverse, mixer at the "
+                        "decimated rate), input resident in HBM",
             "samples_per_buffer": n, "sample_rate": fs, "taps": ntaps, "decimation": D,
             "parallelism": "1 stream per GPU (replicas)" if world > 1 else "1 GPU",
         },
         "roofline": {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "kernel": "hz::fir_decimate_kernel16<4096, u8, fold 8>", "kernel_ms": round(kernel_ms, 4),
+            "kernel": "hz::fir_decimate_kernel16<4096, u8, fold 8, late> + hz::fir_synth_kernel16<4096, 8, late>",
+            "kernel_ms": round(kernel_ms, 4),
+            "kernel_ms_is": "device time per chain_run (both kernels and the gap between them), one "
+                            "HIP-event pair around the timed loop / steps",
             "algorithmic_bytes_per_launch": int(alg_bytes),
-            "note": "3 B/sample puts this chain above the ridge: f32 vector work binds, not HBM",
+            "note": "3 B/sample puts this chain above the ridge: FFT vector work and its LDS/barrier "
+                    "latency bind, not HBM",
             "fp32_vector_frac": round(flops / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
         },
     }
@@ -197,9 +205,12 @@ def main():
     if n == (1 << 24) and os.path.exists(tpath):
         try:
             tk = json.load(open(tpath))["kernels"]
-            key = next(k for k in tk if "fir_decimate_kernel16<4096, 2, 8>" in k)
-            result["roofline"]["traffic"] = tk[key]["hbm_bytes"]
-            result["roofline"]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+            keys = [k for k in tk if "fir_decimate_kernel16<4096, 2, 8, true>" in k
+                    or "fir_synth_kernel16<4096, 8, true>" in k]
+            if len(keys) == 2:
+                result["roofline"]["traffic"] = sum(tk[k]["hbm_bytes"] for k in keys)
+                result["roofline"]["traffic_source"] = ("profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + "
+                                                        "WRITE_SIZE, both kernels of a chain_run)")
         except (StopIteration, KeyError, ValueError):
             pass
 

@@ -71,7 +71,8 @@ __device__ __forceinline__ float2 ew_apply(const EwProgram &P, float2 v, uint64_
 // multiply chains interleave (instruction-level parallelism within a lane; the
 // one-sample form serialises them behind the rolled op loop).
 template <int W>
-__device__ __forceinline__ void ew_apply_n(const EwProgram &P, float2 (&v)[W], uint64_t j0, NcoWin w) {
+__device__ __forceinline__ void ew_apply_n(const EwProgram &P, float2 (&v)[W], uint64_t j0, NcoWin w,
+                                           uint64_t stride = 1) {
     double ts[W];
     bool have_ts = false;
 #pragma unroll 1
@@ -86,7 +87,7 @@ __device__ __forceinline__ void ew_apply_n(const EwProgram &P, float2 (&v)[W], u
         } else {
             if (!have_ts) {
 #pragma unroll
-                for (int l = 0; l < W; l++) ts[l] = nco_ts(P.segs, w, j0 + l);
+                for (int l = 0; l < W; l++) ts[l] = nco_ts(P.segs, w, j0 + l * stride);
                 have_ts = true;
             }
             double s[W], c[W];
@@ -515,10 +516,11 @@ __global__ __launch_bounds__(f16::block(N)) void conv_blocks_kernel16(const void
     }
 }
 
-// FOLD = D (power of two <= 16 with N/D >= 256): lane-local spectral fold, then a
-// backward transform of M = N/D points run by groups of M/16 lanes (group 0's
-// result is kept; the others run the same program on their own LDS slices so the
-// workgroup barriers stay uniform).  FOLD = 0: full backward transform + pick.
+// FOLD = D (power of two <= 16 with N/D >= 256): lane-local spectral fold to M = N/D
+// bins; the M-point inverse runs in fir_synth_kernel16.  (One kernel did both at first:
+// the inverse kept one group of M/16 lanes busy and parked the rest of the workgroup,
+// and cost as much as the whole forward transform -- 33 of 98 us.)  FOLD = 0: full
+// backward transform + pick, in this kernel.
 //
 // LATE: the mixer commutes with the filter.  Inside one exactly-linear run of the NCO
 // clock ts[n-k] = ts[n] - k*step, so with every elementwise stage a multiplication by a
@@ -535,11 +537,20 @@ struct LateFilters {
     const float2 *h[kNcoMaxSegs];
 };
 
+// workgroup-uniform: does block b (input span [p0, p0 + N)) take the late-mixer path?
+__device__ __forceinline__ bool late_block(const EwProgram &P, const LateFilters &late, int64_t p0, int N,
+                                           unsigned off, size_t n_in, NcoWin *run) {
+    *run = NcoWin{0, 0};
+    if (p0 < 0 || (uint64_t)p0 + (uint64_t)N + off > n_in) return false;
+    *run = nco_window(P.segs, (uint64_t)p0, (uint64_t)p0 + N - 1);
+    return run->lo == run->hi && late.h[run->lo] != nullptr;
+}
+
 template <int N, int FMT, int FOLD, bool LATE>
 __global__ __launch_bounds__(f16::block(N), LATE ? 4 : 1) void fir_decimate_kernel16(
     const void *in, float2 *out, const float2 *__restrict__ hist, float2 *__restrict__ new_hist,
     const float2 *__restrict__ hfreq,
-    const float2 *__restrict__ tw, const float2 *__restrict__ tw_small, size_t nblocks, size_t n_in,
+    const float2 *__restrict__ tw, float2 *__restrict__ spec, size_t nblocks, size_t n_in,
     unsigned hop, unsigned off, unsigned D, EwProgram P, LateFilters late) {
     constexpr int R0 = f16::first_radix(N), TPT = f16::tpt(N);
     static_assert(f16::xpb(N) == 1 || FOLD == 0, "fold path assumes one block per workgroup");
@@ -552,12 +563,7 @@ __global__ __launch_bounds__(f16::block(N), LATE ? 4 : 1) void fir_decimate_kern
     const int64_t p0 = (int64_t)(b * hop) - (int64_t)off;
     bool mix_late = false;  // workgroup-uniform
     NcoWin run{0, 0};
-    if constexpr (LATE) {
-        if (p0 >= 0 && (uint64_t)p0 + N + off <= n_in) {
-            run = nco_window(P.segs, (uint64_t)p0, (uint64_t)p0 + N - 1);
-            mix_late = run.lo == run.hi && late.h[run.lo] != nullptr;
-        }
-    }
+    if constexpr (LATE) mix_late = late_block(P, late, p0, N, off, n_in, &run);
     const float2 *__restrict__ hf = mix_late ? late.h[run.lo] : hfreq;
     float2 v[16];
     bool staged = false;
@@ -588,7 +594,7 @@ __global__ __launch_bounds__(f16::block(N), LATE ? 4 : 1) void fir_decimate_kern
             }
         }
     } else {
-        constexpr int M = N / FOLD, S = 16 / FOLD, TPTM = f16::tpt(M), RM = f16::first_radix(M);
+        constexpr int M = N / FOLD, S = 16 / FOLD;
         static_assert(f16::ok(M) && S >= 1, "fold geometry");
         // slot q holds bin lane + q*TPT; folded bin lane + s*TPT sums the slots with q % S == s
         float2 z[S];
@@ -596,43 +602,73 @@ __global__ __launch_bounds__(f16::block(N), LATE ? 4 : 1) void fir_decimate_kern
         for (int s2 = 0; s2 < S; s2++) z[s2] = v[s2];
 #pragma unroll
         for (int q = S; q < 16; q++) z[q % S] = f16::cadd(z[q % S], v[q]);
-        __syncthreads();  // forward's last-pass LDS reads are done
+        if (live) {
 #pragma unroll
-        for (int s2 = 0; s2 < S; s2++) lds[lane + TPT * s2] = z[s2];
-        __syncthreads();
-        // the M-point inverse runs on the first M/16 lanes only; the other waves just
-        // attend its barriers and leave their SIMD issue slots to co-resident blocks
-        const int g = lane / TPTM, l2 = lane % TPTM;
-        float2 w[16];
-        if (g == 0) {
-#pragma unroll
-            for (int q = 0; q < 16; q++) w[q] = lds[f16::edge_index<M, 16>(q, l2)];
+            for (int s2 = 0; s2 < S; s2++) spec[b * M + lane + TPT * s2] = z[s2];
         }
-        f16::backward<M>(w, lds, tw_small, l2, g == 0);
-        const unsigned i_lo = off / FOLD, i_hi = (off + hop) / FOLD;
-        if (!mix_late) {
-            if (g == 0) {
+    }
+}
+
+// The other half of the folded FIR-decimate: the M-point inverse of every block's folded
+// spectrum -- M/16 lanes per block, 256 / (M/16) blocks per workgroup, every lane busy --
+// then, for blocks on the late-mixer path, the elementwise program over the hop/D
+// outputs (output m sits at stream position D*m).
+template <int N, int FOLD> struct SynthGeom {
+    static constexpr int M = N / FOLD, TPTM = f16::tpt(M);
+    static constexpr int BS = TPTM > 64 ? TPTM : 64;  // one wave where a block's group fits in it:
+    static constexpr int XPB = BS / TPTM;              // many small workgroups, all resident at once
+};
+
+template <int N, int FOLD, bool LATE>
+__global__ __launch_bounds__((SynthGeom<N, FOLD>::BS)) void fir_synth_kernel16(
+    const float2 *__restrict__ spec, float2 *out, const float2 *__restrict__ tw_small, size_t nblocks,
+    size_t n_in, unsigned hop, unsigned off, EwProgram P, LateFilters late) {
+    using G = SynthGeom<N, FOLD>;
+    constexpr int M = G::M, TPTM = G::TPTM, RM = f16::first_radix(M), XPB = G::XPB;
+    static_assert(f16::ok(M) && XPB >= 1, "synthesis geometry");
+    __shared__ float2 lds_all[XPB * f16::lds_elems(M)];
+    const int sub = threadIdx.x / TPTM, l2 = threadIdx.x % TPTM;
+    float2 *lds = lds_all + sub * f16::lds_elems(M);
+    const size_t b = (size_t)blockIdx.x * XPB + sub;
+    const bool live = b < nblocks;
+    float2 w[16];
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const unsigned i = f16::edge_index<M, RM>(q, l2);
-                    if (i >= i_lo && i < i_hi) {
-                        const size_t m_out = b * (hop / FOLD) + (i - i_lo);
-                        if (m_out * FOLD < n_in) out[m_out] = w[q];
-                    }
-                }
-            }
-        } else if constexpr (LATE) {
-            // hop/D filtered samples back to LDS, then the elementwise program over them
-            // on every lane of the workgroup: output m sits at stream position D*m
-            if (g == 0) {  // the lanes that read the last pass's inputs are the ones that write
+    for (int q = 0; q < 16; q++)
+        w[q] = live ? spec[b * M + f16::edge_index<M, 16>(q, l2)] : make_float2(0.f, 0.f);
+    f16::backward<M>(w, lds, tw_small, l2);
+    const unsigned i_lo = off / FOLD, i_hi = (off + hop) / FOLD, per = hop / FOLD;
+    bool mix_late = false;  // uniform per block (= per group of TPTM lanes)
+    NcoWin run{0, 0};
+    if constexpr (LATE) mix_late = live && late_block(P, late, (int64_t)(b * hop) - (int64_t)off, N, off, n_in, &run);
+    if (live && !mix_late) {
 #pragma unroll
-                for (int q = 0; q < 16; q++) lds[f16::edge_index<M, RM>(q, l2)] = w[q];
+        for (int q = 0; q < 16; q++) {
+            const unsigned i = f16::edge_index<M, RM>(q, l2);
+            if (i >= i_lo && i < i_hi) {
+                const size_t m_out = b * per + (i - i_lo);
+                if (m_out * FOLD < n_in) out[m_out] = w[q];
             }
-            __syncthreads();
-            const unsigned per = hop / FOLD;
-            for (unsigned t = lane; t < per; t += TPT) {
-                const uint64_t j = (uint64_t)b * hop + (uint64_t)t * FOLD;
-                out[b * per + t] = ew_apply(P, lds[i_lo + t], j, run);
+        }
+    }
+    if constexpr (LATE) {
+        __syncthreads();  // every group's last-pass reads are done: its region can take the outputs
+        if (mix_late) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) lds[f16::edge_index<M, RM>(q, l2)] = w[q];
+        }
+        __syncthreads();
+        if (mix_late) {
+            // four outputs per lane per trip: four independent Sincos chains in flight
+            constexpr int W = 4;
+#pragma unroll 1
+            for (unsigned t0 = l2; t0 < per; t0 += W * TPTM) {
+                float2 y[W];
+#pragma unroll
+                for (int l = 0; l < W; l++) y[l] = lds[i_lo + (t0 + l * TPTM < per ? t0 + l * TPTM : t0)];
+                ew_apply_n<W>(P, y, (uint64_t)b * hop + (uint64_t)t0 * FOLD, run, (uint64_t)TPTM * FOLD);
+#pragma unroll
+                for (int l = 0; l < W; l++)
+                    if (t0 + l * TPTM < per) out[b * per + t0 + l * TPTM] = y[l];
             }
         }
     }
@@ -883,20 +919,32 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
         else HZ_FIR(N, 0);                                                               \
     } while (0)
 // radix-16 core: fold when D is a power of two <= 16 and N/D is itself a radix-16 size
-#define HZ_FIR16_L(N, FOLD, LATE)                                                                       \
+#define HZ_FIR16_L(N, FOLD, LATE, SPEC)                                                                 \
     hipLaunchKernelGGL((fir_decimate_kernel16<N, FMT, FOLD, LATE>),                                     \
                        dim3((unsigned)((nblocks + f16::xpb(N) - 1) / f16::xpb(N))), dim3(f16::block(N)), \
-                       0, ctx->stream, in, (float2 *)out, hist, nhist, (const float2 *)c->hfreq, tw, tws, \
+                       0, ctx->stream, in, (float2 *)out, hist, nhist, (const float2 *)c->hfreq, tw, SPEC, \
                        nblocks, n_cons, c->hop, c->off, D, P, late)
-#define HZ_FIR16(N, FOLD) HZ_FIR16_L(N, FOLD, false)
+#define HZ_FIR16(N, FOLD) HZ_FIR16_L(N, FOLD, false, (float2 *)nullptr)
+#define HZ_SYNTH16(N, F, LATE)                                                                           \
+    hipLaunchKernelGGL((fir_synth_kernel16<N, F, LATE>),                                                 \
+                       dim3((unsigned)((nblocks + SynthGeom<N, F>::XPB - 1) / SynthGeom<N, F>::XPB)),     \
+                       dim3(SynthGeom<N, F>::BS), 0, ctx->stream, (const float2 *)spec, (float2 *)out, tws, nblocks, n_cons, \
+                       c->hop, c->off, P, late)
 #define HZ_FIR16_FOLD(N, F)                                                            \
     if (D == F) {                                                                      \
         if constexpr (f16::xpb(N) == 1 && f16::ok(N / F)) {                            \
             HZ_TRY(get_twiddles(ctx, N / F, &tws));                                    \
             bool any_late = false;                                                     \
             HZ_TRY(late_filters(c, P, n_cons, &late, &any_late));                      \
-            if (any_late) HZ_FIR16_L(N, F, true);                                      \
-            else HZ_FIR16(N, F);                                                       \
+            HZ_TRY(ensure_slot(ctx, 11, nblocks * (size_t)(N / F) * 8));               \
+            float2 *spec = (float2 *)ctx->slots[11].ptr;                               \
+            if (any_late) {                                                            \
+                HZ_FIR16_L(N, F, true, spec);                                          \
+                HZ_SYNTH16(N, F, true);                                                \
+            } else {                                                                   \
+                HZ_FIR16_L(N, F, false, spec);                                         \
+                HZ_SYNTH16(N, F, false);                                               \
+            }                                                                          \
             break;                                                                     \
         }                                                                              \
     }
@@ -922,6 +970,7 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
 #undef HZ_FIR16_FOLD
 #undef HZ_FIR16
 #undef HZ_FIR16_L
+#undef HZ_SYNTH16
 #undef HZ_FIR_N
 #undef HZ_FIR
         c->hist_cur ^= 1;  // the kernel wrote the next run's history into nhist

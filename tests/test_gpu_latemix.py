@@ -75,6 +75,8 @@ CASES = {
     # several stages in front of the filter, two of them Shifts on the shared clock
     "program": dict(fmt="c64", rate=2_400_000, ops=[("gain", 0.5), ("shift", 100e3), ("rotate", 0.6 - 0.8j),
                                                      ("shift", -350e3)], ntaps=257, D=4, n=1 << 20),
+    # D = 2: the folded inverse is 2048 points on 128 lanes (two waves)
+    "d2": dict(fmt="u8", rate=20_000_000, ops=[("shift", -2.5e6)], ntaps=1024, D=2, n=1 << 20),
     "d16": dict(fmt="u8", rate=20_000_000, ops=[("shift", 1e6)], ntaps=600, D=16, n=1 << 20),
 }
 
