@@ -5,8 +5,8 @@
 
 A step = one pass of the north-star chain (u8 -> c64 -> Shift(-fs/8) -> 1024-tap
 FIR -> decimate-by-8: one hzsdr_chain_run, no full-rate c64 intermediate in HBM)
-over one 2^24-sample synthetic buffer already resident in HBM.  With N > 1 every rank runs its own independent stream
-("single-stream chains stay on one GPU": replicas, weak scaling, no data-path
+over one 2^24-sample synthetic buffer already resident in HBM.  With N > 1 every
+rank runs its own independent stream ("single-stream chains stay on one GPU": replicas, weak scaling, no data-path
 collective) and the line also carries the 4-channel Beamform measurement sharded
 over the ranks with its RCCL exchange (the other half of the metric).
 
@@ -217,7 +217,7 @@ def main():
     # ---- side measurements: the other BASELINE configs (rank 0, N = 1 semantics) ----
     if rank == 0 and not args.no_extra:
         extra = {}
-        k, w = max(5, args.steps // 5), 2
+        k, w = 20, 3  # median of 20 runs after 3 warm-ups, per-call HIP events
 
         def rate(nsamp, ms, bytes_per_sample):
             return {"Msamples_per_s": round(nsamp / (ms * 1e-3) / 1e6, 1), "kernel_ms": round(ms, 4),
@@ -232,44 +232,44 @@ def main():
         del u, g
         ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D)
         _, ms = timed(torch, lambda: ch.run(xa, y), k, w)
-        extra["chain_adc_like_u8"] = rate(n, float(np.mean(ms)), 2 + 8 / D)
+        extra["chain_adc_like_u8"] = rate(n, float(np.median(ms)), 2 + 8 / D)
         ch.close()
         del xa
         # the same chain with the mixer forced in front of the filter on every block
         ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D).mix_in_order(True)
         _, ms = timed(torch, lambda: ch.run(x, y), k, w)
-        extra["chain_mix_in_order"] = rate(n, float(np.mean(ms)), 2 + 8 / D)
+        extra["chain_mix_in_order"] = rate(n, float(np.median(ms)), 2 + 8 / D)
         ch.close()
         c = torch.from_numpy(synth_c64(2, n)).cuda()
         out = torch.zeros(n, dtype=torch.complex64, device="cuda")
         # the same-run device copy (8 B read + 8 B written per sample): the practical HBM
         # ceiling the HBM-bound rows below are also quoted against
         _, ms = timed(torch, lambda: out.copy_(c), k, w)
-        extra["device_copy_c64"] = rate(n, float(np.mean(ms)), 16)
+        extra["device_copy_c64"] = rate(n, float(np.median(ms)), 16)
         copy_gbps = extra["device_copy_c64"]["GBps"]
         # cfg 1 kernel: u8 -> c64 (10 B/sample)
         _, ms = timed(torch, lambda: ctx.convert(out, x), k, w)
-        extra["convert_u8_c64"] = rate(n, float(np.mean(ms)), 10)
+        extra["convert_u8_c64"] = rate(n, float(np.median(ms)), 10)
         # cfg 2: Shift + Gain fused (16 B/sample)
         ch = ctx.chain(hz.FMT_C64, fs).shift(2.5e6).gain(0.5)
         _, ms = timed(torch, lambda: ch.run(c, out), k, w)
-        extra["shift_gain_c64"] = rate(n, float(np.mean(ms)), 16)
+        extra["shift_gain_c64"] = rate(n, float(np.median(ms)), 16)
         ch.close()
         # cfg 3: reference ConvolutionReader semantics, 1024 bins (16 B/sample)
         H = torch.from_numpy(np.fft.fft(np.asarray(taps, np.complex128) / ntaps).astype(np.complex64)).cuda()
         _, ms = timed(torch, lambda: ctx.convolution_blocks(out, c, H), k, w)
-        extra["convolution_1024_circular"] = rate(n, float(np.mean(ms)), 16)
+        extra["convolution_1024_circular"] = rate(n, float(np.median(ms)), 16)
         # cfg 4: Downsample by 8 from i16 (5 B/input sample)
         xi = torch.from_numpy(synth_i16(4, n)).cuda()
         o8 = torch.zeros(n // 8, dtype=torch.complex64, device="cuda")
         _, ms = timed(torch, lambda: ctx.downsample(o8, xi, 8), k, w)
-        extra["downsample8_i16"] = rate(n, float(np.mean(ms)), 5)
+        extra["downsample8_i16"] = rate(n, float(np.median(ms)), 5)
         del xi, o8
         # cfg 5 on one GPU: 4-channel c64 beamform (40 B/output sample)
         chans = [torch.from_numpy(synth_c64(5 + i, n)).cuda() for i in range(4)]
         wts = hz.beamform_angles(433e6, 30.0, [0.0, 0.1, 0.2, 0.3])
         _, ms = timed(torch, lambda: ctx.beamform(out, chans, wts), k, w)
-        extra["beamform4_c64_1gpu"] = rate(n, float(np.mean(ms)), 40)
+        extra["beamform4_c64_1gpu"] = rate(n, float(np.median(ms)), 40)
         del chans, c, out
         for name, row in extra.items():
             if name != "device_copy_c64":
