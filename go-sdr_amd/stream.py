@@ -17,11 +17,13 @@ its output is read -- same block structure, no threads -- because the data path
 is the GPU call, not the plumbing.  Readers work on HOST contexts (numpy buffers),
 exactly what a cgo caller with Go slices gets.
 """
+import sys
+
 import numpy as np
 
 from . import (FMT_C64, FMT_I8, FMT_I16, FMT_U8, FFT_BACKWARD, FFT_FORWARD, Context,
                ErrDstTooSmall, ErrSampleFormatMismatch, ErrSampleFormatUnknown, HzsdrError,
-               beamform_angles, beamform_angles_2d, fmt_of, length, make_samples)
+               beamform_angles, beamform_angles_2d, fmt_of, format_size, length, make_samples)
 
 READER_BLOCK = 32 * 1024  # stream/convert.go:43-44, decimate.go:41-42, downsample.go:54-55
 
@@ -142,6 +144,76 @@ class ReadTransformer(Reader):
 
     def sample_rate(self):
         return self.out_rate
+
+
+NATIVE_ENDIAN = sys.byteorder  # "little" on every platform this runs on
+
+
+class ByteReader(Reader):
+    """sdr.ByteReader (bytes_io.go:196-219): IQ samples decoded from an io stream of raw
+    bytes.  Native byte order reads straight into the buffer (bytes_io.go:170-181); the
+    other order (byteReaderForeign, :125-160) reads the same bytes and reverses every
+    int16 / float32 component on the GPU.  Like binary.Read, the foreign i16 / c64 path
+    wants the whole buffer (a short read is ErrUnexpectedEOF, nothing at all is EOF)."""
+
+    def __init__(self, ctx, r, byte_order, samples_per_second, sample_format):
+        self.ctx, self.r, self.rate, self.fmt = ctx, r, int(samples_per_second), sample_format
+        self.foreign = byte_order != NATIVE_ENDIAN
+
+    def sample_format(self):
+        return self.fmt
+
+    def sample_rate(self):
+        return self.rate
+
+    def read(self, samples):
+        if fmt_of(samples) != self.fmt:
+            raise ErrSampleFormatMismatch("sdr: iq sample formats do not match")
+        raw = samples.view(np.uint8).reshape(-1)
+        whole = self.foreign and self.fmt in (FMT_I16, FMT_C64)
+        got = 0
+        while got < raw.size:
+            chunk = self.r.read(raw.size - got)
+            if not chunk:
+                break
+            raw[got:got + len(chunk)] = np.frombuffer(chunk, np.uint8)
+            got += len(chunk)
+            if not whole:
+                break
+        size = format_size(self.fmt)
+        if got == 0 and raw.size:
+            raise EOF()
+        if whole and got < raw.size:
+            raise ErrUnexpectedEOF("sdr: unexpected EOF")
+        n = got // size
+        if whole:
+            self.ctx.byteswap(samples)
+        return n
+
+
+class ByteWriter:
+    """sdr.ByteWriter (bytes_io.go:98-121): the inverse; a foreign order swaps a copy
+    on the GPU (byteWriterForeign, :30-64) and writes that."""
+
+    def __init__(self, ctx, w, byte_order, samples_per_second, sample_format):
+        self.ctx, self.w, self.rate, self.fmt = ctx, w, int(samples_per_second), sample_format
+        self.foreign = byte_order != NATIVE_ENDIAN
+
+    def sample_format(self):
+        return self.fmt
+
+    def sample_rate(self):
+        return self.rate
+
+    def write(self, samples):
+        if fmt_of(samples) != self.fmt:
+            raise ErrSampleFormatMismatch("sdr: iq sample formats do not match")
+        out = samples
+        if self.foreign and self.fmt in (FMT_I16, FMT_C64):
+            out = np.ascontiguousarray(samples).copy()
+            self.ctx.byteswap(out)
+        self.w.write(out.view(np.uint8).reshape(-1).tobytes())
+        return length(samples)
 
 
 class Stream:

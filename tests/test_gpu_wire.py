@@ -99,6 +99,59 @@ def test_convert_foreign_errors(hz, env):
         env.ctx.convert_foreign(env.put(zeros("i16", 10)), env.put(zeros("i16", 10)), False, True)
 
 
+@pytest.mark.parametrize("order", ["little", "big"])
+def test_bytes_io_kat(hz, order):
+    """bytes_io_test.go:69-127 (TestBytesIOLE / TestBytesIOBE): ten writes of 1024 c64
+    samples with sample 10 = 20+10i through ByteWriter -> bytes -> ByteReader + ReadFull."""
+    import io
+    S = importlib.import_module("go-sdr_amd.stream")
+    ctx = hz.Context(0, hz.MEM_HOST)
+    pipe = io.BytesIO()
+    w = S.ByteWriter(ctx, pipe, order, 0, hz.FMT_C64)
+    for _ in range(10):
+        wb = zeros("c64", 1024)
+        wb[10] = 20 + 10j
+        assert w.write(wb) == 1024
+    wire = pipe.getvalue()
+    # the wire really is in that order: numpy decodes it with an explicit-endian dtype
+    dec = np.frombuffer(wire, np.dtype("<f4" if order == "little" else ">f4")).astype(np.float32)
+    assert dec[2 * 10] == 20 and dec[2 * 10 + 1] == 10
+    r = S.ByteReader(ctx, io.BytesIO(wire), order, 0, hz.FMT_C64)
+    buf = zeros("c64", 1024 * 10)
+    assert S.read_full(r, buf) == 1024 * 10
+    for i in range(10):
+        assert buf[i * 1024 + 10] == np.complex64(20 + 10j)
+    with pytest.raises(S.EOF):
+        r.read(zeros("c64", 4))
+    with pytest.raises(hz.ErrSampleFormatMismatch):  # bytes_io.go:126-128
+        r.read(zeros("u8", 4))
+    ctx.close()
+
+
+@pytest.mark.parametrize("fmt,gen,wire_dt", [("i16", rand_i16, ">i2"), ("c64", rand_c64, ">f4"),
+                                             ("u8", rand_u8, "u1")])
+def test_byte_reader_decodes_big_endian_captures(hz, fmt, gen, wire_dt):
+    """A big-endian capture file read through ByteReader equals what numpy decodes."""
+    import io
+    S = importlib.import_module("go-sdr_amd.stream")
+    ctx = hz.Context(0, hz.MEM_HOST)
+    x = gen(9, 50_000)
+    comp = x.view(np.float32) if fmt == "c64" else x
+    wire = comp.astype(np.dtype(wire_dt)).tobytes()
+    r = S.ByteReader(ctx, io.BytesIO(wire), "big", 2_400_000, hz.FMT_C64 if fmt == "c64" else getattr(hz, "FMT_" + fmt.upper()))
+    got = zeros(fmt, 50_000)
+    assert S.read_full(r, got) == 50_000
+    assert bits_equal(got, x)
+    # a capture that ends mid-buffer: binary.Read semantics for the foreign i16 / c64 path
+    r2 = S.ByteReader(ctx, io.BytesIO(wire[:len(wire) // 2 + 1]), "big", 0, r.sample_format())
+    if fmt != "u8":
+        with pytest.raises(S.ErrUnexpectedEOF):
+            r2.read(zeros(fmt, 50_000))
+    else:
+        assert r2.read(zeros(fmt, 50_000)) == (len(wire) // 2 + 1) // 2
+    ctx.close()
+
+
 @pytest.mark.parametrize("gen", [rand_u8, rand_i8])
 def test_byteswap_bytes_have_no_order(env, gen):
     x = gen(5, 1000)
