@@ -404,9 +404,7 @@ __global__ __launch_bounds__(fft_block(N), fft_waves(N)) void fir_decimate_kerne
 template <int N, int FMT>
 __device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const EwProgram &P, int64_t p0,
                                               size_t n_in, const float2 *hist, unsigned off, int lane,
-                                              bool live, float2 *new_hist = nullptr, bool apply = true) {
-    // apply == false (workgroup-uniform): converted samples only, the elementwise
-    // program runs after the filter instead (fir_decimate_kernel16, LATE blocks)
+                                              bool live, float2 *new_hist = nullptr) {
     using R = typename Raw<FMT>::t;
     constexpr int TPT = f16::tpt(N), STEP = TPT * 2;
     struct alignas(sizeof(R) * 2) RV { R v[2]; };
@@ -448,7 +446,7 @@ __device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const
             // third inlined copy of the float64 Sincos on a divergent path.
             const bool in0 = p >= 0 && (size_t)p < n_in, in1 = p + 1 >= 0 && (size_t)(p + 1) < n_in;
             float2 ab[2] = {Raw<FMT>::cvt(x.v[0]), Raw<FMT>::cvt(x.v[1])};
-            if (apply) ew_apply_n<2>(P, ab, (uint64_t)p, w);  // (uint64)(-1) + 1 wraps to sample 0
+            ew_apply_n<2>(P, ab, (uint64_t)p, w);  // (uint64)(-1) + 1 wraps to sample 0
             if (in0) a = ab[0]; else if (p < 0 && hist) a = hist[p + off];
             if (in1) b = ab[1]; else if (p + 1 < 0 && hist) b = hist[p + 1 + off];
         }
@@ -456,28 +454,6 @@ __device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const
         const int q = f16::pad(i0);  // i0 even: i0 and i0+1 share a 16-element row
         lds[q] = a;
         lds[q + 1] = b;
-    }
-}
-
-// Conversion-only staging of a block that lies wholly inside the buffer (LATE blocks):
-// every lane issues all of its 16-byte loads first (8 u8 / 4 i16 / 2 c64 samples each),
-// then converts and writes its rows -- no per-sample arithmetic to hide the load latency
-// behind, so the loads must all be in flight at once.  `src` = in + p0 samples, 16-B aligned.
-template <int N, int FMT>
-__device__ __forceinline__ void stage_block16_raw(float2 *lds, const void *src, int lane) {
-    using R = typename Raw<FMT>::t;
-    constexpr int TPT = f16::tpt(N), SPL = 16 / (int)sizeof(R), TRIPS = N / (TPT * SPL);
-    static_assert(TRIPS >= 1 && N % (TPT * SPL) == 0, "raw staging geometry");
-    struct alignas(16) RV { R v[SPL]; };
-    RV x[TRIPS];
-#pragma unroll
-    for (int t = 0; t < TRIPS; t++) x[t] = ((const RV *)src)[t * TPT + lane];
-#pragma unroll
-    for (int t = 0; t < TRIPS; t++) {
-        const int i0 = (t * TPT + lane) * SPL;  // SPL divides 16: one padded row
-        const int q = f16::pad(i0);
-#pragma unroll
-        for (int s = 0; s < SPL; s++) lds[q + s] = Raw<FMT>::cvt(x[t].v[s]);
     }
 }
 
@@ -566,19 +542,24 @@ __global__ __launch_bounds__(f16::block(N), LATE ? 4 : 1) void fir_decimate_kern
     if constexpr (LATE) mix_late = late_block(P, late, p0, N, off, n_in, &run);
     const float2 *__restrict__ hf = mix_late ? late.h[run.lo] : hfreq;
     float2 v[16];
-    bool staged = false;
-    if constexpr (LATE) {
+    if (LATE && mix_late) {
+        // a late block lies wholly inside the buffer and needs no arithmetic per input
+        // sample: its samples go from global memory straight into the first pass's
+        // register image (a wave reads 64 consecutive samples per load), no LDS staging
         using R = typename Raw<FMT>::t;
         const R *src = (const R *)in + p0;
-        if (mix_late && ((uintptr_t)src % 16) == 0) {
-            stage_block16_raw<N, FMT>(lds, src, lane);
-            staged = true;
-        }
+        R raw[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) raw[q] = src[f16::edge_index<N, R0>(q, lane)];
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = Raw<FMT>::cvt(raw[q]);
+        f16::forward<N>(v, lds, tw, lane);
+    } else {
+        stage_block16<N, FMT>(lds, in, P, p0, n_in, hist, off, lane, live, new_hist);
+        __syncthreads();
+        f16::load_lds<N, R0>(v, lds, lane);
+        f16::forward<N, true>(v, lds, tw, lane);
     }
-    if (!staged) stage_block16<N, FMT>(lds, in, P, p0, n_in, hist, off, lane, live, new_hist, !mix_late);
-    __syncthreads();
-    f16::load_lds<N, R0>(v, lds, lane);
-    f16::forward<N, true>(v, lds, tw, lane);
 #pragma unroll
     for (int q = 0; q < 16; q++) v[q] = f16::cmul(v[q], hf[f16::edge_index<N, 16>(q, lane)]);
     if constexpr (FOLD == 0) {
