@@ -842,7 +842,14 @@ static int late_filter_for(hzsdr_chain *c, double step, double omega, void **dev
 static int late_filters(hzsdr_chain *c, const EwProgram &P, size_t n, LateFilters *out, bool *any) {
     *any = false;
     memset(out, 0, sizeof *out);
-    if (c->mix_in_order || !c->has_shift || P.segs.big_n != 0 || c->taps_host.empty()) return HZSDR_OK;
+    if (c->mix_in_order || P.segs.big_n != 0 || c->taps_host.empty()) return HZSDR_OK;
+    if (!c->has_shift) {
+        // no clock involved: Gain / Multiply commute with the filter everywhere, with the
+        // taps as they are (the kernel sees an empty run table: run 0)
+        out->h[0] = (const float2 *)c->hfreq;
+        *any = true;
+        return HZSDR_OK;
+    }
     double omega = 0.0;
     for (int i = 0; i < P.n; i++)
         if (P.op[i].kind == EW_SHIFT) omega += P.op[i].tau_shift;
