@@ -534,7 +534,13 @@ __global__ __launch_bounds__(f16::block(N), LATE ? 4 : 1) void fir_decimate_kern
     __shared__ float2 lds_all[f16::xpb(N) * f16::lds_elems(N)];
     const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
     float2 *lds = lds_all + sub * f16::lds_elems(N);
-    const size_t b = (size_t)blockIdx.x * f16::xpb(N) + sub;
+    size_t b = (size_t)blockIdx.x * f16::xpb(N) + sub;
+    if constexpr (LATE) {
+        // the stream's last two blocks mix in reference order (several times the work of a
+        // late block): dispatched last they would be the kernel's tail, so they go first
+        static_assert(f16::xpb(N) == 1, "block rotation assumes one block per workgroup");
+        if (nblocks > 2) b = b < 2 ? nblocks - 2 + b : b - 2;
+    }
     const bool live = b < nblocks;
     const int64_t p0 = (int64_t)(b * hop) - (int64_t)off;
     bool mix_late = false;  // workgroup-uniform
