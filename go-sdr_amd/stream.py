@@ -146,6 +146,68 @@ class ReadTransformer(Reader):
         return self.out_rate
 
 
+class Writer:
+    """sdr.Writer (writer.go:31-43)."""
+
+    def write(self, samples):
+        raise NotImplementedError
+
+    def sample_format(self):
+        raise NotImplementedError
+
+    def sample_rate(self):
+        raise NotImplementedError
+
+
+class BufferWriter(Writer):
+    """An in-memory sink: the read end of an sdr.Pipe in the reference's writer tests."""
+
+    def __init__(self, fmt, sample_rate):
+        self.fmt, self.rate, self.chunks = fmt, int(sample_rate), []
+
+    def write(self, samples):
+        if fmt_of(samples) != self.fmt:
+            raise ErrSampleFormatMismatch("sdr: iq sample formats do not match")
+        self.chunks.append(np.array(samples, copy=True))
+        return length(samples)
+
+    def sample_format(self):
+        return self.fmt
+
+    def sample_rate(self):
+        return self.rate
+
+    def samples(self):
+        return np.concatenate(self.chunks) if self.chunks else make_samples(self.fmt, 0)
+
+
+class ConvertWriter(Writer):
+    """stream.ConvertWriter (stream/convert.go:53-118): accepts `input_format`, converts
+    32 Ki samples at a time on the GPU and writes them to `out` in out's format."""
+
+    def __init__(self, ctx, out, input_format):
+        self.ctx, self.out, self.input_format = ctx, out, input_format
+        self.buffer = make_samples(out.sample_format(), READER_BLOCK)
+
+    def sample_format(self):
+        return self.input_format
+
+    def sample_rate(self):
+        return self.out.sample_rate()
+
+    def write(self, samples):
+        if fmt_of(samples) != self.input_format:
+            raise ErrSampleFormatMismatch("sdr: iq sample formats do not match")
+        n = 0
+        for i in range(0, length(samples), READER_BLOCK):
+            ie = min(i + READER_BLOCK, length(samples))
+            got = self.ctx.convert(self.buffer, samples[i:ie])
+            if got != ie - i:
+                raise HzsdrError("ConvertWriter: Conversion mismatch")
+            n += self.out.write(self.buffer[:got])
+        return n
+
+
 NATIVE_ENDIAN = sys.byteorder  # "little" on every platform this runs on
 
 
@@ -227,6 +289,10 @@ class Stream:
     def convert_reader(self, inp, to):
         return ReadTransformer(inp, READER_BLOCK, READER_BLOCK, to, inp.sample_rate(),
                                lambda i, o: self.ctx.convert(o, i))
+
+    # stream.ConvertWriter, stream/convert.go:53-118
+    def convert_writer(self, out, input_format):
+        return ConvertWriter(self.ctx, out, input_format)
 
     # stream.DecimateReader, stream/decimate.go:34-55
     def decimate_reader(self, inp, factor):

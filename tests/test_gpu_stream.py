@@ -71,6 +71,26 @@ def test_convert_reader_drops_partial_block(hz, S, st):
     assert e.value.n == 32768
 
 
+def test_convert_writer(hz, S, st, orc):
+    """stream/convert_test.go:81-108 (TestConvertWriterBufferU8C64): 8000 c64 samples
+    written through ConvertWriter arrive as 8000 u8 samples at the underlying writer;
+    values against the oracle, and a length that is not a multiple of the 32 Ki chunk."""
+    sink = S.BufferWriter(hz.FMT_U8, 1337)
+    w = st.convert_writer(sink, hz.FMT_C64)
+    assert w.sample_format() == hz.FMT_C64 and w.sample_rate() == 1337
+    assert w.write(zeros("c64", 1000 * 8)) == 1000 * 8
+    assert hz.length(sink.samples()) == 1000 * 8
+    x = (rand_c64(12, 100_000) * np.float32(0.99)).astype(np.complex64)
+    sink2 = S.BufferWriter(hz.FMT_I16, 0)
+    assert st.convert_writer(sink2, hz.FMT_C64).write(x) == 100_000
+    want = zeros("i16", 100_000)
+    orc.convert(want, x)
+    assert bits_equal(sink2.samples(), want)
+    assert [hz.length(c) for c in sink2.chunks] == [32768, 32768, 32768, 100_000 - 3 * 32768]
+    with pytest.raises(hz.ErrSampleFormatMismatch):  # stream/convert.go:86-88
+        w.write(zeros("u8", 16))
+
+
 def test_gain_reader(hz, S, st, kats):
     """stream/gain_test.go:52-80."""
     src = filled("c64", 1024, [10, 10])
