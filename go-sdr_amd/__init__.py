@@ -300,6 +300,19 @@ class Context:
     def cross_correlate(self, dst, iq1, iq2):
         return Convolver(self, "xcorr", dst, iq1, iq2)
 
+    def convolve_once(self, dst, iq1, iq2):
+        """fft.ConvolveOnce (fft/convolution.go:200-211)."""
+        conv = self.convolve(dst, iq1, iq2)
+        try:
+            conv()
+        finally:
+            conv.close()
+
+    def fft_shift(self, frequency):
+        """fft.Shift (fft/result.go:230-236, :84-98): swap the halves, 0 Hz to the centre
+        (x / 1.0 is exact, so this is FFTShiftAndScale with scale 1)."""
+        self.fftshift_scale(frequency, 1.0)
+
     def convolution_blocks(self, out, inp, filt):
         n = C.c_size_t(0)
         self._ck(lib.hzsdr_convolution_blocks(self._h, _ptr(out), length(out), _ptr(inp), length(inp),

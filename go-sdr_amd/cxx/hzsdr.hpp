@@ -412,6 +412,12 @@ inline ClosurePtr Convolve(const Context &x, Samples dst, Samples iq1, Samples i
 inline ClosurePtr CrossCorrelate(const Context &x, Samples dst, Samples iq1, Samples iq2) {
     return two_input(x, dst, iq1, iq2, HZSDR_CONV_CROSS_CORRELATE);
 }
+// fft.ConvolveOnce (fft/convolution.go:200-211)
+inline void ConvolveOnce(const Context &x, Samples dst, Samples iq1, Samples iq2) { (*Convolve(x, dst, iq1, iq2))(); }
+// fft.Shift (fft/result.go:230-236, :84-98): 0 Hz to the centre of the buffer and back
+inline void Shift(const Context &x, Samples frequency) {
+    check(x.raw(), hzsdr_fftshift_scale(x.raw(), frequency.data, frequency.length, 1.0f));
+}
 // fft.ConvolveFreq (fft/convolution.go:150-192)
 inline ClosurePtr ConvolveFreq(const Context &x, Samples dst, Samples src, Samples freq) {
     hzsdr_conv *c = nullptr;

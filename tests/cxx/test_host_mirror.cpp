@@ -282,6 +282,18 @@ int main() {
         int64_t lag = 99;
         check(ctx.raw(), hzsdr_peak_lag(ctx.raw(), out.data(), n, &lag));
         EXPECT(lag == 0);
+        // fft/result_test.go:186-204 TestFFTShift
+        std::vector<c64> f(2048);
+        for (int i = 0; i < 2048; i++) f[i] = c64(float(i < 1024 ? i : i - 2048), 0.f);
+        fft::Shift(ctx, view(HZSDR_FMT_C64, f, 1));
+        EXPECT(f[0] == c64(-1024.f, 0.f) && f[1024] == c64(0.f, 0.f) && f[2047] == c64(1023.f, 0.f));
+        fft::Shift(ctx, view(HZSDR_FMT_C64, f, 1));
+        EXPECT(f[0] == c64(0.f, 0.f) && f[1024] == c64(-1024.f, 0.f) && f[1023] == c64(1023.f, 0.f));
+        std::vector<c64> once(n);  // fft.ConvolveOnce: same result as the planned closure above
+        fft::ConvolveOnce(ctx, view(HZSDR_FMT_C64, once, 1), view(HZSDR_FMT_C64, x, 1), view(HZSDR_FMT_C64, d, 1));
+        ok = true;
+        for (size_t i = 0; i < n && ok; i++) ok = std::abs(once[i] - x[(i + n - 3) % n] * float(n)) <= 2e-3f * float(n);
+        EXPECT(ok);
         std::vector<c64> shorter(n / 2);
         try {
             fft::Convolve(ctx, view(HZSDR_FMT_C64, out, 1), view(HZSDR_FMT_C64, x, 1), view(HZSDR_FMT_C64, shorter, 1));

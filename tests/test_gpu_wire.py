@@ -171,6 +171,30 @@ def test_fftshift_scale_bit_exact(env, orc, n, scale):
     assert bits_equal(env.get(d), want)
 
 
+def test_fft_shift_kat(env):
+    """fft/result_test.go:186-204 (TestFFTShift): 2048 bins holding their own signed
+    frequency index; Shift puts -1024 first and 0 at 1024, Shift again restores it."""
+    f = np.concatenate([np.arange(1024), np.arange(-1024, 0)]).astype(np.complex64)
+    d = env.put(f)
+    env.ctx.fft_shift(d)
+    got = env.get(d).copy()
+    assert got[0] == -1024 and got[1024] == 0 and got[2047] == 1023
+    env.ctx.fft_shift(d)
+    assert bits_equal(env.get(d), f)
+
+
+def test_convolve_once(env, orc):
+    """fft.ConvolveOnce (fft/convolution.go:200-211) = plan, run once, close; dst aliases iq1."""
+    n = 4096
+    a, b = rand_c64(1, n), rand_c64(2, n)
+    want = zeros("c64", n)
+    orc.convolve(want, a, b)
+    da, db = env.put(a), env.put(b)
+    env.ctx.convolve_once(da, da, db)
+    got = env.get(da)
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 2e-6
+
+
 @pytest.mark.parametrize("count,n", [(1, 1024), (2, 512), (4, 4096), (2, 65536), (4, 65536),
                                      (8, 65536)])
 def test_graft_matches_oracle(env, orc, count, n):
