@@ -308,6 +308,22 @@ def main():
                       f"with math.Sincos restated, 1024-tap direct-form FIR at the decimated rate, float64 "
                       f"accumulate; gcc -O2, one thread), {dt:.1f} s of CPU work",
         }
+        # "reference algorithm, parallelised, not the reference" -- the two
+        # stages that have an OpenMP driver, on every host core, ~1 s each
+        threads = orc.max_threads()
+        allc = {"cores": threads, "kind": "port, OpenMP static chunks"}
+        bufp = np.zeros(ns, np.complex64)
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 1.0:
+            orc.par_u8_to_c64(xs, bufp, threads)
+            reps += 1
+        allc["convert_u8_c64_Msamples_per_s"] = round(reps * ns / (time.perf_counter() - t0) / 1e6, 1)
+        reps, t0, ts = 0, time.perf_counter(), 0.0
+        while time.perf_counter() - t0 < 1.0:
+            ts = orc.par_shift_gain(ts, fs, 2.5e6, 0.5, bufp, threads)
+            reps += 1
+        allc["shift_gain_c64_Msamples_per_s"] = round(reps * ns / (time.perf_counter() - t0) / 1e6, 1)
+        result["cpu_baseline"]["all_cores"] = allc
 
     if rank == 0:
         print(json.dumps(result))
