@@ -12,6 +12,25 @@
 
 namespace hz {
 
+// Streaming (use-once) global accesses: non-temporal loads / stores of a trivially
+// copyable T of 2, 4, 8 or 16 bytes, so that a buffer that is read or written exactly
+// once does not displace the tables other kernels keep in L2 / the Infinity Cache.
+template <int BYTES> struct NtWord;
+template <> struct NtWord<2> { using t = uint16_t; };
+template <> struct NtWord<4> { using t = uint32_t; };
+template <> struct NtWord<8> { typedef uint32_t t __attribute__((ext_vector_type(2))); };
+template <> struct NtWord<16> { typedef uint32_t t __attribute__((ext_vector_type(4))); };
+
+template <class T> __device__ __forceinline__ T nt_load(const T *p) {
+    using W = typename NtWord<sizeof(T)>::t;
+    const W w = __builtin_nontemporal_load(reinterpret_cast<const W *>(p));
+    return __builtin_bit_cast(T, w);
+}
+template <class T> __device__ __forceinline__ void nt_store(T *p, const T &v) {
+    using W = typename NtWord<sizeof(T)>::t;
+    __builtin_nontemporal_store(__builtin_bit_cast(W, v), reinterpret_cast<W *>(p));
+}
+
 // Go complex64 * complex64: cmd/compile widens to float64 ("Compute in
 // Float64 to minimize cancellation error"), forms ar*br - ai*bi and
 // ar*bi + ai*br, narrows each once.  Products of two float32 values are exact

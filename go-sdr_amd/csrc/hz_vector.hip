@@ -119,7 +119,7 @@ template <> __device__ __forceinline__ float add1(float a, float b) { return __f
 template <> __device__ __forceinline__ int16_t add1(int16_t a, int16_t b) { return (int16_t)((uint16_t)a + (uint16_t)b); }
 template <> __device__ __forceinline__ int8_t add1(int8_t a, int8_t b) { return (int8_t)((uint8_t)a + (uint8_t)b); }
 
-template <class T>
+template <class T, bool NT>  // NT: see beamform_kernel
 __global__ __launch_bounds__(kThreads) void sum_kernel(V16<T> *out, PtrList bufs, int k, size_t nvec,
                                                        bool accumulate) {
     constexpr int L = 16 / sizeof(T);
@@ -133,11 +133,11 @@ __global__ __launch_bounds__(kThreads) void sum_kernel(V16<T> *out, PtrList bufs
             for (int l = 0; l < L; l++) acc.v[l] = (T)0;  // stream/add.go:165-167 zeroes first
         }
         for (int c = 0; c < k; c++) {
-            V16<T> x = ((const V16<T> *)bufs.p[c])[i];
+            V16<T> x = NT ? nt_load((const V16<T> *)bufs.p[c] + i) : ((const V16<T> *)bufs.p[c])[i];
 #pragma unroll
             for (int l = 0; l < L; l++) acc.v[l] = add1<T>(acc.v[l], x.v[l]);
         }
-        out[i] = acc;
+        if (NT) nt_store(out + i, acc); else out[i] = acc;
     }
 }
 template <class T>
@@ -159,9 +159,15 @@ static void launch_sum(hzsdr_ctx *ctx, void *out, const PtrList &bufs, int k, si
     for (int c = 0; c < k; c++) all |= (uintptr_t)bufs.p[c];
     constexpr int L = 16 / sizeof(T);
     size_t nvec = (all % 16 == 0) ? ncomp / L : 0;
-    if (nvec)
-        hipLaunchKernelGGL(sum_kernel<T>, dim3(blocks_for(ctx, nvec)), dim3(kThreads), 0, ctx->stream,
-                           (V16<T> *)out, bufs, k, nvec, accumulate);
+    const bool stream_past_cache = (size_t)(k + 1) * ncomp * sizeof(T) > ((size_t)192 << 20);
+    if (nvec) {
+        if (stream_past_cache)
+            hipLaunchKernelGGL((sum_kernel<T, true>), dim3(blocks_for(ctx, nvec)), dim3(kThreads), 0, ctx->stream,
+                               (V16<T> *)out, bufs, k, nvec, accumulate);
+        else
+            hipLaunchKernelGGL((sum_kernel<T, false>), dim3(blocks_for(ctx, nvec)), dim3(kThreads), 0, ctx->stream,
+                               (V16<T> *)out, bufs, k, nvec, accumulate);
+    }
     size_t done = nvec * L;
     if (done < ncomp)
         hipLaunchKernelGGL(sum_scalar_kernel<T>, dim3(blocks_for(ctx, ncomp - done)), dim3(kThreads), 0,
@@ -190,7 +196,10 @@ template <> struct Chan<HZSDR_FMT_I16> {
     static __device__ __forceinline__ float2 cvt(uint32_t r) { return make_float2(i16_to_f32((int16_t)(r & 0xFFFF)), i16_to_f32((int16_t)(r >> 16))); }
 };
 
-template <int FMT, int W>
+// NT: the channels and the output are touched once and together exceed the Infinity
+// Cache, so they stream past it (non-temporal); a set that fits stays on plain accesses,
+// which is faster when the same buffers come round again.
+template <int FMT, int W, bool NT>
 __global__ __launch_bounds__(kThreads) void beamform_kernel(float2 *out, PtrList chans, WeightList wl,
                                                             int k, size_t nvec, bool accumulate) {
     using R = typename Chan<FMT>::raw_t;
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(kThreads) void beamform_kernel(float2 *out, PtrList
             RV x[4];
 #pragma unroll
             for (int g = 0; g < 4; g++)
-                if (c0 + g < k) x[g] = ((const RV *)chans.p[c0 + g])[i];
+                if (c0 + g < k) x[g] = NT ? nt_load((const RV *)chans.p[c0 + g] + i) : ((const RV *)chans.p[c0 + g])[i];
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 if (c0 + g < k) {
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(kThreads) void beamform_kernel(float2 *out, PtrList
                 }
             }
         }
-        ((OV *)out)[i] = acc;
+        if (NT) nt_store((OV *)out + i, acc); else ((OV *)out)[i] = acc;
     }
 }
 
@@ -240,14 +249,20 @@ static void launch_beamform(hzsdr_ctx *ctx, void *out, const PtrList &ch, const 
     uintptr_t mis = (uintptr_t)out % (8 * W);
     for (int c = 0; c < k; c++) mis |= (uintptr_t)ch.p[c] % (sizeof(R) * W);
     size_t nvec = mis ? 0 : n / W;
-    if (nvec)
-        hipLaunchKernelGGL((beamform_kernel<FMT, W>), dim3(blocks_for(ctx, nvec)), dim3(kThreads), 0,
-                           ctx->stream, (float2 *)out, ch, wl, k, nvec, accumulate);
+    const bool stream_past_cache = ((size_t)k * sizeof(R) + 8) * n > ((size_t)192 << 20);
+    if (nvec) {
+        if (stream_past_cache)
+            hipLaunchKernelGGL((beamform_kernel<FMT, W, true>), dim3(blocks_for(ctx, nvec)), dim3(kThreads), 0,
+                               ctx->stream, (float2 *)out, ch, wl, k, nvec, accumulate);
+        else
+            hipLaunchKernelGGL((beamform_kernel<FMT, W, false>), dim3(blocks_for(ctx, nvec)), dim3(kThreads), 0,
+                               ctx->stream, (float2 *)out, ch, wl, k, nvec, accumulate);
+    }
     size_t done = nvec * W;
     if (done < n) {
         PtrList t = ch;
         for (int c = 0; c < k; c++) t.p[c] = (const R *)ch.p[c] + done;
-        hipLaunchKernelGGL((beamform_kernel<FMT, 1>), dim3(blocks_for(ctx, n - done)), dim3(kThreads), 0,
+        hipLaunchKernelGGL((beamform_kernel<FMT, 1, false>), dim3(blocks_for(ctx, n - done)), dim3(kThreads), 0,
                            ctx->stream, (float2 *)out + done, t, wl, k, n - done, accumulate);
     }
 }

@@ -601,6 +601,28 @@ def test_beamform_bit_exact(env, orc, fmt):
     assert bits_equal(env.get(out2), want)
 
 
+def test_beamform_and_sum_past_the_cache(hz, orc):
+    """Working sets above 192 MiB take the non-temporal form of the two kernels
+    (4 x 2^23 c64 channels + output = 320 MiB): same bits as the oracle."""
+    import torch
+    n = 1 << 23
+    ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+    ch = [rand_c64(40 + i, n) for i in range(4)]
+    w = hz.beamform_angles(433e6, 30.0, [0.0, 0.1, 0.2, 0.3])
+    dch = [torch.from_numpy(x).cuda() for x in ch]
+    out = torch.zeros(n, dtype=torch.complex64, device="cuda")
+    ctx.beamform(out, dch, w)
+    ctx.synchronize()
+    want = zeros("c64", n)
+    orc.beamform(want, ch, w)
+    assert bits_equal(out.cpu().numpy(), want)
+    ctx.sum(out, dch)
+    ctx.synchronize()
+    orc.sum_(want, ch)
+    assert bits_equal(out.cpu().numpy(), want)
+    ctx.close()
+
+
 # ---- fused chains ----------------------------------------------------------------------------------
 
 def test_chain_convert_shift_gain_equals_separate_ops(env, orc):
