@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kThreads) void chain_map_kernel(const void *__restr
     struct alignas(8 * W) OV { float2 v[W]; };
     // a workgroup owns a contiguous tile per trip and issues its U loads per lane
     // back to back before the arithmetic (memory-level parallelism, see hz_nco.hip)
-    constexpr int U = 2;
+    constexpr int U = W >= 4 ? 1 : 2;
     const size_t tile = (size_t)kThreads * U;
     for (size_t t0 = (size_t)blockIdx.x * tile; t0 < nvec; t0 += (size_t)gridDim.x * tile) {
         const uint64_t j_lo = base + t0 * W;
@@ -794,13 +794,22 @@ static int conv_generic_device(hzsdr_ctx *ctx, void *dst, const void *src1, cons
 template <int FMT>
 static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, const EwProgram &P) {
     using R = typename Raw<FMT>::t;
-    constexpr int W = 2;
-    const bool aligned = ((uintptr_t)in % (sizeof(R) * W) == 0) && ((uintptr_t)out % (8 * W) == 0);
-    size_t nvec = aligned ? n / W : 0;
-    if (nvec)
-        hipLaunchKernelGGL((chain_map_kernel<FMT, W>), dim3(blocks_for(ctx, (nvec + 1) / 2)), dim3(kThreads), 0,
+    // four samples per lane (four interleaved Sincos chains) when both pointers allow the
+    // wider vectors, else two; the ragged end, or everything for a sample-aligned Go
+    // sub-slice, one at a time
+    const auto ok = [&](int w) { return ((uintptr_t)in % (sizeof(R) * w) == 0) && ((uintptr_t)out % (8 * w) == 0); };
+    size_t done = 0;
+    if (ok(4) && n >= 4) {
+        const size_t nvec = n / 4;
+        hipLaunchKernelGGL((chain_map_kernel<FMT, 4>), dim3(blocks_for(ctx, nvec)), dim3(kThreads), 0,
                            ctx->stream, in, (float2 *)out, nvec, (uint64_t)0, P);
-    size_t done = nvec * W;
+        done = nvec * 4;
+    } else if (ok(2) && n >= 2) {
+        const size_t nvec = n / 2;
+        hipLaunchKernelGGL((chain_map_kernel<FMT, 2>), dim3(blocks_for(ctx, (nvec + 1) / 2)), dim3(kThreads), 0,
+                           ctx->stream, in, (float2 *)out, nvec, (uint64_t)0, P);
+        done = nvec * 2;
+    }
     if (done < n)
         hipLaunchKernelGGL((chain_map_kernel<FMT, 1>), dim3(blocks_for(ctx, n - done)), dim3(kThreads), 0,
                            ctx->stream, (const R *)in + done, (float2 *)out + done, n - done,

@@ -637,7 +637,7 @@ def test_chain_convert_shift_gain_equals_separate_ops(env, orc):
     ch = env.ctx.chain(env.hz.FMT_U8, rate).shift(shift).gain(gain)
     out = env.zeros("c64", n)
     dx = env.put(x)
-    cuts = [0, 50_001, n]
+    cuts = [0, 50_002, 100_003, n]  # slices aligned for 4-, 2- and 1-sample vectors
     for lo, hi in zip(cuts[:-1], cuts[1:]):
         ref(shift, want[lo:hi])
         orc.scale(want[lo:hi], gain)
