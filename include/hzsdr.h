@@ -313,7 +313,9 @@ int hzsdr_convert_foreign(hzsdr_ctx *ctx, int dst_format, void *dst, size_t dst_
  * (stream/read_transformer.go:92-116 Proc is the per-buffer hook it plugs in
  * at).  Stages are pushed in data-flow order; elementwise stages (convert to
  * c64, shift, gain, rotate) and at most one terminal stage fuse into a single
- * kernel launch per hzsdr_chain_run. */
+ * kernel launch per hzsdr_chain_run (two for the FIR-decimate terminal: the
+ * overlap-save analysis and the small inverse transforms; no full-rate complex64
+ * intermediate is ever written). */
 int hzsdr_chain_create(hzsdr_ctx *ctx, int src_format, uint64_t sample_rate, hzsdr_chain **out);
 /* stream.ShiftReader(r, shift), stream/shifter.go:89-102 (stateful NCO). */
 int hzsdr_chain_shift(hzsdr_chain *c, double shift_hz);
