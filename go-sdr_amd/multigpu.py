@@ -2,8 +2,14 @@
 split contiguously over ranks, each rank runs its channels' weighted partial sum
 locally (hzsdr_beamform_partial) and ONE exchange step combines them.
 
-Two exchanges, both plain torch.distributed (backend "nccl" = RCCL over xGMI on
+Three exchanges, all plain torch.distributed (backend "nccl" = RCCL over xGMI on
 the GPU box, "gloo" in the CPU tests):
+
+  ordered_alltoall rank s owns slice s of the output: every rank sends slice s of
+                   each of its weighted channels to rank s, which adds all K pieces in
+                   channel order from +0, then the slices are collected.  Bit-identical
+                   to the single-GPU / reference result, and each xGMI link carries
+                   1/world of a channel (SURVEY 8e's parity path).
 
   reduce_fast      dist.reduce(SUM) of the per-rank partial sums onto rank 0.
                    Fast path; the summation order is RCCL's, so the result is
@@ -80,6 +86,82 @@ def ordered_pipeline(dist, rank, world, out, partial_fn, n_slices=8):
     return out
 
 
+def slice_bounds(n, world, s):
+    """Samples [lo, hi) of slice s when n samples are cut into `world` slices."""
+    return n * s // world, n * (s + 1) // world
+
+
+def _exchange(dist, torch, sends, recvs):
+    """sends / recvs: lists of (tensor_view_as_real, peer).  One grouped batch on NCCL
+    (ncclGroupStart/End, no ordering deadlock); plain non-blocking ops on gloo, staged
+    through host memory when the tensors live on a GPU (1-GPU debugging only)."""
+    if not sends and not recvs:
+        return
+    staged = any(_staged(dist, t) for t, _ in sends + recvs)
+    if staged:
+        torch.cuda.current_stream().synchronize()
+        hs = [(t.cpu(), p) for t, p in sends]
+        hr = [(torch.empty(t.shape, dtype=t.dtype), p) for t, p in recvs]
+        reqs = [dist.irecv(h, src=p) for h, p in hr] + [dist.isend(h, dst=p) for h, p in hs]
+        for r in reqs:
+            r.wait()
+        for (t, _), (h, _) in zip(recvs, hr):
+            t.copy_(h)
+        return
+    ops = [dist.P2POp(dist.irecv, t, p) for t, p in recvs] + [dist.P2POp(dist.isend, t, p) for t, p in sends]
+    for r in dist.batch_isend_irecv(ops):
+        r.wait()
+
+
+def ordered_alltoall(dist, torch, rank, world, k_total, weighted, first_channel, out, sum_fn, gather_dst=0):
+    """The fixed-order exchange of SURVEY 8e as an all-to-all of sample-range slices: rank s
+    owns slice s of the output; every rank sends slice s of each of ITS weighted channels
+    (`weighted[i]` = 0 + w_c * x_c for channel c = first_channel + i, complex64, n samples)
+    to rank s, which adds the k_total pieces in channel order from +0 (`sum_fn(out_slice,
+    pieces)`: stream/add.go:115-119) -- bit-identical to the one-GPU / reference sum, with
+    every link carrying 1/world of a channel instead of a whole running sum.  The slices
+    are then collected on `gather_dst` (None: leave them distributed).  Channels must be
+    sharded contiguously (shard_channels)."""
+    n = out.shape[0]
+    lo, hi = slice_bounds(n, world, rank)
+    owner_of = []  # channel -> owning rank
+    for r in range(world):
+        a, b = shard_channels(k_total, world, r)
+        owner_of += [r] * (b - a)
+    pieces = []
+    recvs, sends = [], []
+    for c in range(k_total):
+        r = owner_of[c]
+        if r == rank:
+            pieces.append(weighted[c - first_channel][lo:hi])
+        else:
+            buf = torch.empty(hi - lo, dtype=out.dtype, device=out.device)
+            pieces.append(buf)
+            if hi > lo:
+                recvs.append((torch.view_as_real(buf), r))
+    for s in range(world):
+        if s == rank:
+            continue
+        a, b = slice_bounds(n, world, s)
+        if b > a:
+            for w in weighted:
+                sends.append((torch.view_as_real(w[a:b]), s))
+    _exchange(dist, torch, sends, recvs)
+    if hi > lo:
+        sum_fn(out[lo:hi], pieces)
+    if gather_dst is not None:
+        if rank == gather_dst:
+            rv = []
+            for s in range(world):
+                a, b = slice_bounds(n, world, s)
+                if s != rank and b > a:
+                    rv.append((torch.view_as_real(out[a:b]), s))
+            _exchange(dist, torch, [], rv)
+        elif hi > lo:
+            _exchange(dist, torch, [(torch.view_as_real(out[lo:hi]), gather_dst)], [])
+    return lo, hi
+
+
 def bench_beamform(hz, ctx, torch, dist, rank, world, n, steps, warmup, synth):
     """4-channel (or `world`-channel when world > 4) coherent c64 beamform, one
     exchange per buffer.  Returns the JSON sub-object bench.py attaches."""
@@ -107,8 +189,16 @@ def bench_beamform(hz, ctx, torch, dist, rank, world, n, steps, warmup, synth):
                 out[a:b].zero_()
         ordered_pipeline(dist, rank, world, out, part)
 
+    weighted = [torch.zeros(n, dtype=torch.complex64, device="cuda") for _ in chans]
+
+    def alltoall():
+        for y, x, w in zip(weighted, chans, my_w):
+            ctx.beamform(y, [x], [w])  # 0 + w_c * x_c, one channel
+        ordered_alltoall(dist, torch, rank, world, k, weighted, lo, out,
+                         lambda dst, pieces: ctx.sum(dst, pieces), gather_dst=0)
+
     res = {"channels": k, "samples_per_channel": n, "channels_per_gpu": hi - lo}
-    for name, fn in (("rccl_reduce", fast), ("ordered_pipeline", ordered)):
+    for name, fn in (("rccl_reduce", fast), ("ordered_pipeline", ordered), ("ordered_alltoall", alltoall)):
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize()

@@ -601,6 +601,24 @@ def test_beamform_bit_exact(env, orc, fmt):
     assert bits_equal(env.get(out2), want)
 
 
+def test_weighted_channels_then_ordered_sum_is_beamform(env, orc):
+    """The pieces multigpu.ordered_alltoall moves: one weighted channel per launch
+    (0 + w_c * x_c) and the K-way ordered Add reproduce the fused Beamform bit for bit."""
+    n = 30_001
+    ch = [rand_c64(60 + i, n) for i in range(4)]
+    w = env.hz.beamform_angles(433e6, 30.0, [0.0, 0.1, 0.2, 0.3])
+    want = zeros("c64", n)
+    orc.beamform(want, ch, w)
+    weighted = []
+    for x, wc in zip(ch, w):
+        y = env.zeros("c64", n)
+        env.ctx.beamform(y, [env.put(x)], [wc])
+        weighted.append(y)
+    out = env.zeros("c64", n)
+    env.ctx.sum(out, weighted)
+    assert bits_equal(env.get(out), want)
+
+
 def test_beamform_and_sum_past_the_cache(hz, orc):
     """Working sets above 192 MiB take the non-temporal form of the two kernels
     (4 x 2^23 c64 channels + output = 320 MiB): same bits as the oracle."""

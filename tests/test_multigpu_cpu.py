@@ -72,11 +72,30 @@ def _worker(rank, world, port, n, k, result_dir):
         mg.reduce_fast(dist, torch, fast, dst=0)
         if rank == 0:
             np.save(os.path.join(result_dir, "fast.npy"), fast.numpy())
+
+        # fixed-order all-to-all of slices: every rank ships slice s of each of its weighted
+        # channels (0 + w*x) to rank s, which adds all k pieces in channel order
+        weighted = []
+        for x, w in zip(chans, weights[lo:hi]):
+            y = np.zeros(n, np.complex64)
+            orc.beamform(y, [x], [w])
+            weighted.append(torch.from_numpy(y))
+        a2a = torch.zeros(n, dtype=torch.complex64)
+
+        def sum_fn(dst, pieces):
+            d = dst.numpy()
+            tmp2 = np.zeros(d.shape[0], np.complex64)
+            orc.sum_(tmp2, [np.ascontiguousarray(p.numpy()) for p in pieces])
+            d[:] = tmp2
+
+        mg.ordered_alltoall(dist, torch, rank, world, k, weighted, lo, a2a, sum_fn, gather_dst=0)
+        if rank == 0:
+            np.save(os.path.join(result_dir, "alltoall.npy"), a2a.numpy())
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,k", [(2, 4), (4, 4), (2, 5)])
+@pytest.mark.parametrize("world,k", [(2, 4), (4, 4), (2, 5), (3, 7)])
 def test_sharded_beamform_exchange(orc, tmp_path, world, k):
     n = 10_007
     port = _free_port()
@@ -87,6 +106,8 @@ def test_sharded_beamform_exchange(orc, tmp_path, world, k):
     orc.beamform(want, [rand_c64(20 + c, n) for c in range(k)], weights)
     ordered = np.load(tmp_path / "ordered.npy")
     assert ordered.tobytes() == want.tobytes()  # fixed order: bit-exact with the 1-GPU / reference sum
+    a2a = np.load(tmp_path / "alltoall.npy")
+    assert a2a.tobytes() == want.tobytes()  # slices summed in channel order: bit-exact too
     fast = np.load(tmp_path / "fast.npy")
     assert np.allclose(fast, want, rtol=0, atol=4e-6)  # reduce(SUM): order differs, value agrees
 
