@@ -513,6 +513,23 @@ struct LateFilters {
     const float2 *h[kNcoMaxSegs];
 };
 
+// POLYPHASE form of the folded analysis (N = 4096, D in {2, 4, 8, 16}).  The fold sums the
+// D aliases of every output bin, sum_q H[k + M q] X[k + M q] (M = N/D).  Writing the
+// N-point transform by its first decimation-in-time stage, X[k] = sum_r W_N^(r k) U_r[k mod M]
+// with U_r the M-point transform of branch u_r[m] = x[D m + r], the aliases collapse:
+//     Z[k] = sum_r G_r[k] U_r[k],   G_r = FFT_M(g_r) / M,   g_r[j] = h[D j - r]
+// -- D transforms of M points and one multiply-accumulate, no N-point last pass.  Lane p of
+// the workgroup is lane p / D of branch p % D, which makes the first pass (radix 16 over
+// x[p + 256 q]) the very loads and butterflies of the N-point form; the second radix-16 pass
+// stays inside a branch; the last pass of the M-point transforms is radix 16/D at Ns = 256,
+// so lane p can run it for ALL D branches at bins p + 256 i (D * 16/D = 16 values), multiply
+// by the D filter spectra and add up: 24 complex multiplies and 30 adds where the N-point
+// form spent a twiddled radix-16 butterfly, 16 multiplies and the fold (~ 10 % fewer vector
+// instructions per block).  `hfreq` and `late.h[]` hold G[r][k] (D x M) for these chains.
+constexpr bool fold_poly(int n, int fold) {
+    return n == 4096 && (fold == 2 || fold == 4 || fold == 8 || fold == 16);
+}
+
 // workgroup-uniform: does block b (input span [p0, p0 + N)) take the late-mixer path?
 __device__ __forceinline__ bool late_block(const EwProgram &P, const LateFilters &late, int64_t p0, int N,
                                            unsigned off, size_t n_in, NcoWin *run) {
@@ -527,11 +544,13 @@ __global__ __launch_bounds__(f16::block(N), LATE ? 4 : 1) void fir_decimate_kern
     const void *in, float2 *out, const float2 *__restrict__ hist, float2 *__restrict__ new_hist,
     const float2 *__restrict__ hfreq,
     const float2 *__restrict__ tw, float2 *__restrict__ spec, size_t nblocks, size_t n_in,
-    unsigned hop, unsigned off, unsigned D, EwProgram P, LateFilters late) {
+    unsigned hop, unsigned off, unsigned D, EwProgram P, LateFilters late,
+    const float2 *__restrict__ tw_sub) {
     constexpr int R0 = f16::first_radix(N), TPT = f16::tpt(N);
     static_assert(f16::xpb(N) == 1 || FOLD == 0, "fold path assumes one block per workgroup");
     static_assert(!LATE || FOLD != 0, "the late mixer is written for the folded inverse");
-    __shared__ float2 lds_all[f16::xpb(N) * f16::lds_elems(N)];
+    // (+32: the polyphase form shifts each branch's region by 32/D elements, see below)
+    __shared__ float2 lds_all[f16::xpb(N) * f16::lds_elems(N) + 32];
     const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
     float2 *lds = lds_all + sub * f16::lds_elems(N);
     size_t b = (size_t)blockIdx.x * f16::xpb(N) + sub;
@@ -548,7 +567,8 @@ __global__ __launch_bounds__(f16::block(N), LATE ? 4 : 1) void fir_decimate_kern
     if constexpr (LATE) mix_late = late_block(P, late, p0, N, off, n_in, &run);
     const float2 *__restrict__ hf = mix_late ? late.h[run.lo] : hfreq;
     float2 v[16];
-    if (LATE && mix_late) {
+    const bool direct = LATE && mix_late;  // workgroup-uniform
+    if (direct) {
         // a late block lies wholly inside the buffer and needs no arithmetic per input
         // sample: its samples go from global memory straight into the first pass's
         // register image (a wave reads 64 consecutive samples per load), no LDS staging
@@ -559,13 +579,60 @@ __global__ __launch_bounds__(f16::block(N), LATE ? 4 : 1) void fir_decimate_kern
         for (int q = 0; q < 16; q++) raw[q] = src[f16::edge_index<N, R0>(q, lane)];
 #pragma unroll
         for (int q = 0; q < 16; q++) v[q] = Raw<FMT>::cvt(raw[q]);
-        f16::forward<N>(v, lds, tw, lane);
     } else {
         stage_block16<N, FMT>(lds, in, P, p0, n_in, hist, off, lane, live, new_hist);
         __syncthreads();
         f16::load_lds<N, R0>(v, lds, lane);
-        f16::forward<N, true>(v, lds, tw, lane);
     }
+    if constexpr (fold_poly(N, FOLD)) {
+        // branch regions 32/D elements apart in bank space: neighbouring lanes belong to
+        // different branches, and the regions' natural size is a multiple of all 64 banks
+        constexpr int M = N / FOLD, RL = 16 / FOLD, LE = f16::lds_elems(M) + 32 / FOLD;
+        static_assert(FOLD * LE == f16::lds_elems(N) + 32 && R0 == 16 && TPT == 256, "polyphase geometry");
+        const int br = lane % FOLD, bl = lane / FOLD;  // branch, lane inside the branch
+        float2 *ldb = lds + br * LE;
+        // pass 1 of every branch: radix 16 at Ns = 1 over u_r[bl + (M/16) q] = x[lane + 256 q]
+        f16::butterflies<16, false>(v);
+        if (!direct) __syncthreads();  // the staged block has been read by everybody
+        f16::store_lds<M, 16>(v, ldb, bl, 1);
+        {  // pass 2: radix 16 at Ns = 16, inside the branch
+            f16::TwRegs<16> t;
+            f16::twiddle_load<M, 16>(t, tw_sub, bl, 16);
+            __syncthreads();
+            f16::load_lds<M, 16>(v, ldb, bl);
+            f16::twiddle_apply<M, 16, false>(v, t);
+            f16::butterflies<16, false>(v);
+            __syncthreads();
+            f16::store_lds<M, 16>(v, ldb, bl, 16);
+        }
+        // last pass (radix RL at Ns = 256) of ALL branches at bins lane + 256 i, times the
+        // branch's filter spectrum, summed over the branches
+        float2 wl[RL > 1 ? RL - 1 : 1];
+#pragma unroll
+        for (int i = 1; i < RL; i++) wl[i - 1] = tw_sub[i * lane];
+        __syncthreads();
+        float2 z[RL];
+#pragma unroll
+        for (int i = 0; i < RL; i++) z[i] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int r2 = 0; r2 < FOLD; r2++) {
+            float2 u[RL];
+#pragma unroll
+            for (int i = 0; i < RL; i++) u[i] = lds[r2 * LE + f16::pad(lane + 256 * i)];
+#pragma unroll
+            for (int i = 1; i < RL; i++) u[i] = f16::cmul(u[i], wl[i - 1]);
+            if constexpr (RL > 1) f16::dft<RL, false>(u);
+#pragma unroll
+            for (int i = 0; i < RL; i++) z[i] = f16::cadd(z[i], f16::cmul(u[i], hf[r2 * M + lane + 256 * i]));
+        }
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < RL; i++) spec[b * M + lane + 256 * i] = z[i];
+        }
+        return;
+    }
+    if (direct) f16::forward<N>(v, lds, tw, lane);
+    else f16::forward<N, true>(v, lds, tw, lane);
 #pragma unroll
     for (int q = 0; q < 16; q++) v[q] = f16::cmul(v[q], hf[f16::edge_index<N, 16>(q, lane)]);
     if constexpr (FOLD == 0) {
@@ -699,6 +766,7 @@ struct hzsdr_chain {
     std::vector<float> taps_host;
     std::map<uint64_t, void *> late_cache;
     bool mix_in_order = false;
+    bool poly = false;  // hfreq / late_cache hold the polyphase layout (fold_poly)
 };
 
 struct hzsdr_conv {
@@ -816,7 +884,38 @@ static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, cons
                            (uint64_t)done, P);
 }
 
-// H' = FFT(taps[k] * exp(-i * omega * k * step), zero-padded to N) / N for one clock step.
+// The taps' spectrum in the layout the analysis kernel multiplies by: H[k] = FFT_N(h)[k] / N,
+// or, for the polyphase form, G[r][k] = FFT_M(g_r)[k] / M with g_r[j] = h[D j - r] (see
+// fold_poly).  `taps`: ntaps complex64 in host memory; `dst`: N complex64 of device memory.
+static int filter_spectrum(hzsdr_chain *c, const float *taps, void *dst) {
+    hzsdr_ctx *ctx = c->ctx;
+    const unsigned nfft = c->nfft;
+    std::vector<float> padded(2 * (size_t)nfft, 0.0f);
+    size_t len = nfft, batch = 1;
+    if (c->poly) {
+        const unsigned F = c->factor, M = nfft / F;
+        for (unsigned r = 0; r < F; r++)
+            for (unsigned j = 0; j < M; j++) {
+                const long idx = (long)F * j - (long)r;
+                if (idx < 0 || (size_t)idx >= c->ntaps) continue;
+                padded[2 * ((size_t)r * M + j)] = taps[2 * idx];
+                padded[2 * ((size_t)r * M + j) + 1] = taps[2 * idx + 1];
+            }
+        len = M;
+        batch = F;
+    } else {
+        memcpy(padded.data(), taps, c->ntaps * 8);
+    }
+    HZ_TRY(ensure_slot(ctx, 8, (size_t)nfft * 8));
+    HZ_HIP(ctx, hipMemcpyAsync(ctx->slots[8].ptr, padded.data(), (size_t)nfft * 8, hipMemcpyHostToDevice, ctx->stream));
+    HZ_TRY(fft_device(ctx, ctx->slots[8].ptr, dst, len, batch, true));
+    hipLaunchKernelGGL(scale_c64_kernel, dim3(blocks_for(ctx, nfft)), dim3(kThreads), 0, ctx->stream,
+                       (float2 *)dst, (size_t)nfft, 1.0f / (float)len);
+    HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `padded` and slot 8 are reused
+    return HZSDR_OK;
+}
+
+// The spectrum of taps[k] * exp(-i * omega * k * step) for one clock step.
 static int late_filter_for(hzsdr_chain *c, double step, double omega, void **dev) {
     hzsdr_ctx *ctx = c->ctx;
     uint64_t key;
@@ -831,23 +930,17 @@ static int late_filter_for(hzsdr_chain *c, double step, double omega, void **dev
         for (auto &kv : c->late_cache) (void)hipFree(kv.second);
         c->late_cache.clear();
     }
-    const unsigned nfft = c->nfft;
-    std::vector<float> padded(2 * (size_t)nfft, 0.0f);
+    std::vector<float> mod(2 * c->ntaps);
     for (size_t k = 0; k < c->ntaps; k++) {
         const double ph = -omega * ((double)k * step);
         const double cr = cos(ph), ci = sin(ph);
         const double hr = c->taps_host[2 * k], hi = c->taps_host[2 * k + 1];
-        padded[2 * k] = (float)(hr * cr - hi * ci);
-        padded[2 * k + 1] = (float)(hr * ci + hi * cr);
+        mod[2 * k] = (float)(hr * cr - hi * ci);
+        mod[2 * k + 1] = (float)(hr * ci + hi * cr);
     }
     void *h = nullptr;
-    HZ_HIP(ctx, hipMalloc(&h, (size_t)nfft * 8));
-    HZ_TRY(ensure_slot(ctx, 8, (size_t)nfft * 8));
-    HZ_HIP(ctx, hipMemcpyAsync(ctx->slots[8].ptr, padded.data(), (size_t)nfft * 8, hipMemcpyHostToDevice, ctx->stream));
-    HZ_TRY(fft_device(ctx, ctx->slots[8].ptr, h, nfft, 1, true));
-    hipLaunchKernelGGL(scale_c64_kernel, dim3(blocks_for(ctx, nfft)), dim3(kThreads), 0, ctx->stream,
-                       (float2 *)h, (size_t)nfft, 1.0f / (float)nfft);
-    HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `padded` and slot 8 are reused
+    HZ_HIP(ctx, hipMalloc(&h, (size_t)c->nfft * 8));
+    HZ_TRY(filter_spectrum(c, mod.data(), h));
     c->late_cache[key] = h;
     *dev = h;
     return HZSDR_OK;
@@ -926,7 +1019,7 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
     hipLaunchKernelGGL((fir_decimate_kernel16<N, FMT, FOLD, LATE>),                                     \
                        dim3((unsigned)((nblocks + f16::xpb(N) - 1) / f16::xpb(N))), dim3(f16::block(N)), \
                        0, ctx->stream, in, (float2 *)out, hist, nhist, (const float2 *)c->hfreq, tw, SPEC, \
-                       nblocks, n_cons, c->hop, c->off, D, P, late)
+                       nblocks, n_cons, c->hop, c->off, D, P, late, tws)
 #define HZ_FIR16(N, FOLD) HZ_FIR16_L(N, FOLD, false, (float2 *)nullptr)
 #define HZ_SYNTH16(N, F, LATE)                                                                           \
     hipLaunchKernelGGL((fir_synth_kernel16<N, F, LATE>),                                                 \
@@ -1116,15 +1209,11 @@ int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps, size_t n_taps, u
     HZ_HIP(ctx, hipMalloc(&c->hist[1], hb));
     HZ_HIP(ctx, hipMemsetAsync(c->hist[0], 0, hb, ctx->stream));
     HZ_HIP(ctx, hipMemsetAsync(c->hist[1], 0, hb, ctx->stream));
-    // H = FFT(taps zero-padded to N) / N, computed with this library's own transform
-    std::vector<float> padded(2 * (size_t)nfft, 0.0f);
-    memcpy(padded.data(), taps, n_taps * 8);
-    HZ_TRY(ensure_slot(ctx, 8, (size_t)nfft * 8));
-    HZ_HIP(ctx, hipMemcpy(ctx->slots[8].ptr, padded.data(), (size_t)nfft * 8, hipMemcpyHostToDevice));
-    HZ_TRY(fft_device(ctx, ctx->slots[8].ptr, c->hfreq, nfft, 1, true));
-    hipLaunchKernelGGL(scale_c64_kernel, dim3(blocks_for(ctx, nfft)), dim3(kThreads), 0, ctx->stream,
-                       (float2 *)c->hfreq, (size_t)nfft, 1.0f / (float)nfft);
-    HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    c->ntaps = n_taps;
+    c->nfft = nfft;
+    c->factor = factor;
+    c->poly = fold_poly((int)nfft, (int)factor);
+    HZ_TRY(filter_spectrum(c, taps, c->hfreq));
     c->taps_host.assign(taps, taps + 2 * n_taps);
     c->ntaps = n_taps;
     c->nfft = nfft;
