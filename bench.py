@@ -162,8 +162,11 @@ def main():
     alg_bytes = (2 + 8 / D) * n                     # 2 B read + 8/D B written per input sample
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     nfft, valid = 4096, 3072
-    # per 3072-sample hop: forward 4096-point FFT, 4096 bin multiplies, 512-point inverse
-    flops = (5 * nfft * 12 + 6 * nfft + 5 * (nfft // D) * 9) / valid * n
+    # per 3072-sample hop (polyphase form): D forward 512-point FFTs up to their last pass,
+    # the fused last pass x filter x sum (24 complex multiplies + 30 adds per lane, 256
+    # lanes), one 512-point inverse
+    m = nfft // D
+    flops = (D * 5 * m * (np.log2(m) - 1) + 256 * (24 * 6 + 30 * 2) + 5 * m * np.log2(m)) / valid * n
     result = {
         "metric": "Msamples/s: u8->c64->Shift->FIR-decimate chain @1 GPU; 4-ch Beamform @1/2/4 GPU",
         "value": round(value, 1),
