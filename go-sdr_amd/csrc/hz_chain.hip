@@ -526,8 +526,11 @@ struct LateFilters {
 // by the D filter spectra and add up: 24 complex multiplies and 30 adds where the N-point
 // form spent a twiddled radix-16 butterfly, 16 multiplies and the fold (~ 10 % fewer vector
 // instructions per block).  `hfreq` and `late.h[]` hold G[r][k] (D x M) for these chains.
+// (N = 2048 and 1024 -- 128 and 64 lanes -- work the same way with a second pass of radix
+// N/256 = 8 or 4 and the fused last pass at Ns = N/16.)
 constexpr bool fold_poly(int n, int fold) {
-    return n == 4096 && (fold == 2 || fold == 4 || fold == 8 || fold == 16);
+    return (n == 4096 || n == 2048 || n == 1024) && (fold == 2 || fold == 4 || fold == 8 || fold == 16) &&
+           n / fold >= 256;
 }
 
 // workgroup-uniform: does block b (input span [p0, p0 + N)) take the late-mixer path?
@@ -568,6 +571,9 @@ __global__ __launch_bounds__(f16::block(N), LATE ? 4 : 1) void fir_decimate_kern
     const float2 *__restrict__ hf = mix_late ? late.h[run.lo] : hfreq;
     float2 v[16];
     const bool direct = LATE && mix_late;  // workgroup-uniform
+    // register image of the first pass: radix-16 edge for the polyphase form, the N-point
+    // plan's first radix otherwise
+    constexpr int RIN = fold_poly(N, FOLD) ? 16 : R0;
     if (direct) {
         // a late block lies wholly inside the buffer and needs no arithmetic per input
         // sample: its samples go from global memory straight into the first pass's
@@ -576,36 +582,37 @@ __global__ __launch_bounds__(f16::block(N), LATE ? 4 : 1) void fir_decimate_kern
         const R *src = (const R *)in + p0;
         R raw[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) raw[q] = src[f16::edge_index<N, R0>(q, lane)];
+        for (int q = 0; q < 16; q++) raw[q] = src[f16::edge_index<N, RIN>(q, lane)];
 #pragma unroll
         for (int q = 0; q < 16; q++) v[q] = Raw<FMT>::cvt(raw[q]);
     } else {
         stage_block16<N, FMT>(lds, in, P, p0, n_in, hist, off, lane, live, new_hist);
         __syncthreads();
-        f16::load_lds<N, R0>(v, lds, lane);
+        f16::load_lds<N, RIN>(v, lds, lane);
     }
     if constexpr (fold_poly(N, FOLD)) {
         // branch regions 32/D elements apart in bank space: neighbouring lanes belong to
         // different branches, and the regions' natural size is a multiple of all 64 banks
-        constexpr int M = N / FOLD, RL = 16 / FOLD, LE = f16::lds_elems(M) + 32 / FOLD;
-        static_assert(FOLD * LE == f16::lds_elems(N) + 32 && R0 == 16 && TPT == 256, "polyphase geometry");
+        constexpr int M = N / FOLD, RL = 16 / FOLD, R2 = N / 256, LE = f16::lds_elems(M) + 32 / FOLD;
+        static_assert(FOLD * LE == f16::lds_elems(N) + 32 && FOLD * (M / 16) == TPT && R2 * 256 == N,
+                      "polyphase geometry");
         const int br = lane % FOLD, bl = lane / FOLD;  // branch, lane inside the branch
         float2 *ldb = lds + br * LE;
-        // pass 1 of every branch: radix 16 at Ns = 1 over u_r[bl + (M/16) q] = x[lane + 256 q]
+        // pass 1 of every branch: radix 16 at Ns = 1 over u_r[bl + (M/16) q] = x[lane + TPT q]
         f16::butterflies<16, false>(v);
         if (!direct) __syncthreads();  // the staged block has been read by everybody
         f16::store_lds<M, 16>(v, ldb, bl, 1);
-        {  // pass 2: radix 16 at Ns = 16, inside the branch
-            f16::TwRegs<16> t;
-            f16::twiddle_load<M, 16>(t, tw_sub, bl, 16);
+        {  // pass 2: radix N/256 at Ns = 16, inside the branch
+            f16::TwRegs<R2> t;
+            f16::twiddle_load<M, R2>(t, tw_sub, bl, 16);
             __syncthreads();
-            f16::load_lds<M, 16>(v, ldb, bl);
-            f16::twiddle_apply<M, 16, false>(v, t);
-            f16::butterflies<16, false>(v);
+            f16::load_lds<M, R2>(v, ldb, bl);
+            f16::twiddle_apply<M, R2, false>(v, t);
+            f16::butterflies<R2, false>(v);
             __syncthreads();
-            f16::store_lds<M, 16>(v, ldb, bl, 16);
+            f16::store_lds<M, R2>(v, ldb, bl, 16);
         }
-        // last pass (radix RL at Ns = 256) of ALL branches at bins lane + 256 i, times the
+        // last pass (radix RL at Ns = N/16) of ALL branches at bins lane + TPT i, times the
         // branch's filter spectrum, summed over the branches
         float2 wl[RL > 1 ? RL - 1 : 1];
 #pragma unroll
@@ -618,16 +625,16 @@ __global__ __launch_bounds__(f16::block(N), LATE ? 4 : 1) void fir_decimate_kern
         for (int r2 = 0; r2 < FOLD; r2++) {
             float2 u[RL];
 #pragma unroll
-            for (int i = 0; i < RL; i++) u[i] = lds[r2 * LE + f16::pad(lane + 256 * i)];
+            for (int i = 0; i < RL; i++) u[i] = lds[r2 * LE + f16::pad(lane + TPT * i)];
 #pragma unroll
             for (int i = 1; i < RL; i++) u[i] = f16::cmul(u[i], wl[i - 1]);
             if constexpr (RL > 1) f16::dft<RL, false>(u);
 #pragma unroll
-            for (int i = 0; i < RL; i++) z[i] = f16::cadd(z[i], f16::cmul(u[i], hf[r2 * M + lane + 256 * i]));
+            for (int i = 0; i < RL; i++) z[i] = f16::cadd(z[i], f16::cmul(u[i], hf[r2 * M + lane + TPT * i]));
         }
         if (live) {
 #pragma unroll
-            for (int i = 0; i < RL; i++) spec[b * M + lane + 256 * i] = z[i];
+            for (int i = 0; i < RL; i++) spec[b * M + lane + TPT * i] = z[i];
         }
         return;
     }

@@ -77,6 +77,11 @@ CASES = {
                                                      ("shift", -350e3)], ntaps=257, D=4, n=1 << 20),
     # D = 2: the folded inverse is 2048 points on 128 lanes (two waves)
     "d2": dict(fmt="u8", rate=20_000_000, ops=[("shift", -2.5e6)], ntaps=1024, D=2, n=1 << 20),
+    # shorter filters: N_fft 2048 / 1024, polyphase with a radix-8 / radix-4 second pass
+    "n2048_d8": dict(fmt="u8", rate=20_000_000, ops=[("shift", 3e6)], ntaps=300, D=8, n=1 << 20),
+    "n2048_d2": dict(fmt="i16", rate=2_400_000, ops=[("shift", -5e5), ("gain", 0.7)], ntaps=400, D=2, n=1 << 19),
+    "n1024_d4": dict(fmt="c64", rate=20_000_000, ops=[("shift", 1.25e6)], ntaps=200, D=4, n=1 << 19),
+    "n1024_d2": dict(fmt="u8", rate=20_000_000, ops=[("shift", -4e6)], ntaps=150, D=2, n=1 << 19),
     "d16": dict(fmt="u8", rate=20_000_000, ops=[("shift", 1e6)], ntaps=600, D=16, n=1 << 20),
 }
 
@@ -85,8 +90,9 @@ CASES = {
 def test_late_and_in_order_mixers_meet_the_same_bound(hz, ctx, orc, name):
     c = CASES[name]
     n, D, taps = c["n"], c["D"], taps_for(c["ntaps"])
-    x = rand_u8(77, n) if c["fmt"] == "u8" else rand_c64(77, n)
-    fmt = hz.FMT_U8 if c["fmt"] == "u8" else hz.FMT_C64
+    from util import rand_i16
+    x = {"u8": rand_u8, "i16": rand_i16, "c64": rand_c64}[c["fmt"]](77, n)
+    fmt = {"u8": hz.FMT_U8, "i16": hz.FMT_I16, "c64": hz.FMT_C64}[c["fmt"]]
     want, xc = oracle_chain(orc, x, c["rate"], c["ops"], taps, D)
     bound = 4e-6 * float(np.abs(taps).sum()) * float(np.abs(xc).max())
     outs = {}
