@@ -596,10 +596,53 @@ public:
         return {used, made};
     }
     void Reset() { check(x_.raw(), hzsdr_chain_reset(c_)); }
+    // every sample mixed before the FIR (reference order) instead of after it
+    Chain &MixInOrder(bool in_order = true) { check(x_.raw(), hzsdr_chain_mix_in_order(c_, in_order ? 1 : 0)); return *this; }
+    hzsdr_chain *raw() const { return c_; }
+    const Context &context() const { return x_; }
 
 private:
     const Context &x_;
     hzsdr_chain *c_ = nullptr;
+};
+
+// The pinned ring in front of a chain: what stream.RingBuffer with an IQBufferAllocator of
+// hipHostMalloc memory is to a driver callback (stream/ring.go:48-69, :337-392).
+class Ring {
+public:
+    Ring(Chain &chain, size_t slot_length, int slots) : x_(chain.context()) {
+        check(x_.raw(), hzsdr_ring_create(chain.raw(), slot_length, slots, &r_));
+        void *base = nullptr;
+        size_t n = 0;
+        check(x_.raw(), hzsdr_ring_iq_buffer(r_, &base, &n, &slot_length_));
+        base_ = base;
+        total_ = n;
+    }
+    ~Ring() { if (r_) hzsdr_ring_free(r_); }
+    Ring(const Ring &) = delete;
+    // the whole IQBufferAllocator region, in the chain's source format
+    Samples IQBuffer(int format) const { return Samples{format, base_, total_}; }
+    // write cursor: the next slot's memory
+    Samples Acquire(int format, int *slot) {
+        void *p = nullptr;
+        check(x_.raw(), hzsdr_ring_acquire(r_, slot, &p));
+        return Samples{format, p, slot_length_};
+    }
+    void Submit(int slot, size_t n) { check(x_.raw(), hzsdr_ring_submit(r_, slot, n)); }
+    // read cursor: the oldest submitted slot's output (complex64), valid until that slot is resubmitted
+    Samples Pop() {
+        const void *p = nullptr;
+        size_t n = 0;
+        check(x_.raw(), hzsdr_ring_pop(r_, &p, &n));
+        return Samples{HZSDR_FMT_C64, const_cast<void *>(p), n};
+    }
+    int InFlight() const { return hzsdr_ring_in_flight(r_); }
+
+private:
+    const Context &x_;
+    hzsdr_ring *r_ = nullptr;
+    void *base_ = nullptr;
+    size_t total_ = 0, slot_length_ = 0;
 };
 
 }  // namespace stream
