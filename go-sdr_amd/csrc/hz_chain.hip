@@ -543,7 +543,7 @@ __device__ __forceinline__ bool late_block(const EwProgram &P, const LateFilters
 }
 
 template <int N, int FMT, int FOLD, bool LATE>
-__global__ __launch_bounds__(f16::block(N), LATE ? 4 : 1) void fir_decimate_kernel16(
+__global__ __launch_bounds__(f16::block(N), LATE ? (FOLD != 0 ? 4 : 3) : 1) void fir_decimate_kernel16(
     const void *in, float2 *out, const float2 *__restrict__ hist, float2 *__restrict__ new_hist,
     const float2 *__restrict__ hfreq,
     const float2 *__restrict__ tw, float2 *__restrict__ spec, size_t nblocks, size_t n_in,
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(f16::block(N), LATE ? 4 : 1) void fir_decimate_kern
     const float2 *__restrict__ tw_sub) {
     constexpr int R0 = f16::first_radix(N), TPT = f16::tpt(N);
     static_assert(f16::xpb(N) == 1 || FOLD == 0, "fold path assumes one block per workgroup");
-    static_assert(!LATE || FOLD != 0, "the late mixer is written for the folded inverse");
+    static_assert(!LATE || f16::xpb(N) == 1, "the late mixer assumes one block per workgroup");
     // (+32: the polyphase form shifts each branch's region by 32/D elements, see below)
     __shared__ float2 lds_all[f16::xpb(N) * f16::lds_elems(N) + 32];
     const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
@@ -644,14 +644,38 @@ __global__ __launch_bounds__(f16::block(N), LATE ? 4 : 1) void fir_decimate_kern
     for (int q = 0; q < 16; q++) v[q] = f16::cmul(v[q], hf[f16::edge_index<N, 16>(q, lane)]);
     if constexpr (FOLD == 0) {
         f16::backward<N>(v, lds, tw, lane);
-        if (live) {
+        if (!direct) {
+            if (live) {
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const unsigned idx = f16::edge_index<N, R0>(q, lane);
-                if (idx >= off && idx < off + hop && ((idx - off) % D) == 0) {
-                    const size_t p = b * hop + (idx - off);
-                    if (p < n_in) out[p / D] = v[q];
+                for (int q = 0; q < 16; q++) {
+                    const unsigned idx = f16::edge_index<N, R0>(q, lane);
+                    if (idx >= off && idx < off + hop && ((idx - off) % D) == 0) {
+                        const size_t p = b * hop + (idx - off);
+                        if (p < n_in) out[p / D] = v[q];
+                    }
                 }
+            }
+        } else if constexpr (LATE) {
+            // late block: the filtered block back to LDS, then the elementwise program over
+            // the hop/D kept outputs (output t of the block sits at stream position b*hop + t*D)
+            __syncthreads();  // the backward transform's last-pass reads are done
+#pragma unroll
+            for (int q = 0; q < 16; q++) lds[f16::pad(f16::edge_index<N, R0>(q, lane))] = v[q];
+            __syncthreads();
+            const unsigned per = hop / D;
+            constexpr int W = 4;
+#pragma unroll 1
+            for (unsigned t0 = lane; t0 < per; t0 += W * TPT) {
+                float2 y[W];
+#pragma unroll
+                for (int l = 0; l < W; l++) {
+                    const unsigned tt = t0 + l * TPT < per ? t0 + l * TPT : t0;
+                    y[l] = lds[f16::pad(off + tt * D)];
+                }
+                ew_apply_n<W>(P, y, (uint64_t)b * hop + (uint64_t)t0 * D, run, (uint64_t)TPT * D);
+#pragma unroll
+                for (int l = 0; l < W; l++)
+                    if (t0 + l * TPT < per) out[b * per + t0 + l * TPT] = y[l];
             }
         }
     } else {
@@ -1051,13 +1075,24 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
             break;                                                                     \
         }                                                                              \
     }
+// any other factor (1, 3, 5, 10, ...): full backward transform in the analysis kernel; the
+// late mixer applies there too when a workgroup is one block (N >= 1024)
+#define HZ_FIR16_FULL(N)                                                               \
+    if constexpr (f16::xpb(N) == 1) {                                                  \
+        bool any_late = false;                                                         \
+        HZ_TRY(late_filters(c, P, n_cons, &late, &any_late));                          \
+        if (any_late) HZ_FIR16_L(N, 0, true, (float2 *)nullptr);                       \
+        else HZ_FIR16(N, 0);                                                           \
+    } else {                                                                           \
+        HZ_FIR16(N, 0);                                                                \
+    }
 #define HZ_FIR16_N(N)            \
     do {                         \
         HZ_FIR16_FOLD(N, 2)      \
         HZ_FIR16_FOLD(N, 4)      \
         HZ_FIR16_FOLD(N, 8)      \
         HZ_FIR16_FOLD(N, 16)     \
-        HZ_FIR16(N, 0);          \
+        HZ_FIR16_FULL(N)         \
     } while (0)
         LateFilters late{};
         switch (c->nfft) {
@@ -1070,6 +1105,7 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
         default: return HZSDR_ERR_INVALID_ARGUMENT;
         }
 #undef HZ_FIR16_N
+#undef HZ_FIR16_FULL
 #undef HZ_FIR16_FOLD
 #undef HZ_FIR16
 #undef HZ_FIR16_L
