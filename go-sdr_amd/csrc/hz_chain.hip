@@ -1264,6 +1264,25 @@ int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps, size_t n_taps, u
     c->off = off;
     c->factor = factor;
     c->term = TERM_FIR;
+    // The late mixer's modulated spectra, one per long run of the clock over a whole 2*pi
+    // period (one per binade): prepared now, so that no run of the stream has to stop for one.
+    if (c->has_shift && nfft >= 1024 && nfft <= 4096) {  // the sizes whose blocks can mix late
+        double omega = 0.0;
+        for (int i = 0; i < c->n_ops; i++)
+            if (c->ops[i].kind == EW_SHIFT) omega += c->ops[i].tau_shift;
+        std::vector<hzsdr_nco_segment> segs(64);
+        size_t need = 0;
+        double ts_end = 0.0;
+        const uint64_t period = (uint64_t)(6.283185307179586 * (double)c->sample_rate) + 2;
+        if (hzsdr_nco_segments(c->sample_rate, 0.0, period, segs.data(), segs.size(), &need, &ts_end) == HZSDR_OK) {
+            const size_t have = need < segs.size() ? need : segs.size();
+            for (size_t q = 0; q < have; q++) {
+                if (segs[q].count < 2 * (uint64_t)nfft) continue;
+                void *dev;
+                HZ_TRY(late_filter_for(c, segs[q].step, omega, &dev));
+            }
+        }
+    }
     return HZSDR_OK;
 }
 
