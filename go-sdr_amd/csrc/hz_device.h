@@ -66,15 +66,24 @@ __device__ __forceinline__ float div_const_rn(float x, float d, float rcp_d) {
     float rem = __fmaf_rn(-d, q0, x);
     return __fmaf_rn(rem, rcp_d, q0);
 }
+// x / d for the two divisors the converters use, in two instructions: with c = RN(1/d) and
+// c_lo = RN(1/d - c), fma(x, c, RN(x * c_lo)) is the correctly rounded quotient for EVERY
+// input these converters can see -- checked exhaustively in exact rational arithmetic (all
+// 256 values of b - 127.5 against d = 127.5, all 65 536 int16 values against d = 32767) and
+// again on the GPU by tests/test_gpu_parity.py::test_convert_exhaustive_bit_exact.  It is
+// NOT a general division (div_const_rn is).
+__device__ __forceinline__ float div_by_const2(float x, float c, float c_lo) {
+    return __fmaf_rn(x, c, __fmul_rn(x, c_lo));
+}
 // iq_u8.go:111-121 / iq_u8_amd64.s:71-89: (float32(b) - 127.5) / 127.5
 __device__ __forceinline__ float u8_to_f32(uint32_t b) {
-    return div_const_rn(__fsub_rn((float)b, 127.5f), 127.5f, 1.0f / 127.5f);
+    return div_by_const2(__fsub_rn((float)b, 127.5f), 0x1.010102p-7f, -0x1.fdfdfep-32f);
 }
 // iq_i8.go:109-119: float32(b) / 128 (a power of two: the multiply is exact)
 __device__ __forceinline__ float i8_to_f32(int32_t b) { return __fmul_rn((float)b, 0.0078125f); }
 // iq_i16.go:137-147: float32(v) / 32767
 __device__ __forceinline__ float i16_to_f32(int32_t v) {
-    return div_const_rn((float)v, 32767.0f, 1.0f / 32767.0f);
+    return div_by_const2((float)v, 0x1.0002p-15f, 0x1.0002p-45f);
 }
 // iq_c64.go:77-89: uint8(x*127.5 + 127.5), un-fused
 __device__ __forceinline__ uint32_t f32_to_u8(float x) {

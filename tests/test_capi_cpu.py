@@ -88,6 +88,42 @@ def test_nco_planner_reproduces_the_serial_clock(hz, orc, rate, n, ts0):
     assert ts_end == sh.ts.value
 
 
+def test_two_instruction_constant_division_is_exact():
+    """hz_device.h div_by_const2: fma(x, c, RN(x * c_lo)) with c = RN(1/d), c_lo = RN(1/d - c)
+    must be the correctly rounded x / d for every input the converters can produce -- proven
+    here in exact rational arithmetic, not sampled: all 256 byte values against 127.5
+    (iq_u8.go:111-121), all 65 536 int16 values against 32767 (iq_i16.go:137-147).  The
+    constants are the ones in the header."""
+    from fractions import Fraction as Fr
+
+    def rn32(x):  # round a rational to float32, ties to even
+        if x == 0:
+            return Fr(0)
+        s, a = (1 if x > 0 else -1), abs(x)
+        e = math.floor(math.log2(float(a)))
+        while Fr(2) ** e > a:
+            e -= 1
+        while Fr(2) ** (e + 1) <= a:
+            e += 1
+        ulp = Fr(2) ** (e - 23)
+        q = a / ulp
+        fl = q.numerator // q.denominator
+        rem = q - fl
+        if rem > Fr(1, 2) or (rem == Fr(1, 2) and fl % 2 == 1):
+            fl += 1
+        return s * fl * ulp
+
+    src = open(os.path.join(ROOT, "go-sdr_amd", "csrc", "hz_device.h")).read()
+    assert "0x1.010102p-7f, -0x1.fdfdfep-32f" in src and "0x1.0002p-15f, 0x1.0002p-45f" in src
+    c, c_lo = Fr(float.fromhex("0x1.010102p-7")), Fr(float.fromhex("-0x1.fdfdfep-32"))
+    for b in range(256):
+        t = Fr(b) - Fr(255, 2)
+        assert rn32(t * c + rn32(t * c_lo)) == rn32(t / Fr(255, 2)), b
+    c, c_lo = Fr(float.fromhex("0x1.0002p-15")), Fr(float.fromhex("0x1.0002p-45"))
+    for v in range(-32768, 32768):
+        assert rn32(Fr(v) * c + rn32(Fr(v) * c_lo)) == rn32(Fr(v, 32767)), v
+
+
 def test_nco_planner_is_compact(hz):
     segs, _ = hz.nco_segments(20_000_000, 0.0, 1 << 24)
     assert len(segs) <= 32  # fits the by-value kernel table
