@@ -99,6 +99,27 @@ __device__ __forceinline__ void ew_apply_n(const EwProgram &P, float2 (&v)[W], u
     }
 }
 
+// The two most common programs -- Shift, and Shift then Gain (BASELINE config 2) -- spelt
+// out, without the op loop: same operations in the same order, but straight-line code the
+// scheduler can overlap with the loads and stores around it.  SHAPE 0 = interpret.
+enum EwShape { SHAPE_ANY = 0, SHAPE_SHIFT = 1, SHAPE_SHIFT_GAIN = 2 };
+template <int W, int SHAPE>
+__device__ __forceinline__ void ew_apply_shape(const EwProgram &P, float2 (&v)[W], uint64_t j0, NcoWin w) {
+    if constexpr (SHAPE == SHAPE_ANY) {
+        ew_apply_n<W>(P, v, j0, w);
+    } else {
+        double s[W], c[W];
+#pragma unroll
+        for (int l = 0; l < W; l++) go_sincos(__dmul_rn(P.op[0].tau_shift, nco_ts(P.segs, w, j0 + l)), s[l], c[l]);
+#pragma unroll
+        for (int l = 0; l < W; l++) {
+            v[l] = go_cmul(v[l], make_float2((float)c[l], (float)s[l]));
+            if constexpr (SHAPE == SHAPE_SHIFT_GAIN)
+                v[l] = make_float2(__fmul_rn(v[l].x, P.op[1].a), __fmul_rn(v[l].y, P.op[1].a));
+        }
+    }
+}
+
 template <int FMT> struct Raw;
 template <> struct Raw<HZSDR_FMT_C64> {
     using t = float2;
@@ -127,7 +148,7 @@ __device__ __forceinline__ float2 chain_sample(const void *in, const EwProgram &
 // ---- streaming terminals ---------------------------------------------------------------
 
 // TERM 0: out[j] = f(j).  W samples per lane per step (vector load / store).
-template <int FMT, int W>
+template <int FMT, int W, int SHAPE = SHAPE_ANY>
 __global__ __launch_bounds__(kThreads) void chain_map_kernel(const void *__restrict__ in,
                                                              float2 *__restrict__ out, size_t nvec,
                                                              uint64_t base, EwProgram P) {
@@ -154,7 +175,7 @@ __global__ __launch_bounds__(kThreads) void chain_map_kernel(const void *__restr
                 OV o;
 #pragma unroll
                 for (int l = 0; l < W; l++) o.v[l] = Raw<FMT>::cvt(x[u].v[l]);
-                ew_apply_n<W>(P, o.v, base + i * W, w);
+                ew_apply_shape<W, SHAPE>(P, o.v, base + i * W, w);
                 ((OV *)out)[i] = o;
             }
         }
@@ -898,10 +919,21 @@ static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, cons
     // sub-slice, one at a time
     const auto ok = [&](int w) { return ((uintptr_t)in % (sizeof(R) * w) == 0) && ((uintptr_t)out % (8 * w) == 0); };
     size_t done = 0;
+    const int shape = P.n == 1 && P.op[0].kind == EW_SHIFT ? SHAPE_SHIFT
+                      : P.n == 2 && P.op[0].kind == EW_SHIFT && P.op[1].kind == EW_SCALE ? SHAPE_SHIFT_GAIN
+                                                                                         : SHAPE_ANY;
     if (ok(4) && n >= 4) {
         const size_t nvec = n / 4;
-        hipLaunchKernelGGL((chain_map_kernel<FMT, 4>), dim3(blocks_for(ctx, nvec)), dim3(kThreads), 0,
-                           ctx->stream, in, (float2 *)out, nvec, (uint64_t)0, P);
+        const dim3 grid(blocks_for(ctx, nvec)), block(kThreads);
+        if (shape == SHAPE_SHIFT_GAIN)
+            hipLaunchKernelGGL((chain_map_kernel<FMT, 4, SHAPE_SHIFT_GAIN>), grid, block, 0, ctx->stream, in,
+                               (float2 *)out, nvec, (uint64_t)0, P);
+        else if (shape == SHAPE_SHIFT)
+            hipLaunchKernelGGL((chain_map_kernel<FMT, 4, SHAPE_SHIFT>), grid, block, 0, ctx->stream, in,
+                               (float2 *)out, nvec, (uint64_t)0, P);
+        else
+            hipLaunchKernelGGL((chain_map_kernel<FMT, 4>), grid, block, 0, ctx->stream, in, (float2 *)out, nvec,
+                               (uint64_t)0, P);
         done = nvec * 4;
     } else if (ok(2) && n >= 2) {
         const size_t nvec = n / 2;
