@@ -479,7 +479,7 @@ __device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const
 }
 
 template <int N, int FMT, bool STAGED>
-__global__ __launch_bounds__(f16::block(N)) void conv_blocks_kernel16(const void *in, float2 *out,
+__global__ __launch_bounds__(f16::block(N), 4) void conv_blocks_kernel16(const void *in, float2 *out,
                                                                       const float2 *__restrict__ filt,
                                                                       const float2 *__restrict__ tw,
                                                                       size_t nblocks, unsigned dec,
