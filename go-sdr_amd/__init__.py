@@ -491,6 +491,11 @@ class Convolver:
     def __call__(self):
         self.ctx._ck(lib.hzsdr_conv_exec(self._h))
 
+    def set_filter(self, freq):
+        """ConvolveFreq only: the reference closure reads `freq` on every call
+        (fft/convolution.go:183-189); here an updated filter is handed over explicitly."""
+        self.ctx._ck(lib.hzsdr_conv_set_filter(self._h, _ptr(freq), length(freq)))
+
     def close(self):
         if self._h:
             lib.hzsdr_conv_free(self._h)
@@ -556,6 +561,16 @@ class Chain:
 
     def reset(self):
         self.ctx._ck(lib.hzsdr_chain_reset(self._h))
+
+    def set_time(self, ts):
+        """The Shift closure's clock (stream/shifter.go:71): resume a stream / start a test near 2*pi."""
+        self.ctx._ck(lib.hzsdr_chain_set_time(self._h, float(ts)))
+        return self
+
+    def time(self):
+        t = C.c_double(0.0)
+        self.ctx._ck(lib.hzsdr_chain_time(self._h, C.byref(t)))
+        return t.value
 
     def ring(self, slot_length, slots=4):
         return Ring(self, slot_length, slots)

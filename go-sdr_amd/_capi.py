@@ -115,6 +115,7 @@ SIGNATURES = {
     "hzsdr_convolve_create": (i32, [vp, vp, sz, vp, sz, vp, sz, i32, pvp]),
     "hzsdr_convolve_freq_create": (i32, [vp, vp, sz, vp, sz, vp, sz, pvp]),
     "hzsdr_conv_exec": (i32, [vp]),
+    "hzsdr_conv_set_filter": (i32, [vp, vp, sz]),
     "hzsdr_conv_free": (i32, [vp]),
     "hzsdr_convolution_blocks": (i32, [vp, vp, sz, vp, sz, vp, sz, psz]),
     "hzsdr_beamform_angles_2d": (i32, [f64, f64, C.POINTER(f64), C.POINTER(f64), i32,
@@ -140,6 +141,8 @@ SIGNATURES = {
     "hzsdr_chain_plan": (i32, [vp, sz, psz, psz]),
     "hzsdr_chain_run": (i32, [vp, vp, sz, vp, sz, psz, psz]),
     "hzsdr_chain_reset": (i32, [vp]),
+    "hzsdr_chain_set_time": (i32, [vp, f64]),
+    "hzsdr_chain_time": (i32, [vp, C.POINTER(f64)]),
     "hzsdr_chain_free": (i32, [vp]),
     "hzsdr_ring_create": (i32, [vp, sz, i32, pvp]),
     "hzsdr_ring_iq_buffer": (i32, [vp, pvp, psz, psz]),

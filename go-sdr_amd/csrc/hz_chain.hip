@@ -554,6 +554,9 @@ constexpr bool fold_poly(int n, int fold) {
            n / fold >= 256;
 }
 
+// the FFT sizes whose blocks can mix late (one overlap-save block per workgroup)
+constexpr bool late_capable(unsigned nfft) { return nfft >= 1024 && nfft <= 4096; }
+
 // workgroup-uniform: does block b (input span [p0, p0 + N)) take the late-mixer path?
 __device__ __forceinline__ bool late_block(const EwProgram &P, const LateFilters &late, int64_t p0, int N,
                                            unsigned off, size_t n_in, NcoWin *run) {
@@ -978,9 +981,15 @@ static int filter_spectrum(hzsdr_chain *c, const float *taps, void *dst) {
     return HZSDR_OK;
 }
 
-// The spectrum of taps[k] * exp(-i * omega * k * step) for one clock step.
-static int late_filter_for(hzsdr_chain *c, double step, double omega, void **dev) {
+// The spectrum of taps[k] * exp(-i * omega * k * step) for one clock step.  A miss uploads,
+// transforms and WAITS (filter_spectrum), so callers on the streaming path only look up
+// (`make` = false: *dev = nullptr on a miss); hzsdr_chain_fir_decimate / _set_time prepare
+// every step a stream can meet ahead of time (prepare_late_filters).  Entries are never
+// evicted while the chain lives: pointers handed to enqueued kernels stay valid.
+constexpr size_t kLateCacheMax = 64;
+static int late_filter_for(hzsdr_chain *c, double step, double omega, void **dev, bool make) {
     hzsdr_ctx *ctx = c->ctx;
+    *dev = nullptr;
     uint64_t key;
     memcpy(&key, &step, 8);
     auto it = c->late_cache.find(key);
@@ -988,11 +997,7 @@ static int late_filter_for(hzsdr_chain *c, double step, double omega, void **dev
         *dev = it->second;
         return HZSDR_OK;
     }
-    if (c->late_cache.size() >= 64) {  // a clock that keeps changing binade: start over
-        HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (auto &kv : c->late_cache) (void)hipFree(kv.second);
-        c->late_cache.clear();
-    }
+    if (!make || c->late_cache.size() >= kLateCacheMax) return HZSDR_OK;  // that run mixes in reference order
     std::vector<float> mod(2 * c->ntaps);
     for (size_t k = 0; k < c->ntaps; k++) {
         const double ph = -omega * ((double)k * step);
@@ -1003,13 +1008,49 @@ static int late_filter_for(hzsdr_chain *c, double step, double omega, void **dev
     }
     void *h = nullptr;
     HZ_HIP(ctx, hipMalloc(&h, (size_t)c->nfft * 8));
-    HZ_TRY(filter_spectrum(c, mod.data(), h));
+    int rc = filter_spectrum(c, mod.data(), h);
+    if (rc != HZSDR_OK) {
+        (void)hipFree(h);
+        return rc;
+    }
     c->late_cache[key] = h;
     *dev = h;
     return HZSDR_OK;
 }
 
-// The modulated filter of every clock run long enough to hold a whole block.
+static double chain_omega(const hzsdr_chain *c) {
+    double omega = 0.0;
+    for (int i = 0; i < c->n_ops; i++)
+        if (c->ops[i].kind == EW_SHIFT) omega += c->ops[i].tau_shift;
+    return omega;
+}
+
+// The late mixer's modulated spectra for every long run the clock can produce from `ts0`
+// on: the rest of the current 2*pi period plus one whole period from 0 (the clock's step is
+// a function of the binade alone, so after the first wrap the runs repeat).  Done at chain
+// construction and whenever the clock is set, so hzsdr_chain_run never allocates or waits.
+static int prepare_late_filters(hzsdr_chain *c, double ts0) {
+    if (!c->has_shift || !late_capable(c->nfft) || c->taps_host.empty()) return HZSDR_OK;
+    const double omega = chain_omega(c);
+    const uint64_t period = (uint64_t)(6.283185307179586 * (double)c->sample_rate) + 2;
+    for (int pass = 0; pass < 2; pass++) {
+        std::vector<hzsdr_nco_segment> segs(96);
+        size_t need = 0;
+        double ts_end = 0.0;
+        if (hzsdr_nco_segments(c->sample_rate, pass == 0 ? ts0 : 0.0, period, segs.data(), segs.size(), &need,
+                               &ts_end) != HZSDR_OK)
+            continue;
+        const size_t have = need < segs.size() ? need : segs.size();
+        for (size_t q = 0; q < have; q++) {
+            if (segs[q].count < 2 * (uint64_t)c->nfft) continue;
+            void *dev;
+            HZ_TRY(late_filter_for(c, segs[q].step, omega, &dev, true));
+        }
+    }
+    return HZSDR_OK;
+}
+
+// The modulated filter of every clock run long enough to hold a whole block (lookups only).
 static int late_filters(hzsdr_chain *c, const EwProgram &P, size_t n, LateFilters *out, bool *any) {
     *any = false;
     memset(out, 0, sizeof *out);
@@ -1021,16 +1062,14 @@ static int late_filters(hzsdr_chain *c, const EwProgram &P, size_t n, LateFilter
         *any = true;
         return HZSDR_OK;
     }
-    double omega = 0.0;
-    for (int i = 0; i < P.n; i++)
-        if (P.op[i].kind == EW_SHIFT) omega += P.op[i].tau_shift;
+    const double omega = chain_omega(c);
     for (int r = 0; r < P.segs.n; r++) {
         const uint64_t first = P.segs.first[r], end = r + 1 < P.segs.n ? P.segs.first[r + 1] : (uint64_t)n;
         if (end - first < 2 * (uint64_t)c->nfft) continue;
         void *dev;
-        HZ_TRY(late_filter_for(c, P.segs.step[r], omega, &dev));
+        HZ_TRY(late_filter_for(c, P.segs.step[r], omega, &dev, false));
         out->h[r] = (const float2 *)dev;
-        *any = true;
+        if (dev) *any = true;
     }
     return HZSDR_OK;
 }
@@ -1171,6 +1210,17 @@ static int chain_launch(hzsdr_chain *c, const void *din, size_t cons, void *dout
     return HZSDR_OK;
 }
 
+// Snapshot a caller's frequency-domain filter into library memory ON THE CONTEXT'S STREAM:
+// in a DEVICE context the filter may still be being produced by work enqueued on that
+// stream (an hzsdr_fft_transform, a torch kernel), which the legacy null stream does not
+// order against.  HOST contexts wait, so the caller's slice may be reused on return.
+static int upload_filter(hzsdr_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    const bool host = ctx->memspace == HZSDR_MEM_HOST;
+    HZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
+    if (host) HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HZSDR_OK;
+}
+
 static int chain_terminal_set(hzsdr_chain *c) {
     if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
     if (c->term != TERM_NONE) return fail(c->ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: terminal stage already set");
@@ -1256,9 +1306,14 @@ int hzsdr_chain_convolution(hzsdr_chain *c, const void *filter_freq, size_t filt
         return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: filter length must be a power of two in 4..8192");
     if (decimate_factor == 0 || decimate_factor > kReaderBlock) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: decimate factor");
     HZ_TRY(enter(ctx));
-    HZ_HIP(ctx, hipMalloc(&c->filt, filter_len * 8));
-    hipMemcpyKind kind = ctx->memspace == HZSDR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-    HZ_HIP(ctx, hipMemcpy(c->filt, filter_freq, filter_len * 8, kind));
+    void *filt = nullptr;
+    HZ_HIP(ctx, hipMalloc(&filt, filter_len * 8));
+    int rc = upload_filter(ctx, filt, filter_freq, filter_len * 8);
+    if (rc != HZSDR_OK) {
+        (void)hipFree(filt);
+        return rc;
+    }
+    c->filt = filt;
     c->flen = filter_len;
     c->factor = decimate_factor;
     c->term = TERM_CONV;
@@ -1279,42 +1334,37 @@ int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps, size_t n_taps, u
     unsigned hop = (nfft - off) / factor * factor;
     HZ_TRY(enter(ctx));
     const size_t hb = (size_t)(off ? off : 1) * 8;
-    HZ_HIP(ctx, hipMalloc(&c->hfreq, (size_t)nfft * 8));
-    HZ_HIP(ctx, hipMalloc(&c->hist[0], hb));
-    HZ_HIP(ctx, hipMalloc(&c->hist[1], hb));
-    HZ_HIP(ctx, hipMemsetAsync(c->hist[0], 0, hb, ctx->stream));
-    HZ_HIP(ctx, hipMemsetAsync(c->hist[1], 0, hb, ctx->stream));
-    c->ntaps = n_taps;
-    c->nfft = nfft;
-    c->factor = factor;
-    c->poly = fold_poly((int)nfft, (int)factor);
-    HZ_TRY(filter_spectrum(c, taps, c->hfreq));
-    c->taps_host.assign(taps, taps + 2 * n_taps);
     c->ntaps = n_taps;
     c->nfft = nfft;
     c->hop = hop;
     c->off = off;
     c->factor = factor;
-    c->term = TERM_FIR;
-    // The late mixer's modulated spectra, one per long run of the clock over a whole 2*pi
-    // period (one per binade): prepared now, so that no run of the stream has to stop for one.
-    if (c->has_shift && nfft >= 1024 && nfft <= 4096) {  // the sizes whose blocks can mix late
-        double omega = 0.0;
-        for (int i = 0; i < c->n_ops; i++)
-            if (c->ops[i].kind == EW_SHIFT) omega += c->ops[i].tau_shift;
-        std::vector<hzsdr_nco_segment> segs(64);
-        size_t need = 0;
-        double ts_end = 0.0;
-        const uint64_t period = (uint64_t)(6.283185307179586 * (double)c->sample_rate) + 2;
-        if (hzsdr_nco_segments(c->sample_rate, 0.0, period, segs.data(), segs.size(), &need, &ts_end) == HZSDR_OK) {
-            const size_t have = need < segs.size() ? need : segs.size();
-            for (size_t q = 0; q < have; q++) {
-                if (segs[q].count < 2 * (uint64_t)nfft) continue;
-                void *dev;
-                HZ_TRY(late_filter_for(c, segs[q].step, omega, &dev));
-            }
+    c->poly = fold_poly((int)nfft, (int)factor);
+    c->taps_host.assign(taps, taps + 2 * n_taps);
+    // every allocation is released again if a later step fails: the chain stays without a
+    // terminal stage (a retry starts clean, nothing leaks)
+    auto build = [&]() -> int {
+        HZ_HIP(ctx, hipMalloc(&c->hfreq, (size_t)nfft * 8));
+        HZ_HIP(ctx, hipMalloc(&c->hist[0], hb));
+        HZ_HIP(ctx, hipMalloc(&c->hist[1], hb));
+        HZ_HIP(ctx, hipMemsetAsync(c->hist[0], 0, hb, ctx->stream));
+        HZ_HIP(ctx, hipMemsetAsync(c->hist[1], 0, hb, ctx->stream));
+        HZ_TRY(filter_spectrum(c, taps, c->hfreq));
+        return prepare_late_filters(c, c->ts);
+    };
+    const int rc = build();
+    if (rc != HZSDR_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void **p : {&c->hfreq, &c->hist[0], &c->hist[1]}) {
+            if (*p) (void)hipFree(*p);
+            *p = nullptr;
         }
+        for (auto &kv : c->late_cache) (void)hipFree(kv.second);
+        c->late_cache.clear();
+        c->taps_host.clear();
+        return rc;
     }
+    c->term = TERM_FIR;
     return HZSDR_OK;
 }
 
@@ -1385,6 +1435,22 @@ int hzsdr_chain_reset(hzsdr_chain *c) {
     return HZSDR_OK;
 }
 
+int hzsdr_chain_set_time(hzsdr_chain *c, double ts) {
+    if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
+    if (!(ts >= 0.0) || ts > 6.283185307179586476925286766559)  // the closure's clock lives in [0, 2*pi]
+        return hz::fail(c->ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: clock outside [0, 2*pi]");
+    HZ_TRY(hz::enter(c->ctx));
+    c->ts = ts;
+    if (c->term == TERM_FIR) HZ_TRY(hz::prepare_late_filters(c, ts));
+    return HZSDR_OK;
+}
+
+int hzsdr_chain_time(const hzsdr_chain *c, double *ts) {
+    if (!c || !ts) return HZSDR_ERR_INVALID_ARGUMENT;
+    *ts = c->ts;
+    return HZSDR_OK;
+}
+
 int hzsdr_chain_free(hzsdr_chain *c) {
     if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->ctx->device);
@@ -1419,11 +1485,10 @@ int hzsdr_convolve_freq_create(hzsdr_ctx *ctx, void *dst, size_t dst_len, const 
     HZ_TRY(enter(ctx));
     void *filt = nullptr;
     HZ_HIP(ctx, hipMalloc(&filt, n * 8));
-    hipMemcpyKind kind = ctx->memspace == HZSDR_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-    hipError_t e = hipMemcpy(filt, freq, n * 8, kind);
-    if (e != hipSuccess) {
+    int rc = upload_filter(ctx, filt, freq, n * 8);
+    if (rc != HZSDR_OK) {
         (void)hipFree(filt);
-        return hip_fail(ctx, e, "filter upload", __FILE__, __LINE__);
+        return rc;
     }
     *out = new hzsdr_conv{ctx, 0, dst, src, nullptr, n, filt};
     return HZSDR_OK;
@@ -1463,6 +1528,16 @@ int hzsdr_conv_exec(hzsdr_conv *cv) {
         HZ_TRY(conv_generic_device(ctx, dd, d1, cv->kind == 0 ? cv->filt : d2, cv->n, cv->kind));
     }
     return st.finish();
+}
+
+int hzsdr_conv_set_filter(hzsdr_conv *cv, const void *freq, size_t freq_len) {
+    using namespace hz;
+    if (!cv) return HZSDR_ERR_INVALID_ARGUMENT;
+    hzsdr_ctx *ctx = cv->ctx;
+    if (cv->kind != 0 || !freq) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "conv: not a ConvolveFreq closure");
+    if (freq_len != cv->n) return fail(ctx, HZSDR_ERR_LENGTH_MISMATCH, "sdr/fft.Convolve: Lengths do not match exactly");
+    HZ_TRY(enter(ctx));
+    return upload_filter(ctx, cv->filt, freq, cv->n * 8);  // stream-ordered after earlier execs
 }
 
 int hzsdr_conv_free(hzsdr_conv *cv) {

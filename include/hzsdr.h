@@ -237,6 +237,13 @@ int hzsdr_convolve_freq_create(hzsdr_ctx *ctx, void *dst, size_t dst_len, const 
 /* Calls the closure once: forward transform(s), pointwise multiply with Go
  * complex64 semantics (fft/convolution.go:107-109, :187-189), backward. */
 int hzsdr_conv_exec(hzsdr_conv *conv);
+/* DIFFERENCE from the reference: fft.ConvolveFreq's closure captures the `freq` slice by
+ * reference (fft/convolution.go:183-189), so a Go caller that rewrites the filter bins
+ * between calls sees the new filter; here the bins were snapshotted into device memory at
+ * creation.  A caller that updates its filter calls this before the next hzsdr_conv_exec
+ * (the copy is ordered on the context's stream behind earlier execs).  ConvolveFreq
+ * closures only; LENGTH_MISMATCH unless freq_len equals the closure's length. */
+int hzsdr_conv_set_filter(hzsdr_conv *conv, const void *freq, size_t freq_len);
 int hzsdr_conv_free(hzsdr_conv *conv);
 /* The whole-buffer form of stream.ConvolutionReader, stream/convolution.go:36-82:
  * block-circular filtering of consecutive len(filter)-sample blocks; a
@@ -356,6 +363,12 @@ int hzsdr_chain_run(hzsdr_chain *c, const void *in, size_t n_in, void *out, size
                     size_t *n_consumed, size_t *n_out);
 /* Forget stream state (NCO time, FIR history). */
 int hzsdr_chain_reset(hzsdr_chain *c);
+/* The Shift closure's clock `ts` (stream/shifter.go:71,77-80), in [0, 2*pi]: read it to
+ * checkpoint a stream, set it to resume one (or to start a test next to the 2*pi wrap).
+ * Setting it also prepares the late mixer's spectra for the runs that follow, so that
+ * hzsdr_chain_run itself never allocates or waits. */
+int hzsdr_chain_set_time(hzsdr_chain *c, double ts);
+int hzsdr_chain_time(const hzsdr_chain *c, double *ts);
 int hzsdr_chain_free(hzsdr_chain *c);
 
 /* ---- pinned ring in front of a chain -------------------- */

@@ -258,6 +258,25 @@ def par_shift_gain(ts, sample_rate, freq_hz, gain, buf, threads):
     return t.value
 
 
+def par_fir_decimate_f64(out, x, taps, d, hist=None, threads=None):
+    """fir_decimate_f64 over `threads` cores (default: all), bit-identical to the serial form."""
+    taps = np.ascontiguousarray(taps, np.complex64)
+    lib().orc_par_fir_decimate_f64(_p(out), _p(x), C.c_long(length(x)), _p(taps), C.c_long(len(taps)),
+                                   C.c_uint(d), _p(hist) if hist is not None else None,
+                                   C.c_int(threads or max_threads()))
+    return out
+
+
+def par_chain_fir(src_u8, out, sample_rate, freq_hz, taps, d, threads, scratch=None):
+    """u8 -> c64 -> Shift -> FIR -> decimate by d from a fresh stream, OpenMP over `threads`."""
+    n = length(src_u8)
+    buf = scratch if scratch is not None else np.zeros(n, np.complex64)
+    taps = np.ascontiguousarray(taps, np.complex64)
+    lib().orc_par_chain_fir(_p(src_u8), _p(buf), _p(out), C.c_long(n), C.c_ulong(int(sample_rate)),
+                            C.c_double(freq_hz), _p(taps), C.c_long(len(taps)), C.c_uint(d), C.c_int(threads))
+    return out
+
+
 def peak_lag(corr):
     lag = C.c_long(0)
     lib().orc_peak_lag(_p(corr), C.c_long(length(corr)), C.byref(lag))

@@ -1,0 +1,153 @@
+"""The benchmarked configurations at their FULL size, against the oracle.
+
+* north star: 2^24 u8 samples, 20 Msps, Shift(-fs/8), 1024 taps, decimate by 8, DEVICE
+  space, both mixer orders, then a second 2^24-sample call whose clock crosses the 2*pi
+  wrap (history carried over) -- the buffer the bench line is quoted on, including the long
+  0.25 -> 0.5 and 0.5 -> 1 binades of the NCO clock that no smaller case reaches.
+* BASELINE config 3 in its north-star form: c64, 1024 taps, D = 1 (the kernel instantiation
+  bench.py times as `fir_1024_overlap_save_c64`), with and without a Shift in front.
+* a filter that is still being PRODUCED on the context's stream when the chain / closure
+  is created (DEVICE space): the snapshot must be ordered behind the producer.
+
+The oracle legs run on every host core through oracle/oracle_parallel.c (bit-identical to
+the serial oracle, checked in tests/test_oracle.py); bounds are tests/util.py's."""
+import importlib
+
+import numpy as np
+import pytest
+
+from util import assert_fir_close, rand_c64, rand_u8, zeros
+
+pytestmark = pytest.mark.gpu
+
+TAU = 6.283185307179586476925286766559
+
+
+@pytest.fixture(scope="module")
+def hz():
+    return importlib.import_module("go-sdr_amd")
+
+
+@pytest.fixture(scope="module")
+def dev(hz):
+    import torch
+    ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+    yield ctx, torch
+    ctx.close()
+
+
+def lowpass(ntaps, cutoff):
+    k = np.arange(ntaps) - (ntaps - 1) / 2
+    return (2 * cutoff * np.sinc(2 * cutoff * k) * np.hamming(ntaps)).astype(np.complex64)
+
+
+def test_north_star_full_size(hz, dev, orc):
+    ctx, torch = dev
+    n, fs, D = 1 << 24, 20_000_000, 8
+    shift, taps = -fs / 8, lowpass(1024, 1.0 / 16)
+    x = rand_u8(9, 2 * n)
+    # oracle: reference order.  Call 1 starts the clock at 0; call 2 resumes at 2*pi - 0.4 s
+    # (0.84 s of signal per call: the wrap falls in the middle of call 2); one FIR over the
+    # concatenation = history carried from call 1 into call 2.
+    ts2 = TAU - 0.4
+    xc = zeros("c64", 2 * n)
+    orc.convert(xc, x)
+    sh = orc.Shifter(fs)
+    sh(shift, xc[:n])
+    sh.ts.value = ts2
+    sh(shift, xc[n:])
+    assert sh.ts.value < 1.0  # the clock wrapped inside call 2
+    want = zeros("c64", 2 * n // D)
+    orc.par_fir_decimate_f64(want, xc, taps, D)
+    xmax = float(np.abs(xc).max())
+    del xc
+    dx = torch.from_numpy(x).cuda()
+    outs = {}
+    for in_order in (False, True):
+        ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D).mix_in_order(in_order)
+        out = torch.zeros(2 * n // D, dtype=torch.complex64, device="cuda")
+        assert ch.run(dx[:n], out[:n // D]) == (n, n // D)
+        ch.set_time(ts2)
+        assert ch.run(dx[n:], out[n // D:]) == (n, n // D)
+        ctx.synchronize()
+        assert ch.time() == sh.ts.value  # the clock planner lands on the serial recurrence's value
+        got = out.cpu().numpy()
+        assert_fir_close(got[:n // D], want[:n // D], taps, xmax, ("call 1", in_order))
+        assert_fir_close(got[n // D:], want[n // D:], taps, xmax, ("call 2, 2*pi wrap", in_order))
+        outs[in_order] = got
+        ch.close()
+    d = outs[False].astype(np.complex128) - outs[True]
+    assert np.linalg.norm(d) <= 2e-7 * np.linalg.norm(want.astype(np.complex128))
+
+
+@pytest.mark.parametrize("with_shift", [False, True])
+def test_config3_fir_1024_c64_no_decimation(hz, dev, orc, with_shift):
+    """fir_decimate_kernel16<4096, c64, FOLD 0, late>: 1024 taps, D = 1."""
+    ctx, torch = dev
+    n, fs = 1 << 21, 20_000_000
+    taps = lowpass(1024, 1.0 / 16)
+    x = rand_c64(2, n)
+    xc = x.copy()
+    if with_shift:
+        orc.Shifter(fs)(2.5e6, xc)
+    want = zeros("c64", n)
+    orc.par_fir_decimate_f64(want, xc, taps, 1)
+    dx = torch.from_numpy(x).cuda()
+    for in_order in (False, True):
+        ch = ctx.chain(hz.FMT_C64, fs)
+        if with_shift:
+            ch.shift(2.5e6)
+        ch.fir_decimate(taps, 1).mix_in_order(in_order)
+        out = torch.zeros(n, dtype=torch.complex64, device="cuda")
+        half = n // 2 + 4096 + 17  # two ragged calls: history crosses a call boundary
+        assert ch.run(dx[:half], out[:half]) == (half, half)
+        assert ch.run(dx[half:], out[half:]) == (n - half, n - half)
+        ctx.synchronize()
+        assert_fir_close(out.cpu().numpy(), want, taps, float(np.abs(xc).max()), (with_shift, in_order))
+        ch.close()
+
+
+def test_filter_produced_on_the_stream_just_before(hz, dev, orc):
+    """ConvolutionReader chain and ConvolveFreq closure whose frequency-domain filter is the
+    output of an hzsdr_fft_transform enqueued immediately before on the same DEVICE context
+    (stream/convolution.go:36-49 builds its filter exactly like that)."""
+    ctx, torch = dev
+    flen, nblk = 1024, 512
+    h = np.zeros(flen, np.complex64)
+    h[:129] = lowpass(129, 0.1)
+    x = rand_c64(4, flen * nblk)
+    Hw = np.zeros(flen, np.complex64)
+    orc.fft(h, Hw, True)
+    want = zeros("c64", flen * nblk)
+    orc.convolution_reader(want, x, Hw)
+    dx = torch.from_numpy(x).cuda()
+    for rep in range(3):  # a race would not lose every time: repeat with fresh buffers
+        dh = torch.from_numpy(h).cuda()
+        # big transform first so the stream is busy when the filter's transform is enqueued
+        busy_in = torch.from_numpy(rand_c64(50 + rep, 1 << 22)).cuda()
+        busy_out = torch.empty_like(busy_in)
+        dH = torch.zeros(flen, dtype=torch.complex64, device="cuda")
+        plan_busy = ctx.fft_plan(busy_in, busy_out, hz.FFT_FORWARD)
+        plan = ctx.fft_plan(dh, dH, hz.FFT_FORWARD)
+        plan_busy.transform()
+        plan.transform()
+        ch = ctx.chain(hz.FMT_C64).convolution(dH)          # snapshot of dH: must follow plan.transform()
+        dst = torch.zeros(flen, dtype=torch.complex64, device="cuda")
+        cv = ctx.convolve_freq(dst, dx[:flen], dH)
+        out = torch.zeros(flen * nblk, dtype=torch.complex64, device="cuda")
+        assert ch.run(dx, out) == (flen * nblk, flen * nblk)
+        cv()
+        ctx.synchronize()
+        got = out.cpu().numpy().astype(np.complex128)
+        assert np.linalg.norm(got - want) <= 2e-6 * np.linalg.norm(want.astype(np.complex128)), rep
+        g1 = dst.cpu().numpy().astype(np.complex128)
+        assert np.linalg.norm(g1 - want[:flen]) <= 2e-6 * np.linalg.norm(want[:flen].astype(np.complex128)), rep
+        # ConvolveFreq: an updated filter is handed over explicitly (hzsdr_conv_set_filter)
+        dH2 = dH * 2
+        cv.set_filter(dH2)
+        cv()
+        ctx.synchronize()
+        g2 = dst.cpu().numpy().astype(np.complex128)
+        assert np.linalg.norm(g2 - 2 * want[:flen]) <= 2e-6 * np.linalg.norm(2 * want[:flen].astype(np.complex128))
+        for o in (ch, cv, plan, plan_busy):
+            o.close()
