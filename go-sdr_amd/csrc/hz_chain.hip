@@ -17,779 +17,10 @@
 // HBM between stages.
 #include <math.h>
 
-#include "hz_common.h"
-#include "hz_device.h"
-#include "hz_fft.h"
-#include "hz_fft16.h"
+#include <algorithm>
+
+#include "hz_chain_dev.h"
 #include "hz_fft_api.h"
-#include "hz_nco.h"
-
-namespace hz {
-
-// ---- elementwise program -------------------------------------------------------------
-
-constexpr int kMaxEw = 6;
-enum EwKind { EW_SCALE = 1, EW_ROTATE = 2, EW_SHIFT = 3 };
-struct EwOp {
-    int kind;
-    float a, b;        // scale: a = r; rotate: a + ib
-    double tau_shift;  // shift: fl(2*pi * shift_hz)
-};
-struct EwProgram {
-    int n;
-    EwOp op[kMaxEw];
-    NcoSegs segs;  // one clock serves every Shift stage: same rate, same start, same length
-};
-
-// `w`: the NCO runs that can contain sample j (nco_window of the caller's span)
-__device__ __forceinline__ float2 ew_apply(const EwProgram &P, float2 v, uint64_t j, NcoWin w) {
-    double ts = 0.0;
-    bool have_ts = false;
-#pragma unroll 1
-    for (int i = 0; i < P.n; i++) {  // uniform
-        const EwOp &o = P.op[i];
-        if (o.kind == EW_SCALE) {
-            v = make_float2(__fmul_rn(v.x, o.a), __fmul_rn(v.y, o.a));  // stream/gain.go:39-48
-        } else if (o.kind == EW_ROTATE) {
-            v = go_cmul(v, make_float2(o.a, o.b));  // stream/multiply.go:46-70
-        } else {
-            if (!have_ts) {
-                ts = nco_ts(P.segs, w, j);
-                have_ts = true;
-            }
-            double ph = __dmul_rn(o.tau_shift, ts);  // stream/shifter.go:81
-            double s, c;
-            go_sincos(ph, s, c);
-            v = go_cmul(v, make_float2((float)c, (float)s));  // :82
-        }
-    }
-    return v;
-}
-
-// The same program over W consecutive samples j0 .. j0+W-1 at once: the op loop is
-// outside, the sample loop inside and unrolled, so the W independent Sincos /
-// multiply chains interleave (instruction-level parallelism within a lane; the
-// one-sample form serialises them behind the rolled op loop).
-template <int W>
-__device__ __forceinline__ void ew_apply_n(const EwProgram &P, float2 (&v)[W], uint64_t j0, NcoWin w,
-                                           uint64_t stride = 1) {
-    double ts[W];
-    bool have_ts = false;
-#pragma unroll 1
-    for (int i = 0; i < P.n; i++) {  // uniform
-        const EwOp &o = P.op[i];
-        if (o.kind == EW_SCALE) {
-#pragma unroll
-            for (int l = 0; l < W; l++) v[l] = make_float2(__fmul_rn(v[l].x, o.a), __fmul_rn(v[l].y, o.a));
-        } else if (o.kind == EW_ROTATE) {
-#pragma unroll
-            for (int l = 0; l < W; l++) v[l] = go_cmul(v[l], make_float2(o.a, o.b));
-        } else {
-            if (!have_ts) {
-#pragma unroll
-                for (int l = 0; l < W; l++) ts[l] = nco_ts(P.segs, w, j0 + l * stride);
-                have_ts = true;
-            }
-            double s[W], c[W];
-#pragma unroll
-            for (int l = 0; l < W; l++) go_sincos(__dmul_rn(o.tau_shift, ts[l]), s[l], c[l]);
-#pragma unroll
-            for (int l = 0; l < W; l++) v[l] = go_cmul(v[l], make_float2((float)c[l], (float)s[l]));
-        }
-    }
-}
-
-// The two most common programs -- Shift, and Shift then Gain (BASELINE config 2) -- spelt
-// out, without the op loop: same operations in the same order, but straight-line code the
-// scheduler can overlap with the loads and stores around it.  SHAPE 0 = interpret.
-enum EwShape { SHAPE_ANY = 0, SHAPE_SHIFT = 1, SHAPE_SHIFT_GAIN = 2 };
-template <int W, int SHAPE>
-__device__ __forceinline__ void ew_apply_shape(const EwProgram &P, float2 (&v)[W], uint64_t j0, NcoWin w) {
-    if constexpr (SHAPE == SHAPE_ANY) {
-        ew_apply_n<W>(P, v, j0, w);
-    } else {
-        double s[W], c[W];
-#pragma unroll
-        for (int l = 0; l < W; l++) go_sincos(__dmul_rn(P.op[0].tau_shift, nco_ts(P.segs, w, j0 + l)), s[l], c[l]);
-#pragma unroll
-        for (int l = 0; l < W; l++) {
-            v[l] = go_cmul(v[l], make_float2((float)c[l], (float)s[l]));
-            if constexpr (SHAPE == SHAPE_SHIFT_GAIN)
-                v[l] = make_float2(__fmul_rn(v[l].x, P.op[1].a), __fmul_rn(v[l].y, P.op[1].a));
-        }
-    }
-}
-
-template <int FMT> struct Raw;
-template <> struct Raw<HZSDR_FMT_C64> {
-    using t = float2;
-    static __device__ __forceinline__ float2 cvt(float2 r) { return r; }
-};
-template <> struct Raw<HZSDR_FMT_U8> {
-    using t = uint16_t;
-    static __device__ __forceinline__ float2 cvt(uint16_t r) { return make_float2(u8_to_f32(r & 0xFF), u8_to_f32(r >> 8)); }
-};
-template <> struct Raw<HZSDR_FMT_I8> {
-    using t = uint16_t;
-    static __device__ __forceinline__ float2 cvt(uint16_t r) { return make_float2(i8_to_f32((int8_t)(r & 0xFF)), i8_to_f32((int8_t)(r >> 8))); }
-};
-template <> struct Raw<HZSDR_FMT_I16> {
-    using t = uint32_t;
-    static __device__ __forceinline__ float2 cvt(uint32_t r) { return make_float2(i16_to_f32((int16_t)(r & 0xFFFF)), i16_to_f32((int16_t)(r >> 16))); }
-};
-
-// sample j of the buffer after conversion and the elementwise stages
-template <int FMT>
-__device__ __forceinline__ float2 chain_sample(const void *in, const EwProgram &P, uint64_t j) {
-    using R = typename Raw<FMT>::t;
-    return ew_apply(P, Raw<FMT>::cvt(((const R *)in)[j]), j, nco_window_all(P.segs));
-}
-
-// ---- streaming terminals ---------------------------------------------------------------
-
-// TERM 0: out[j] = f(j).  W samples per lane per step (vector load / store).
-template <int FMT, int W, int SHAPE = SHAPE_ANY>
-__global__ __launch_bounds__(kThreads) void chain_map_kernel(const void *__restrict__ in,
-                                                             float2 *__restrict__ out, size_t nvec,
-                                                             uint64_t base, EwProgram P) {
-    using R = typename Raw<FMT>::t;
-    struct alignas(sizeof(R) * W) RV { R v[W]; };
-    struct alignas(8 * W) OV { float2 v[W]; };
-    // a workgroup owns a contiguous tile per trip and issues its U loads per lane
-    // back to back before the arithmetic (memory-level parallelism, see hz_nco.hip)
-    constexpr int U = W >= 4 ? 1 : 2;
-    const size_t tile = (size_t)kThreads * U;
-    for (size_t t0 = (size_t)blockIdx.x * tile; t0 < nvec; t0 += (size_t)gridDim.x * tile) {
-        const uint64_t j_lo = base + t0 * W;
-        const NcoWin w = nco_window(P.segs, j_lo, j_lo + tile * W - 1);
-        RV x[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const size_t i = t0 + (size_t)u * kThreads + threadIdx.x;
-            if (i < nvec) x[u] = ((const RV *)in)[i];
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const size_t i = t0 + (size_t)u * kThreads + threadIdx.x;
-            if (i < nvec) {
-                OV o;
-#pragma unroll
-                for (int l = 0; l < W; l++) o.v[l] = Raw<FMT>::cvt(x[u].v[l]);
-                ew_apply_shape<W, SHAPE>(P, o.v, base + i * W, w);
-                ((OV *)out)[i] = o;
-            }
-        }
-    }
-}
-
-// DecimateReader: 32 Ki-sample blocks, `per` = 32768 / factor outputs per block,
-// out[blk*per + i] = f(blk*32768 + i*factor)  (stream/decimate.go:34-101)
-template <int FMT>
-__global__ __launch_bounds__(kThreads) void chain_decimate_kernel(const void *__restrict__ in,
-                                                                  float2 *__restrict__ out,
-                                                                  size_t n_out, size_t per,
-                                                                  size_t factor, EwProgram P) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += stride) {
-        const size_t blk = o / per, i = o - blk * per;
-        out[o] = chain_sample<FMT>(in, P, blk * kReaderBlock + i * factor);
-    }
-}
-
-// DownsampleReader: boxcar over `factor` samples inside 32 Ki-sample blocks
-// (stream/downsample.go:47-127), accumulated in order from +0.
-template <int FMT>
-__global__ __launch_bounds__(kThreads) void chain_downsample_kernel(const void *__restrict__ in,
-                                                                    float2 *__restrict__ out,
-                                                                    size_t n_out, size_t per,
-                                                                    unsigned factor, EwProgram P) {
-    const float div = (float)factor;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < n_out; o += stride) {
-        const size_t blk = o / per, i = o - blk * per;
-        const size_t j0 = blk * kReaderBlock + i * factor;
-        float sr = 0.0f, si = 0.0f;
-        for (unsigned k = 0; k < factor; k++) {
-            float2 c = chain_sample<FMT>(in, P, j0 + k);
-            sr = __fadd_rn(sr, c.x);
-            si = __fadd_rn(si, c.y);
-        }
-        out[o] = make_float2(__fdiv_rn(sr, div), __fdiv_rn(si, div));
-    }
-}
-
-// ---- reference convolution: block-circular, one workgroup pass per block ----------------
-
-// out stream position g -> optional DecimateReader pick over the conv output.
-__device__ __forceinline__ void conv_store(float2 *out, size_t g, float2 v, unsigned dec, size_t per) {
-    if (dec <= 1) {
-        out[g] = v;
-    } else {
-        const size_t blk = g / kReaderBlock, i = g - blk * kReaderBlock;
-        const size_t q = i / dec;
-        if (q * dec == i && q < per) out[blk * per + q] = v;
-    }
-}
-
-// Stage N post-elementwise samples of one block into LDS in natural order with a
-// ROLLED loop (two samples per lane per trip: one 16-B LDS store, the float64
-// sincos of the Shift stage instantiated twice, not N/TPT times -- the unrolled
-// register-direct form needs 256 VGPRs and drops to one wave per SIMD).
-// FIR history for the next run = the last `off` samples of (old history ++ this
-// run): every staged position p in [n_in - off, n_in) is written to
-// new_hist[p - (n_in - off)] by whichever block stages it (blocks overlap by
-// N - hop positions; both write the same value), so no second kernel is needed.
-__device__ __forceinline__ void keep_history(float2 *new_hist, int64_t p, size_t n_in, unsigned off,
-                                             bool live, float2 a, float2 b) {
-    if (!new_hist) return;  // uniform
-    const int64_t h0 = (int64_t)n_in - (int64_t)off;
-    if (live && p >= h0 && p < (int64_t)n_in) new_hist[p - h0] = a;
-    if (live && p + 1 >= h0 && p + 1 < (int64_t)n_in) new_hist[p + 1 - h0] = b;
-}
-
-// lds[i] = sample at stream position p0 + i; positions < 0 come from `hist`
-// (`off` entries, may be null = zeros), positions >= n_in are zero.
-template <int N, int FMT>
-__device__ __forceinline__ void stage_block(float2 *lds, const void *in, const EwProgram &P, int64_t p0,
-                                            size_t n_in, const float2 *hist, unsigned off, int lane,
-                                            bool live, float2 *new_hist = nullptr) {
-    using R = typename Raw<FMT>::t;
-    constexpr int TPT = fft_tpt(N);
-    struct alignas(sizeof(R) * 2) RV { R v[2]; };
-    // pair loads need 2*sizeof(R) alignment of in + p0 (i0 is even); mod-2 arithmetic wraps safely
-    const bool vec_ok = ((((uintptr_t)in / sizeof(R)) + (uint64_t)p0) & 1) == 0;
-#pragma unroll 1
-    for (int ib = 0; ib < N; ib += TPT * 2) {
-        const int i0 = ib + lane * 2;
-        const int64_t p = p0 + i0;
-        const int64_t span_lo = p0 + ib;  // uniform: the TPT*2 samples this trip covers
-        const NcoWin w = nco_window(P.segs, span_lo < 0 ? 0 : (uint64_t)span_lo,
-                                    span_lo + TPT * 2 <= 0 ? 0 : (uint64_t)(span_lo + TPT * 2 - 1));
-        float2 a = make_float2(0.f, 0.f), b = a;
-        if (live) {
-            // ONE instantiation of the elementwise program for the pair (p, p+1):
-            // lanes whose position lies outside [0, n_in) run it on a dummy value and
-            // are overridden afterwards (history or zero), instead of a second and
-            // third inlined copy of the float64 Sincos on a divergent path.
-            const bool in0 = p >= 0 && (size_t)p < n_in, in1 = p + 1 >= 0 && (size_t)(p + 1) < n_in;
-            RV x{};
-            if (vec_ok && in0 && in1) {
-                x = *reinterpret_cast<const RV *>((const R *)in + p);
-            } else {
-                if (in0) x.v[0] = ((const R *)in)[p];
-                if (in1) x.v[1] = ((const R *)in)[p + 1];
-            }
-            float2 ab[2] = {Raw<FMT>::cvt(x.v[0]), Raw<FMT>::cvt(x.v[1])};
-            ew_apply_n<2>(P, ab, (uint64_t)p, w);  // (uint64)(-1) + 1 wraps to sample 0
-            if (in0) a = ab[0]; else if (p < 0 && hist) a = hist[p + off];
-            if (in1) b = ab[1]; else if (p + 1 < 0 && hist) b = hist[p + 1 + off];
-        }
-        keep_history(new_hist, p, n_in, off, live, a, b);
-        *reinterpret_cast<float4 *>(lds + i0) = make_float4(a.x, a.y, b.x, b.y);
-    }
-}
-
-// first-pass register image from staged LDS
-template <int N> __device__ __forceinline__ void load_edge_from_lds(FftRegs<N> &R, const float2 *lds, int lane) {
-    if constexpr (fft_odd(N)) r2_load_lds<N>(R, lds, lane); else r4_load_lds<N>(R, lds, lane);
-}
-
-// STAGED = the source needs the elementwise program (or a non-c64 format):
-// samples go through stage_block; otherwise c64 samples are loaded straight
-// into the first pass's registers.
-template <int N, int FMT, bool STAGED>
-__global__ __launch_bounds__(fft_block(N), fft_waves(N)) void conv_blocks_kernel(const void *in, float2 *out,
-                                                                   const float2 *__restrict__ filt,
-                                                                   const float2 *__restrict__ tw,
-                                                                   size_t nblocks, unsigned dec,
-                                                                   size_t per, EwProgram P) {
-    constexpr int TPT = fft_tpt(N), XPB = fft_xpb(N), CNT = N / TPT;
-    __shared__ __attribute__((aligned(16))) float2 lds_all[XPB * N];
-    const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
-    float2 *lds = lds_all + sub * N;
-    {   // one workgroup per XPB blocks, no grid-stride loop (see hz_fft.hip: LICM of twiddles)
-        const size_t b0 = (size_t)blockIdx.x * XPB;
-        const size_t b = b0 + sub;
-        const bool live = b < nblocks;
-        FftRegs<N> R;
-        __syncthreads();
-        if constexpr (STAGED) {
-            stage_block<N, FMT>(lds, in, P, (int64_t)(b * N), ~(size_t)0, nullptr, 0, lane, live);
-            __syncthreads();
-            load_edge_from_lds<N>(R, lds, lane);
-            fft_forward_regs<N, true>(R, lds, tw, lane);
-        } else {
-#pragma unroll
-            for (int q = 0; q < CNT; q++) {
-                const int idx = fft_odd(N) ? edge2_index<N>(q, lane) : edge4_index<N>(q, lane);
-                R.v[q] = live ? Raw<FMT>::cvt(((const typename Raw<FMT>::t *)in)[b * N + idx]) : make_float2(0.f, 0.f);
-            }
-            fft_forward_regs<N>(R, lds, tw, lane);
-        }
-#pragma unroll
-        for (int q = 0; q < CNT; q++)  // freq1[i] = freq1[i] * freq[i], fft/convolution.go:187-189
-            R.v[q] = go_cmul(R.v[q], filt[edge4_index<N>(q, lane)]);
-        fft_backward_regs<N>(R, lds, tw, lane);
-        if (live) {
-#pragma unroll
-            for (int q = 0; q < CNT; q++) {
-                const int idx = fft_odd(N) ? edge2_index<N>(q, lane) : edge4_index<N>(q, lane);
-                conv_store(out, b * N + idx, R.v[q], dec, per);
-            }
-        }
-    }
-}
-
-// ---- north-star FIR-decimate: overlap-save ------------------------------------------------
-
-// Block b covers input positions [b*hop - off, b*hop - off + N); positions < 0
-// come from `hist` (the last `off` post-elementwise samples of the previous
-// run), positions >= n_in are zero.  Circular outputs at idx in [off, off+hop)
-// on the decimation grid are y[(b*hop + idx - off) / D].
-// FOLD = D when the decimation folds into the spectrum (D a power of two that
-// divides the per-lane bin count): y[D i] = IFFT_{N/D}( sum_q Y[k + q N/D] )[i],
-// so the backward transform is N/D points instead of N, and the fold itself is
-// lane-local in the edge4 register image.  FOLD = 0: full backward transform,
-// outputs picked on the decimation grid.
-template <int N, int FMT, int FOLD>
-__global__ __launch_bounds__(fft_block(N), fft_waves(N)) void fir_decimate_kernel(
-    const void *in, float2 *out, const float2 *__restrict__ hist, float2 *__restrict__ new_hist,
-    const float2 *__restrict__ hfreq,
-    const float2 *__restrict__ tw, const float2 *__restrict__ tw_small, size_t nblocks, size_t n_in,
-    unsigned hop, unsigned off, unsigned D, EwProgram P) {
-    constexpr int TPT = fft_tpt(N), CNT = N / TPT;
-    static_assert(fft_xpb(N) == 1, "fir_decimate_kernel: one block per workgroup");
-    __shared__ __attribute__((aligned(16))) float2 lds[N];
-    const int lane = threadIdx.x;
-    {   // one workgroup per overlap-save block (no grid-stride loop: see hz_fft.hip)
-        const size_t b = blockIdx.x;
-        FftRegs<N> R;
-        __syncthreads();
-        stage_block<N, FMT>(lds, in, P, (int64_t)(b * hop) - (int64_t)off, n_in, hist, off, lane, true, new_hist);
-        __syncthreads();
-        load_edge_from_lds<N>(R, lds, lane);
-        fft_forward_regs<N, true>(R, lds, tw, lane);
-#pragma unroll
-        for (int q = 0; q < CNT; q++) R.v[q] = cmulf(R.v[q], hfreq[edge4_index<N>(q, lane)]);
-        if constexpr (FOLD == 0) {
-            fft_backward_regs<N>(R, lds, tw, lane);
-#pragma unroll
-            for (int q = 0; q < CNT; q++) {
-                const unsigned idx = fft_odd(N) ? edge2_index<N>(q, lane) : edge4_index<N>(q, lane);
-                if (idx >= off && idx < off + hop && ((idx - off) % D) == 0) {
-                    const size_t p = b * hop + (idx - off);
-                    if (p < n_in) out[p / D] = R.v[q];
-                }
-            }
-        } else {
-            constexpr int M = N / FOLD, S = CNT / FOLD, TPTM = fft_tpt(M), CNTM = M / TPTM;
-            static_assert(S >= 1 && M >= 4, "fold geometry");
-            // register slot q holds bin lane + TPT*m(q), m(q) = (q>>2) + (q&3)*(CNT/4);
-            // folded bin lane + TPT*s collects every m with m % S == s
-            float2 z[S];
-#pragma unroll
-            for (int s2 = 0; s2 < S; s2++) z[s2] = make_float2(0.f, 0.f);
-#pragma unroll
-            for (int q = 0; q < CNT; q++) {
-                constexpr int B4 = CNT / 4;
-                const int m = (q >> 2) + (q & 3) * B4;
-                z[m % S] = cadd(z[m % S], R.v[q]);
-            }
-            __syncthreads();  // forward's last-pass LDS reads are done
-#pragma unroll
-            for (int s2 = 0; s2 < S; s2++) lds[lane + TPT * s2] = z[s2];
-            __syncthreads();
-            const int g = lane / TPTM, l2 = lane % TPTM;
-            FftRegs<M> Q;
-#pragma unroll
-            for (int q = 0; q < CNTM; q++) Q.v[q] = lds[edge4_index<M>(q, l2)];
-            fft_backward_regs<M>(Q, lds + g * M, tw_small, l2);  // groups > 0 redo it in their own region
-            if (g == 0) {
-                const unsigned i_lo = off / FOLD, i_hi = (off + hop) / FOLD;
-#pragma unroll
-                for (int q = 0; q < CNTM; q++) {
-                    const unsigned i = fft_odd(M) ? edge2_index<M>(q, l2) : edge4_index<M>(q, l2);
-                    if (i >= i_lo && i < i_hi) {
-                        const size_t m_out = b * (hop / FOLD) + (i - i_lo);
-                        if (m_out * FOLD < n_in) out[m_out] = Q.v[q];
-                    }
-                }
-            }
-        }
-    }
-}
-
-// ==== the same two kernels on the radix-16 core (hz_fft16.h), N = 256 .. 4096 ================
-
-// stage_block for the padded LDS image of the radix-16 core
-template <int N, int FMT>
-__device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const EwProgram &P, int64_t p0,
-                                              size_t n_in, const float2 *hist, unsigned off, int lane,
-                                              bool live, float2 *new_hist = nullptr) {
-    using R = typename Raw<FMT>::t;
-    constexpr int TPT = f16::tpt(N), STEP = TPT * 2;
-    struct alignas(sizeof(R) * 2) RV { R v[2]; };
-    const bool vec_ok = ((((uintptr_t)in / sizeof(R)) + (uint64_t)p0) & 1) == 0;
-    // raw pair at block offset ib (zeros outside [0, n_in)): the only memory access of a trip
-    auto load_raw = [&](int ib) {
-        RV x{};
-        const int64_t p = p0 + ib + lane * 2;
-        if (live && ib < N) {
-            const bool in0 = p >= 0 && (size_t)p < n_in, in1 = p + 1 >= 0 && (size_t)(p + 1) < n_in;
-            if (vec_ok && in0 && in1) {
-                x = *reinterpret_cast<const RV *>((const R *)in + p);
-            } else {
-                if (in0) x.v[0] = ((const R *)in)[p];
-                if (in1) x.v[1] = ((const R *)in)[p + 1];
-            }
-        }
-        return x;
-    };
-    // Software prefetch two trips ahead (named registers, no indexed array): the
-    // ~1-2 us HBM/L2 latency of a trip's load hides behind the ~600-cycle Sincos work
-    // of the two trips before it instead of being paid eight times per block.
-    RV x0 = load_raw(0), x1 = load_raw(STEP);
-#pragma unroll 1
-    for (int ib = 0; ib < N; ib += STEP) {
-        const RV x = x0;
-        x0 = x1;
-        x1 = load_raw(ib + 2 * STEP);
-        const int i0 = ib + lane * 2;
-        const int64_t p = p0 + i0;
-        const int64_t span_lo = p0 + ib;  // uniform: the STEP samples this trip covers
-        const NcoWin w = nco_window(P.segs, span_lo < 0 ? 0 : (uint64_t)span_lo,
-                                    span_lo + STEP <= 0 ? 0 : (uint64_t)(span_lo + STEP - 1));
-        float2 a = make_float2(0.f, 0.f), b = a;
-        if (live) {
-            // ONE instantiation of the elementwise program for the pair (p, p+1):
-            // lanes whose position lies outside [0, n_in) run it on a dummy value and
-            // are overridden afterwards (history or zero), instead of a second and
-            // third inlined copy of the float64 Sincos on a divergent path.
-            const bool in0 = p >= 0 && (size_t)p < n_in, in1 = p + 1 >= 0 && (size_t)(p + 1) < n_in;
-            float2 ab[2] = {Raw<FMT>::cvt(x.v[0]), Raw<FMT>::cvt(x.v[1])};
-            ew_apply_n<2>(P, ab, (uint64_t)p, w);  // (uint64)(-1) + 1 wraps to sample 0
-            if (in0) a = ab[0]; else if (p < 0 && hist) a = hist[p + off];
-            if (in1) b = ab[1]; else if (p + 1 < 0 && hist) b = hist[p + 1 + off];
-        }
-        keep_history(new_hist, p, n_in, off, live, a, b);
-        const int q = f16::pad(i0);  // i0 even: i0 and i0+1 share a 16-element row
-        lds[q] = a;
-        lds[q + 1] = b;
-    }
-}
-
-template <int N, int FMT, bool STAGED>
-__global__ __launch_bounds__(f16::block(N), 4) void conv_blocks_kernel16(const void *in, float2 *out,
-                                                                      const float2 *__restrict__ filt,
-                                                                      const float2 *__restrict__ tw,
-                                                                      size_t nblocks, unsigned dec,
-                                                                      size_t per, EwProgram P) {
-    constexpr int TPT = f16::tpt(N), XPB = f16::xpb(N), R0 = f16::first_radix(N);
-    __shared__ float2 lds_all[XPB * f16::lds_elems(N)];
-    const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
-    float2 *lds = lds_all + sub * f16::lds_elems(N);
-    const size_t b = (size_t)blockIdx.x * XPB + sub;
-    const bool live = b < nblocks;
-    float2 v[16];
-    if constexpr (STAGED) {
-        stage_block16<N, FMT>(lds, in, P, (int64_t)(b * N), ~(size_t)0, nullptr, 0, lane, live);
-        __syncthreads();
-        f16::load_lds<N, R0>(v, lds, lane);
-        f16::forward<N, true>(v, lds, tw, lane);
-    } else {
-#pragma unroll
-        for (int q = 0; q < 16; q++)
-            v[q] = live ? Raw<FMT>::cvt(((const typename Raw<FMT>::t *)in)[b * N + f16::edge_index<N, R0>(q, lane)])
-                        : make_float2(0.f, 0.f);
-        f16::forward<N>(v, lds, tw, lane);
-    }
-#pragma unroll
-    for (int q = 0; q < 16; q++)  // freq1[i] = freq1[i] * freq[i], fft/convolution.go:187-189
-        v[q] = go_cmul(v[q], filt[f16::edge_index<N, 16>(q, lane)]);
-    f16::backward<N>(v, lds, tw, lane);
-    if (live) {
-#pragma unroll
-        for (int q = 0; q < 16; q++) conv_store(out, b * N + f16::edge_index<N, R0>(q, lane), v[q], dec, per);
-    }
-}
-
-// FOLD = D (power of two <= 16 with N/D >= 256): lane-local spectral fold to M = N/D
-// bins; the M-point inverse runs in fir_synth_kernel16.  (One kernel did both at first:
-// the inverse kept one group of M/16 lanes busy and parked the rest of the workgroup,
-// and cost as much as the whole forward transform -- 33 of 98 us.)  FOLD = 0: full
-// backward transform + pick, in this kernel.
-//
-// LATE: the mixer commutes with the filter.  Inside one exactly-linear run of the NCO
-// clock ts[n-k] = ts[n] - k*step, so with every elementwise stage a multiplication by a
-// complex scalar (Gain, Multiply) or by exp(i*tau_s*ts[n]) (Shift),
-//     sum_k h[k] * ew(x, n-k)  =  ew( sum_k (h[k] * exp(-i*Omega*k*step)) * x[n-k], n ),
-// Omega = sum of the Shift stages' tau_s: filter the CONVERTED samples with the run's
-// modulated taps (late.h[run], prepared by the host per distinct step) and run the
-// unchanged elementwise program on the hop/D outputs instead of the N inputs -- the
-// float64 Sincos at the decimated rate.  A block takes this path only when its whole
-// input span lies in one run, inside [0, n_in - off) (no history read or written);
-// every other block -- the first, the last, any block across a run boundary or a
-// 2*pi wrap of the clock -- mixes in reference order before the filter, as before.
-struct LateFilters {
-    const float2 *h[kNcoMaxSegs];
-};
-
-// POLYPHASE form of the folded analysis (N = 4096, D in {2, 4, 8, 16}).  The fold sums the
-// D aliases of every output bin, sum_q H[k + M q] X[k + M q] (M = N/D).  Writing the
-// N-point transform by its first decimation-in-time stage, X[k] = sum_r W_N^(r k) U_r[k mod M]
-// with U_r the M-point transform of branch u_r[m] = x[D m + r], the aliases collapse:
-//     Z[k] = sum_r G_r[k] U_r[k],   G_r = FFT_M(g_r) / M,   g_r[j] = h[D j - r]
-// -- D transforms of M points and one multiply-accumulate, no N-point last pass.  Lane p of
-// the workgroup is lane p / D of branch p % D, which makes the first pass (radix 16 over
-// x[p + 256 q]) the very loads and butterflies of the N-point form; the second radix-16 pass
-// stays inside a branch; the last pass of the M-point transforms is radix 16/D at Ns = 256,
-// so lane p can run it for ALL D branches at bins p + 256 i (D * 16/D = 16 values), multiply
-// by the D filter spectra and add up: 24 complex multiplies and 30 adds where the N-point
-// form spent a twiddled radix-16 butterfly, 16 multiplies and the fold (~ 10 % fewer vector
-// instructions per block).  `hfreq` and `late.h[]` hold G[r][k] (D x M) for these chains.
-// (N = 2048 and 1024 -- 128 and 64 lanes -- work the same way with a second pass of radix
-// N/256 = 8 or 4 and the fused last pass at Ns = N/16.)
-constexpr bool fold_poly(int n, int fold) {
-    return (n == 4096 || n == 2048 || n == 1024) && (fold == 2 || fold == 4 || fold == 8 || fold == 16) &&
-           n / fold >= 256;
-}
-
-// the FFT sizes whose blocks can mix late (one overlap-save block per workgroup)
-constexpr bool late_capable(unsigned nfft) { return nfft >= 1024 && nfft <= 4096; }
-
-// workgroup-uniform: does block b (input span [p0, p0 + N)) take the late-mixer path?
-__device__ __forceinline__ bool late_block(const EwProgram &P, const LateFilters &late, int64_t p0, int N,
-                                           unsigned off, size_t n_in, NcoWin *run) {
-    *run = NcoWin{0, 0};
-    if (p0 < 0 || (uint64_t)p0 + (uint64_t)N + off > n_in) return false;
-    *run = nco_window(P.segs, (uint64_t)p0, (uint64_t)p0 + N - 1);
-    return run->lo == run->hi && late.h[run->lo] != nullptr;
-}
-
-template <int N, int FMT, int FOLD, bool LATE>
-__global__ __launch_bounds__(f16::block(N), LATE ? (FOLD != 0 ? 4 : 3) : 1) void fir_decimate_kernel16(
-    const void *in, float2 *out, const float2 *__restrict__ hist, float2 *__restrict__ new_hist,
-    const float2 *__restrict__ hfreq,
-    const float2 *__restrict__ tw, float2 *__restrict__ spec, size_t nblocks, size_t n_in,
-    unsigned hop, unsigned off, unsigned D, EwProgram P, LateFilters late,
-    const float2 *__restrict__ tw_sub) {
-    constexpr int R0 = f16::first_radix(N), TPT = f16::tpt(N);
-    static_assert(f16::xpb(N) == 1 || FOLD == 0, "fold path assumes one block per workgroup");
-    static_assert(!LATE || f16::xpb(N) == 1, "the late mixer assumes one block per workgroup");
-    // (+32: the polyphase form shifts each branch's region by 32/D elements, see below)
-    __shared__ float2 lds_all[f16::xpb(N) * f16::lds_elems(N) + 32];
-    const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
-    float2 *lds = lds_all + sub * f16::lds_elems(N);
-    size_t b = (size_t)blockIdx.x * f16::xpb(N) + sub;
-    if constexpr (LATE) {
-        // the stream's last two blocks mix in reference order (several times the work of a
-        // late block): dispatched last they would be the kernel's tail, so they go first
-        static_assert(f16::xpb(N) == 1, "block rotation assumes one block per workgroup");
-        if (nblocks > 2) b = b < 2 ? nblocks - 2 + b : b - 2;
-    }
-    const bool live = b < nblocks;
-    const int64_t p0 = (int64_t)(b * hop) - (int64_t)off;
-    bool mix_late = false;  // workgroup-uniform
-    NcoWin run{0, 0};
-    if constexpr (LATE) mix_late = late_block(P, late, p0, N, off, n_in, &run);
-    const float2 *__restrict__ hf = mix_late ? late.h[run.lo] : hfreq;
-    float2 v[16];
-    const bool direct = LATE && mix_late;  // workgroup-uniform
-    // register image of the first pass: radix-16 edge for the polyphase form, the N-point
-    // plan's first radix otherwise
-    constexpr int RIN = fold_poly(N, FOLD) ? 16 : R0;
-    if (direct) {
-        // a late block lies wholly inside the buffer and needs no arithmetic per input
-        // sample: its samples go from global memory straight into the first pass's
-        // register image (a wave reads 64 consecutive samples per load), no LDS staging
-        using R = typename Raw<FMT>::t;
-        const R *src = (const R *)in + p0;
-        R raw[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) raw[q] = src[f16::edge_index<N, RIN>(q, lane)];
-#pragma unroll
-        for (int q = 0; q < 16; q++) v[q] = Raw<FMT>::cvt(raw[q]);
-    } else {
-        stage_block16<N, FMT>(lds, in, P, p0, n_in, hist, off, lane, live, new_hist);
-        __syncthreads();
-        f16::load_lds<N, RIN>(v, lds, lane);
-    }
-    if constexpr (fold_poly(N, FOLD)) {
-        // branch regions 32/D elements apart in bank space: neighbouring lanes belong to
-        // different branches, and the regions' natural size is a multiple of all 64 banks
-        constexpr int M = N / FOLD, RL = 16 / FOLD, R2 = N / 256, LE = f16::lds_elems(M) + 32 / FOLD;
-        static_assert(FOLD * LE == f16::lds_elems(N) + 32 && FOLD * (M / 16) == TPT && R2 * 256 == N,
-                      "polyphase geometry");
-        const int br = lane % FOLD, bl = lane / FOLD;  // branch, lane inside the branch
-        float2 *ldb = lds + br * LE;
-        // pass 1 of every branch: radix 16 at Ns = 1 over u_r[bl + (M/16) q] = x[lane + TPT q]
-        f16::butterflies<16, false>(v);
-        if (!direct) __syncthreads();  // the staged block has been read by everybody
-        f16::store_lds<M, 16>(v, ldb, bl, 1);
-        {  // pass 2: radix N/256 at Ns = 16, inside the branch
-            f16::TwRegs<R2> t;
-            f16::twiddle_load<M, R2>(t, tw_sub, bl, 16);
-            __syncthreads();
-            f16::load_lds<M, R2>(v, ldb, bl);
-            f16::twiddle_apply<M, R2, false>(v, t);
-            f16::butterflies<R2, false>(v);
-            __syncthreads();
-            f16::store_lds<M, R2>(v, ldb, bl, 16);
-        }
-        // last pass (radix RL at Ns = N/16) of ALL branches at bins lane + TPT i, times the
-        // branch's filter spectrum, summed over the branches
-        float2 wl[RL > 1 ? RL - 1 : 1];
-#pragma unroll
-        for (int i = 1; i < RL; i++) wl[i - 1] = tw_sub[i * lane];
-        __syncthreads();
-        float2 z[RL];
-#pragma unroll
-        for (int i = 0; i < RL; i++) z[i] = make_float2(0.f, 0.f);
-#pragma unroll
-        for (int r2 = 0; r2 < FOLD; r2++) {
-            float2 u[RL];
-#pragma unroll
-            for (int i = 0; i < RL; i++) u[i] = lds[r2 * LE + f16::pad(lane + TPT * i)];
-#pragma unroll
-            for (int i = 1; i < RL; i++) u[i] = f16::cmul(u[i], wl[i - 1]);
-            if constexpr (RL > 1) f16::dft<RL, false>(u);
-#pragma unroll
-            for (int i = 0; i < RL; i++) z[i] = f16::cadd(z[i], f16::cmul(u[i], hf[r2 * M + lane + TPT * i]));
-        }
-        if (live) {
-#pragma unroll
-            for (int i = 0; i < RL; i++) spec[b * M + lane + TPT * i] = z[i];
-        }
-        return;
-    }
-    if (direct) f16::forward<N>(v, lds, tw, lane);
-    else f16::forward<N, true>(v, lds, tw, lane);
-#pragma unroll
-    for (int q = 0; q < 16; q++) v[q] = f16::cmul(v[q], hf[f16::edge_index<N, 16>(q, lane)]);
-    if constexpr (FOLD == 0) {
-        f16::backward<N>(v, lds, tw, lane);
-        if (!direct) {
-            if (live) {
-#pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const unsigned idx = f16::edge_index<N, R0>(q, lane);
-                    if (idx >= off && idx < off + hop && ((idx - off) % D) == 0) {
-                        const size_t p = b * hop + (idx - off);
-                        if (p < n_in) out[p / D] = v[q];
-                    }
-                }
-            }
-        } else if constexpr (LATE) {
-            // late block: the filtered block back to LDS, then the elementwise program over
-            // the hop/D kept outputs (output t of the block sits at stream position b*hop + t*D)
-            __syncthreads();  // the backward transform's last-pass reads are done
-#pragma unroll
-            for (int q = 0; q < 16; q++) lds[f16::pad(f16::edge_index<N, R0>(q, lane))] = v[q];
-            __syncthreads();
-            const unsigned per = hop / D;
-            constexpr int W = 4;
-#pragma unroll 1
-            for (unsigned t0 = lane; t0 < per; t0 += W * TPT) {
-                float2 y[W];
-#pragma unroll
-                for (int l = 0; l < W; l++) {
-                    const unsigned tt = t0 + l * TPT < per ? t0 + l * TPT : t0;
-                    y[l] = lds[f16::pad(off + tt * D)];
-                }
-                ew_apply_n<W>(P, y, (uint64_t)b * hop + (uint64_t)t0 * D, run, (uint64_t)TPT * D);
-#pragma unroll
-                for (int l = 0; l < W; l++)
-                    if (t0 + l * TPT < per) out[b * per + t0 + l * TPT] = y[l];
-            }
-        }
-    } else {
-        constexpr int M = N / FOLD, S = 16 / FOLD;
-        static_assert(f16::ok(M) && S >= 1, "fold geometry");
-        // slot q holds bin lane + q*TPT; folded bin lane + s*TPT sums the slots with q % S == s
-        float2 z[S];
-#pragma unroll
-        for (int s2 = 0; s2 < S; s2++) z[s2] = v[s2];
-#pragma unroll
-        for (int q = S; q < 16; q++) z[q % S] = f16::cadd(z[q % S], v[q]);
-        if (live) {
-#pragma unroll
-            for (int s2 = 0; s2 < S; s2++) spec[b * M + lane + TPT * s2] = z[s2];
-        }
-    }
-}
-
-// The other half of the folded FIR-decimate: the M-point inverse of every block's folded
-// spectrum -- M/16 lanes per block, 256 / (M/16) blocks per workgroup, every lane busy --
-// then, for blocks on the late-mixer path, the elementwise program over the hop/D
-// outputs (output m sits at stream position D*m).
-template <int N, int FOLD> struct SynthGeom {
-    static constexpr int M = N / FOLD, TPTM = f16::tpt(M);
-    static constexpr int BS = TPTM > 64 ? TPTM : 64;  // one wave where a block's group fits in it:
-    static constexpr int XPB = BS / TPTM;              // many small workgroups, all resident at once
-};
-
-template <int N, int FOLD, bool LATE>
-__global__ __launch_bounds__((SynthGeom<N, FOLD>::BS)) void fir_synth_kernel16(
-    const float2 *__restrict__ spec, float2 *out, const float2 *__restrict__ tw_small, size_t nblocks,
-    size_t n_in, unsigned hop, unsigned off, EwProgram P, LateFilters late) {
-    using G = SynthGeom<N, FOLD>;
-    constexpr int M = G::M, TPTM = G::TPTM, RM = f16::first_radix(M), XPB = G::XPB;
-    static_assert(f16::ok(M) && XPB >= 1, "synthesis geometry");
-    __shared__ float2 lds_all[XPB * f16::lds_elems(M)];
-    const int sub = threadIdx.x / TPTM, l2 = threadIdx.x % TPTM;
-    float2 *lds = lds_all + sub * f16::lds_elems(M);
-    const size_t b = (size_t)blockIdx.x * XPB + sub;
-    const bool live = b < nblocks;
-    float2 w[16];
-#pragma unroll
-    for (int q = 0; q < 16; q++)
-        w[q] = live ? spec[b * M + f16::edge_index<M, 16>(q, l2)] : make_float2(0.f, 0.f);
-    f16::backward<M>(w, lds, tw_small, l2);
-    const unsigned i_lo = off / FOLD, i_hi = (off + hop) / FOLD, per = hop / FOLD;
-    bool mix_late = false;  // uniform per block (= per group of TPTM lanes)
-    NcoWin run{0, 0};
-    if constexpr (LATE) mix_late = live && late_block(P, late, (int64_t)(b * hop) - (int64_t)off, N, off, n_in, &run);
-    if (live && !mix_late) {
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const unsigned i = f16::edge_index<M, RM>(q, l2);
-            if (i >= i_lo && i < i_hi) {
-                const size_t m_out = b * per + (i - i_lo);
-                if (m_out * FOLD < n_in) out[m_out] = w[q];
-            }
-        }
-    }
-    if constexpr (LATE) {
-        __syncthreads();  // every group's last-pass reads are done: its region can take the outputs
-        if (mix_late) {
-#pragma unroll
-            for (int q = 0; q < 16; q++) lds[f16::edge_index<M, RM>(q, l2)] = w[q];
-        }
-        __syncthreads();
-        if (mix_late) {
-            // four outputs per lane per trip: four independent Sincos chains in flight
-            constexpr int W = 4;
-#pragma unroll 1
-            for (unsigned t0 = l2; t0 < per; t0 += W * TPTM) {
-                float2 y[W];
-#pragma unroll
-                for (int l = 0; l < W; l++) y[l] = lds[i_lo + (t0 + l * TPTM < per ? t0 + l * TPTM : t0)];
-                ew_apply_n<W>(P, y, (uint64_t)b * hop + (uint64_t)t0 * FOLD, run, (uint64_t)TPTM * FOLD);
-#pragma unroll
-                for (int l = 0; l < W; l++)
-                    if (t0 + l * TPTM < per) out[b * per + t0 + l * TPTM] = y[l];
-            }
-        }
-    }
-}
-
-__global__ void scale_c64_kernel(float2 *buf, size_t n, float r) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        buf[i] = make_float2(buf[i].x * r, buf[i].y * r);
-}
-
-}  // namespace hz
 
 // =============================================================================
 
@@ -818,7 +49,7 @@ struct hzsdr_chain {
     unsigned nfft = 0, hop = 0, off = 0;
     // late mixer (see fir_decimate_kernel16): the taps, and FFT(taps * exp(-i*Omega*k*step))/N
     // per distinct clock step seen so far (one per binade of the NCO clock)
-    std::vector<float> taps_host;
+    std::vector<double> taps_host;  // (re, im) pairs, exact copies of the caller's float32 taps
     std::map<uint64_t, void *> late_cache;
     bool mix_in_order = false;
     bool poly = false;  // hfreq / late_cache hold the polyphase layout (fold_poly)
@@ -835,20 +66,35 @@ struct hzsdr_conv {
 
 namespace hz {
 
+// Launch with `lds` bytes of dynamic LDS; above the 64 KiB default a kernel needs its limit
+// raised once (160 KiB per CU on gfx950).
+template <class K, class... A>
+static void launch_fv(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, A... args) {
+    if (lds > 48 * 1024) {
+        static bool raised = false;  // one flag per kernel instantiation (K, A... are its types)
+        if (!raised) {
+            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
+}
+
 template <int N, int FMT>
 static void launch_conv_n(hzsdr_ctx *ctx, const void *in, void *out, const void *filt, const float2 *tw,
-                          size_t nblocks, unsigned dec, size_t per, const EwProgram &P) {
+                          const FvTabs &tabs, size_t nblocks, unsigned dec, size_t per, const EwProgram &P) {
     const bool direct = FMT == HZSDR_FMT_C64 && P.n == 0;
-    if constexpr (f16::ok(N)) {  // radix-16 core
-        constexpr int XPB = f16::xpb(N);
-        const dim3 grid((unsigned)((nblocks + XPB - 1) / XPB)), block(f16::block(N));
+    if constexpr (fv::ok(N)) {  // packed-math core
+        constexpr int XPB = fv::xpb(N);
+        const dim3 grid((unsigned)((nblocks + XPB - 1) / XPB)), block(fv::block(N));
+        const size_t lds = (size_t)XPB * fv::lds_elems(N) * sizeof(cf);
         if (direct)
-            hipLaunchKernelGGL((conv_blocks_kernel16<N, FMT, false>), grid, block, 0, ctx->stream, in,
-                               (float2 *)out, (const float2 *)filt, tw, nblocks, dec, per, P);
+            launch_fv(conv_blocks_kernel16<N, FMT, false>, grid, block, lds, ctx->stream, in, (float2 *)out,
+                      (const float2 *)filt, tabs, nblocks, dec, per, P);
         else
-            hipLaunchKernelGGL((conv_blocks_kernel16<N, FMT, true>), grid, block, 0, ctx->stream, in,
-                               (float2 *)out, (const float2 *)filt, tw, nblocks, dec, per, P);
-    } else {  // radix-4 core: N < 256 and N = 8192
+            launch_fv(conv_blocks_kernel16<N, FMT, true>, grid, block, lds, ctx->stream, in, (float2 *)out,
+                      (const float2 *)filt, tabs, nblocks, dec, per, P);
+    } else {  // radix-4 core: N < 256
         constexpr int XPB = fft_xpb(N);
         const dim3 grid((unsigned)((nblocks + XPB - 1) / XPB)), block(fft_block(N));
         if (direct)
@@ -862,20 +108,21 @@ static void launch_conv_n(hzsdr_ctx *ctx, const void *in, void *out, const void 
 
 template <int FMT>
 static int launch_conv_fmt(hzsdr_ctx *ctx, size_t n, const void *in, void *out, const void *filt,
-                           const float2 *tw, size_t nblocks, unsigned dec, size_t per, const EwProgram &P) {
+                           const float2 *tw, const FvTabs &tabs, size_t nblocks, unsigned dec, size_t per,
+                           const EwProgram &P) {
     switch (n) {
-    case 4: launch_conv_n<4, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
-    case 8: launch_conv_n<8, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
-    case 16: launch_conv_n<16, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
-    case 32: launch_conv_n<32, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
-    case 64: launch_conv_n<64, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
-    case 128: launch_conv_n<128, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
-    case 256: launch_conv_n<256, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
-    case 512: launch_conv_n<512, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
-    case 1024: launch_conv_n<1024, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
-    case 2048: launch_conv_n<2048, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
-    case 4096: launch_conv_n<4096, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
-    case 8192: launch_conv_n<8192, FMT>(ctx, in, out, filt, tw, nblocks, dec, per, P); break;
+    case 4: launch_conv_n<4, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
+    case 8: launch_conv_n<8, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
+    case 16: launch_conv_n<16, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
+    case 32: launch_conv_n<32, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
+    case 64: launch_conv_n<64, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
+    case 128: launch_conv_n<128, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
+    case 256: launch_conv_n<256, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
+    case 512: launch_conv_n<512, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
+    case 1024: launch_conv_n<1024, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
+    case 2048: launch_conv_n<2048, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
+    case 4096: launch_conv_n<4096, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
+    case 8192: launch_conv_n<8192, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
     default: return HZSDR_ERR_INVALID_ARGUMENT;
     }
     return HZSDR_OK;
@@ -887,13 +134,15 @@ static int conv_blocks_device(hzsdr_ctx *ctx, int fmt, size_t n, const void *in,
                               const void *filt, size_t nblocks, unsigned dec, size_t per,
                               const EwProgram &P) {
     if (nblocks == 0) return HZSDR_OK;
-    const float2 *tw;
-    HZ_TRY(get_twiddles(ctx, n, &tw));
+    const float2 *tw = nullptr;
+    FvTabs tabs{};
+    if (fv::ok((int)n)) HZ_TRY(get_fv_tables(ctx, n, &tabs));
+    else HZ_TRY(get_twiddles(ctx, n, &tw));
     switch (fmt) {
-    case HZSDR_FMT_C64: return launch_conv_fmt<HZSDR_FMT_C64>(ctx, n, in, out, filt, tw, nblocks, dec, per, P);
-    case HZSDR_FMT_U8: return launch_conv_fmt<HZSDR_FMT_U8>(ctx, n, in, out, filt, tw, nblocks, dec, per, P);
-    case HZSDR_FMT_I8: return launch_conv_fmt<HZSDR_FMT_I8>(ctx, n, in, out, filt, tw, nblocks, dec, per, P);
-    default: return launch_conv_fmt<HZSDR_FMT_I16>(ctx, n, in, out, filt, tw, nblocks, dec, per, P);
+    case HZSDR_FMT_C64: return launch_conv_fmt<HZSDR_FMT_C64>(ctx, n, in, out, filt, tw, tabs, nblocks, dec, per, P);
+    case HZSDR_FMT_U8: return launch_conv_fmt<HZSDR_FMT_U8>(ctx, n, in, out, filt, tw, tabs, nblocks, dec, per, P);
+    case HZSDR_FMT_I8: return launch_conv_fmt<HZSDR_FMT_I8>(ctx, n, in, out, filt, tw, tabs, nblocks, dec, per, P);
+    default: return launch_conv_fmt<HZSDR_FMT_I16>(ctx, n, in, out, filt, tw, tabs, nblocks, dec, per, P);
     }
 }
 
@@ -950,13 +199,45 @@ static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, cons
                            (uint64_t)done, P);
 }
 
+// In-place radix-2 transform in float64 (host): the filter spectra are computed once per
+// chain (and once per clock binade for the late mixer), so they are formed in double
+// precision and rounded to float32 ONCE -- a float32 transform of the taps would put its
+// own ~1e-7 relative error, the same in every block, into every output.
+static void host_fft(std::vector<double> &re, std::vector<double> &im, size_t off, size_t n) {
+    for (size_t i = 1, j = 0; i < n; i++) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) {
+            std::swap(re[off + i], re[off + j]);
+            std::swap(im[off + i], im[off + j]);
+        }
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const size_t half = len / 2;
+        for (size_t k = 0; k < half; k++) {
+            const double a = -2.0 * M_PI * (double)k / (double)len, wr = cos(a), wi = sin(a);
+            for (size_t i = k; i < n; i += len) {
+                const size_t u = off + i, v = off + i + half;
+                const double tr = re[v] * wr - im[v] * wi, ti = re[v] * wi + im[v] * wr;
+                re[v] = re[u] - tr;
+                im[v] = im[u] - ti;
+                re[u] += tr;
+                im[u] += ti;
+            }
+        }
+    }
+}
+
 // The taps' spectrum in the layout the analysis kernel multiplies by: H[k] = FFT_N(h)[k] / N,
 // or, for the polyphase form, G[r][k] = FFT_M(g_r)[k] / M with g_r[j] = h[D j - r] (see
-// fold_poly).  `taps`: ntaps complex64 in host memory; `dst`: N complex64 of device memory.
-static int filter_spectrum(hzsdr_chain *c, const float *taps, void *dst) {
+// fold_poly).  `taps`: ntaps complex values (real, imaginary) in host memory, float64;
+// `dst`: N complex64 of device memory.  Uploaded through the context's stream; returns
+// after the copy has completed (the staging vector is local).
+static int filter_spectrum(hzsdr_chain *c, const double *taps, void *dst) {
     hzsdr_ctx *ctx = c->ctx;
     const unsigned nfft = c->nfft;
-    std::vector<float> padded(2 * (size_t)nfft, 0.0f);
+    std::vector<double> re(nfft, 0.0), im(nfft, 0.0);
     size_t len = nfft, batch = 1;
     if (c->poly) {
         const unsigned F = c->factor, M = nfft / F;
@@ -964,20 +245,26 @@ static int filter_spectrum(hzsdr_chain *c, const float *taps, void *dst) {
             for (unsigned j = 0; j < M; j++) {
                 const long idx = (long)F * j - (long)r;
                 if (idx < 0 || (size_t)idx >= c->ntaps) continue;
-                padded[2 * ((size_t)r * M + j)] = taps[2 * idx];
-                padded[2 * ((size_t)r * M + j) + 1] = taps[2 * idx + 1];
+                re[(size_t)r * M + j] = taps[2 * idx];
+                im[(size_t)r * M + j] = taps[2 * idx + 1];
             }
         len = M;
         batch = F;
     } else {
-        memcpy(padded.data(), taps, c->ntaps * 8);
+        for (size_t k = 0; k < c->ntaps; k++) {
+            re[k] = taps[2 * k];
+            im[k] = taps[2 * k + 1];
+        }
     }
-    HZ_TRY(ensure_slot(ctx, 8, (size_t)nfft * 8));
-    HZ_HIP(ctx, hipMemcpyAsync(ctx->slots[8].ptr, padded.data(), (size_t)nfft * 8, hipMemcpyHostToDevice, ctx->stream));
-    HZ_TRY(fft_device(ctx, ctx->slots[8].ptr, dst, len, batch, true));
-    hipLaunchKernelGGL(scale_c64_kernel, dim3(blocks_for(ctx, nfft)), dim3(kThreads), 0, ctx->stream,
-                       (float2 *)dst, (size_t)nfft, 1.0f / (float)len);
-    HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `padded` and slot 8 are reused
+    for (size_t t = 0; t < batch; t++) host_fft(re, im, t * len, len);
+    std::vector<float> h(2 * (size_t)nfft);
+    const double scale = 1.0 / (double)len;
+    for (size_t i = 0; i < nfft; i++) {
+        h[2 * i] = (float)(re[i] * scale);
+        h[2 * i + 1] = (float)(im[i] * scale);
+    }
+    HZ_HIP(ctx, hipMemcpyAsync(dst, h.data(), (size_t)nfft * 8, hipMemcpyHostToDevice, ctx->stream));
+    HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HZSDR_OK;
 }
 
@@ -998,13 +285,13 @@ static int late_filter_for(hzsdr_chain *c, double step, double omega, void **dev
         return HZSDR_OK;
     }
     if (!make || c->late_cache.size() >= kLateCacheMax) return HZSDR_OK;  // that run mixes in reference order
-    std::vector<float> mod(2 * c->ntaps);
+    std::vector<double> mod(2 * c->ntaps);
     for (size_t k = 0; k < c->ntaps; k++) {
         const double ph = -omega * ((double)k * step);
         const double cr = cos(ph), ci = sin(ph);
         const double hr = c->taps_host[2 * k], hi = c->taps_host[2 * k + 1];
-        mod[2 * k] = (float)(hr * cr - hi * ci);
-        mod[2 * k + 1] = (float)(hr * ci + hi * cr);
+        mod[2 * k] = hr * cr - hi * ci;
+        mod[2 * k + 1] = hr * ci + hi * cr;
     }
     void *h = nullptr;
     HZ_HIP(ctx, hipMalloc(&h, (size_t)c->nfft * 8));
@@ -1062,6 +349,9 @@ static int late_filters(hzsdr_chain *c, const EwProgram &P, size_t n, LateFilter
         *any = true;
         return HZSDR_OK;
     }
+    // sincos_late (the late mixer's Sincos) takes |tau * ts| < 2^30, ts <= 2 pi
+    for (int i = 0; i < P.n; i++)
+        if (P.op[i].kind == EW_SHIFT && !(fabs(P.op[i].tau_shift) * 6.2832 < 1073741824.0)) return HZSDR_OK;
     const double omega = chain_omega(c);
     for (int r = 0; r < P.segs.n; r++) {
         const uint64_t first = P.segs.first[r], end = r + 1 < P.segs.n ? P.segs.first[r + 1] : (uint64_t)n;
@@ -1072,6 +362,44 @@ static int late_filters(hzsdr_chain *c, const EwProgram &P, size_t n, LateFilter
         if (dev) *any = true;
     }
     return HZSDR_OK;
+}
+
+// The blocks of this run that mix in reference order, ascending, for the analysis kernel's
+// dispatch order (device side: late_block).  Block b spans [b*hop - off, b*hop - off + N) and
+// is late iff that span lies in [0, n - off] AND inside one clock run that has a filter.
+// Walks the runs, not the blocks; more than kMaxSlowBlocks of them -> empty list (stream order).
+static void slow_blocks(const hzsdr_chain *c, const EwProgram &P, const LateFilters &late, size_t n,
+                        size_t nblocks, SlowBlocks *out) {
+    out->n = 0;
+    const int64_t N = c->nfft, hop = c->hop, off = c->off;
+    std::vector<unsigned> v;
+    auto add_range = [&](int64_t lo, int64_t hi) {  // blocks lo .. hi inclusive, clipped
+        if (lo < 0) lo = 0;
+        if (hi >= (int64_t)nblocks) hi = (int64_t)nblocks - 1;
+        for (int64_t b = lo; b <= hi && v.size() <= (size_t)kMaxSlowBlocks; b++) v.push_back((unsigned)b);
+    };
+    // every block whose span contains a sample of [s_lo, s_hi]: b*hop - off <= s_hi and b*hop - off + N > s_lo
+    auto touching = [&](int64_t s_lo, int64_t s_hi) {
+        int64_t lo = s_lo + off - N;            // b*hop > lo
+        lo = lo < 0 ? 0 : lo / hop + 1;
+        add_range(lo, (s_hi + off) / hop);
+    };
+    // stream edges: spans that start before sample 0 (b*hop < off) or end after n - off (b*hop > n - N)
+    if (off > 0) add_range(0, (off - 1) / hop);
+    add_range((int64_t)n >= N ? ((int64_t)n - N) / hop + 1 : 0, (int64_t)nblocks - 1);
+    const int nr = P.segs.n > 0 ? P.segs.n : 1;
+    for (int r = 0; r < nr; r++) {
+        const int64_t first = P.segs.n > 0 ? (int64_t)P.segs.first[r] : 0;
+        const int64_t end = (P.segs.n > 0 && r + 1 < P.segs.n) ? (int64_t)P.segs.first[r + 1] : (int64_t)n;
+        if (late.h[r] == nullptr) touching(first, end - 1);      // a run without a filter: every block in it
+        else if (r > 0) touching(first - 1, first);              // a boundary: the blocks that straddle it
+        if (v.size() > (size_t)kMaxSlowBlocks) return;
+    }
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    if (v.size() > (size_t)kMaxSlowBlocks) return;
+    out->n = (int)v.size();
+    for (size_t i = 0; i < v.size(); i++) out->idx[i] = v[i];
 }
 
 template <int FMT>
@@ -1093,47 +421,36 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
         return conv_blocks_device(ctx, FMT, c->flen, in, out, c->filt, n_cons / c->flen, c->factor,
                                   c->factor > 1 ? kReaderBlock / c->factor : 0, P);
     case TERM_FIR: {
-        const float2 *tw, *tws = nullptr;
-        HZ_TRY(get_twiddles(ctx, c->nfft, &tw));
         const size_t nblocks = (n_cons + c->hop - 1) / c->hop;
         const float2 *hist = (const float2 *)c->hist[c->hist_cur];
         float2 *nhist = (float2 *)c->hist[c->hist_cur ^ 1];
-        unsigned grid = (unsigned)nblocks;
         const unsigned D = c->factor;
-#define HZ_FIR(N, FOLD)                                                                                  \
-    hipLaunchKernelGGL((fir_decimate_kernel<N, FMT, FOLD>), dim3(grid), dim3(fft_block(N)), 0,           \
-                       ctx->stream, in, (float2 *)out, hist, nhist, (const float2 *)c->hfreq, tw, tws, nblocks, \
-                       n_cons, c->hop, c->off, D, P)
-#define HZ_FIR_N(N)                                                                      \
-    do {                                                                                 \
-        constexpr int CNT_ = N / fft_tpt(N);                                             \
-        const bool pow2 = (D & (D - 1)) == 0;                                            \
-        if (pow2 && D >= 2 && D <= 16 && (int)D <= CNT_ && N / D >= 4)                   \
-            HZ_TRY(get_twiddles(ctx, N / D, &tws));                                      \
-        if (pow2 && D == 2 && 2 <= CNT_) HZ_FIR(N, (2 <= CNT_ ? 2 : 0));                 \
-        else if (pow2 && D == 4 && 4 <= CNT_) HZ_FIR(N, (4 <= CNT_ ? 4 : 0));            \
-        else if (pow2 && D == 8 && 8 <= CNT_) HZ_FIR(N, (8 <= CNT_ ? 8 : 0));            \
-        else if (pow2 && D == 16 && 16 <= CNT_) HZ_FIR(N, (16 <= CNT_ ? 16 : 0));        \
-        else HZ_FIR(N, 0);                                                               \
-    } while (0)
-// radix-16 core: fold when D is a power of two <= 16 and N/D is itself a radix-16 size
-#define HZ_FIR16_L(N, FOLD, LATE, SPEC)                                                                 \
-    hipLaunchKernelGGL((fir_decimate_kernel16<N, FMT, FOLD, LATE>),                                     \
-                       dim3((unsigned)((nblocks + f16::xpb(N) - 1) / f16::xpb(N))), dim3(f16::block(N)), \
-                       0, ctx->stream, in, (float2 *)out, hist, nhist, (const float2 *)c->hfreq, tw, SPEC, \
-                       nblocks, n_cons, c->hop, c->off, D, P, late, tws)
+        if (!fv::ok((int)c->nfft)) return HZSDR_ERR_INVALID_ARGUMENT;
+        FvTabs tabs{}, tabs_m{};
+        PolyTabs ptabs{};
+        HZ_TRY(get_fv_tables(ctx, c->nfft, &tabs));
+        LateFilters late{};
+        SlowBlocks slow{};
+// packed-math core: fold when D is a power of two <= 16 and N/D is itself a core size
+#define HZ_FIR16_L(N, FOLD, LATE, SPEC)                                                                        \
+    launch_fv(fir_decimate_kernel16<N, FMT, FOLD, LATE>, dim3((unsigned)((nblocks + fv::xpb(N) - 1) / fv::xpb(N))), \
+              dim3(fv::block(N)), fir_lds_bytes(N, FOLD), ctx->stream, in,                                      \
+              (float2 *)out, hist, nhist, (const float2 *)c->hfreq, tabs, SPEC, nblocks, n_cons, c->hop, c->off, D, \
+              P, late, ptabs, slow)
 #define HZ_FIR16(N, FOLD) HZ_FIR16_L(N, FOLD, false, (float2 *)nullptr)
-#define HZ_SYNTH16(N, F, LATE)                                                                           \
-    hipLaunchKernelGGL((fir_synth_kernel16<N, F, LATE>),                                                 \
-                       dim3((unsigned)((nblocks + SynthGeom<N, F>::XPB - 1) / SynthGeom<N, F>::XPB)),     \
-                       dim3(SynthGeom<N, F>::BS), 0, ctx->stream, (const float2 *)spec, (float2 *)out, tws, nblocks, n_cons, \
-                       c->hop, c->off, P, late)
+#define HZ_SYNTH16(N, F, LATE)                                                                                 \
+    launch_fv(fir_synth_kernel16<N, F, LATE>,                                                                  \
+              dim3((unsigned)((nblocks + SynthGeom<N, F>::XPB - 1) / SynthGeom<N, F>::XPB)),                    \
+              dim3(SynthGeom<N, F>::BS), (size_t)SynthGeom<N, F>::XPB * fv::lds_elems(N / F) * sizeof(cf),      \
+              ctx->stream, (const float2 *)spec, (float2 *)out, tabs_m.bwd, nblocks, n_cons, c->hop, c->off, P, late)
 #define HZ_FIR16_FOLD(N, F)                                                            \
     if (D == F) {                                                                      \
-        if constexpr (f16::xpb(N) == 1 && f16::ok(N / F)) {                            \
-            HZ_TRY(get_twiddles(ctx, N / F, &tws));                                    \
+        if constexpr (fv::xpb(N) == 1 && fv::ok(N / F)) {                              \
+            HZ_TRY(get_fv_tables(ctx, N / F, &tabs_m));                                \
+            if constexpr (fold_poly(N, F)) HZ_TRY(get_fv_poly_tables(ctx, N, F, &ptabs)); \
             bool any_late = false;                                                     \
             HZ_TRY(late_filters(c, P, n_cons, &late, &any_late));                      \
+            if (any_late) slow_blocks(c, P, late, n_cons, nblocks, &slow);             \
             HZ_TRY(ensure_slot(ctx, 11, nblocks * (size_t)(N / F) * 8));               \
             float2 *spec = (float2 *)ctx->slots[11].ptr;                               \
             if (any_late) {                                                            \
@@ -1149,9 +466,10 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
 // any other factor (1, 3, 5, 10, ...): full backward transform in the analysis kernel; the
 // late mixer applies there too when a workgroup is one block (N >= 1024)
 #define HZ_FIR16_FULL(N)                                                               \
-    if constexpr (f16::xpb(N) == 1) {                                                  \
+    if constexpr (fv::xpb(N) == 1) {                                                   \
         bool any_late = false;                                                         \
         HZ_TRY(late_filters(c, P, n_cons, &late, &any_late));                          \
+        if (any_late) slow_blocks(c, P, late, n_cons, nblocks, &slow);                 \
         if (any_late) HZ_FIR16_L(N, 0, true, (float2 *)nullptr);                       \
         else HZ_FIR16(N, 0);                                                           \
     } else {                                                                           \
@@ -1165,14 +483,13 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
         HZ_FIR16_FOLD(N, 16)     \
         HZ_FIR16_FULL(N)         \
     } while (0)
-        LateFilters late{};
         switch (c->nfft) {
         case 256: HZ_FIR16_N(256); break;
         case 512: HZ_FIR16_N(512); break;
         case 1024: HZ_FIR16_N(1024); break;
         case 2048: HZ_FIR16_N(2048); break;
         case 4096: HZ_FIR16_N(4096); break;
-        case 8192: HZ_FIR_N(8192); break;
+        case 8192: HZ_FIR16_N(8192); break;
         default: return HZSDR_ERR_INVALID_ARGUMENT;
         }
 #undef HZ_FIR16_N
@@ -1181,8 +498,6 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
 #undef HZ_FIR16
 #undef HZ_FIR16_L
 #undef HZ_SYNTH16
-#undef HZ_FIR_N
-#undef HZ_FIR
         c->hist_cur ^= 1;  // the kernel wrote the next run's history into nhist
         break;
     }
@@ -1349,7 +664,7 @@ int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps, size_t n_taps, u
         HZ_HIP(ctx, hipMalloc(&c->hist[1], hb));
         HZ_HIP(ctx, hipMemsetAsync(c->hist[0], 0, hb, ctx->stream));
         HZ_HIP(ctx, hipMemsetAsync(c->hist[1], 0, hb, ctx->stream));
-        HZ_TRY(filter_spectrum(c, taps, c->hfreq));
+        HZ_TRY(filter_spectrum(c, c->taps_host.data(), c->hfreq));
         return prepare_late_filters(c, c->ts);
     };
     const int rc = build();

@@ -227,4 +227,36 @@ __device__ __forceinline__ void go_sincos(double x, double &sn, double &cs) {
     if (x == 0.0) sn = x;  // +-0 in, +-0 out (cs is already exactly 1)
 }
 
+// sin and cos of x, |x| < 2^30, for the LATE mixer (hz_chain_dev.h): the same Cephes kernels
+// as math.Sincos on the same float64 argument, but with a two-fma Cody-Waite reduction by
+// pi/2, fused Horner steps and branch-free quadrant logic -- a third of the issue slots of
+// the operation-for-operation restatement above.  The float64 results agree with
+// math.Sincos to ~1e-16, so after narrowing to float32 the mixer's factors are the same
+// numbers except within ~1e-8 ulp of a rounding boundary; they multiply a filter output
+// that is held to an error bound, not to bits (reference-order blocks, and every
+// bit-exact operator, keep go_sincos).
+__device__ __forceinline__ void sincos_late(double x, double &sn, double &cs) {
+    const double k = rint(__dmul_rn(x, 0.63661977236758134308));  // x * 2/pi
+    double r = __fma_rn(-k, 1.57079632679489655800e+00, x);
+    r = __fma_rn(-k, 6.12323399573676603587e-17, r);
+    const int q = __double2int_rn(k);
+    const double z = __dmul_rn(r, r);
+    double ps = __fma_rn(1.58962301576546568060e-10, z, -2.50507477628578072866e-8);
+    ps = __fma_rn(ps, z, 2.75573136213857245213e-6);
+    ps = __fma_rn(ps, z, -1.98412698295895385996e-4);
+    ps = __fma_rn(ps, z, 8.33333333332211858878e-3);
+    ps = __fma_rn(ps, z, -1.66666666666666307295e-1);
+    const double s = __fma_rn(__dmul_rn(r, z), ps, r);
+    double pc = __fma_rn(-1.13585365213876817300e-11, z, 2.08757008419747316778e-9);
+    pc = __fma_rn(pc, z, -2.75573141792967388112e-7);
+    pc = __fma_rn(pc, z, 2.48015872888517045348e-5);
+    pc = __fma_rn(pc, z, -1.38888888888730564116e-3);
+    pc = __fma_rn(pc, z, 4.16666666666665929218e-2);
+    const double c = __fma_rn(__dmul_rn(z, z), pc, __fma_rn(-0.5, z, 1.0));
+    const bool swap = q & 1;
+    const double a = swap ? c : s, b = swap ? s : c;
+    sn = (q & 2) ? -a : a;
+    cs = ((q + 1) & 2) ? -b : b;
+}
+
 }  // namespace hz

@@ -6,6 +6,7 @@
 // correct, unoptimised (the 64 Ki-point kerberos sizes are a "next" row).
 #include "hz_fft.h"
 #include "hz_fft16.h"
+#include "hz_fftv.h"
 
 #include <math.h>
 
@@ -37,6 +38,102 @@ int get_twiddles(hzsdr_ctx *ctx, size_t n, const float2 **out) {
     }
     ctx->twiddles[n] = d;
     *out = (const float2 *)d;
+    return HZSDR_OK;
+}
+
+// ---- per-pass twiddle tables of the packed-math core (hz_fftv.h) ---------------------------
+// Entry = (w.re, w.im, -w.im, w.re) = (w, i w), computed in float64.  Cached per context under
+// keys that cannot collide with the plain tables' (n) and the big-twiddle tables' (2n + 1).
+
+static void fv_entry(std::vector<float> &t, double angle) {
+    const float c = (float)cos(angle), s = (float)sin(angle);
+    t.push_back(c);
+    t.push_back(s);
+    t.push_back(-s);
+    t.push_back(c);
+}
+
+// radix-16 pass at Ns = ns: rows k < ns of the six entries w^(m k), m = 1, 2, 3, 4, 8, 12,
+// w = exp(sign * 2 pi i / (16 ns))
+static void fv_pass16_table(std::vector<float> &t, int ns, double sign) {
+    static const int m[6] = {1, 2, 3, 4, 8, 12};
+    for (int k = 0; k < ns; k++)
+        for (int e = 0; e < 6; e++) fv_entry(t, sign * 2.0 * M_PI * (double)m[e] * (double)k / (16.0 * ns));
+}
+// full rows (r < radix entries w^(r k)) for tables a kernel keeps in LDS
+static void fv_rows_table(std::vector<float> &t, int radix, int ns, double sign) {
+    for (int k = 0; k < ns; k++)
+        for (int r = 0; r < radix; r++) fv_entry(t, sign * 2.0 * M_PI * (double)r * (double)k / ((double)ns * radix));
+}
+// pass of radix < 16 at Ns = ns: rows k < ns of radix-1 plain (re, im) twiddles w^(r k), r >= 1
+static void fv_small_table(std::vector<float> &t, int radix, int ns, double sign) {
+    for (int k = 0; k < ns; k++)
+        for (int r = 1; r < radix; r++) {
+            const double a = sign * 2.0 * M_PI * (double)r * (double)k / ((double)ns * radix);
+            t.push_back((float)cos(a));
+            t.push_back((float)sin(a));
+        }
+    while (t.size() % 4) t.push_back(0.f);
+}
+
+static int fv_upload(hzsdr_ctx *ctx, size_t key, const std::vector<float> &t, const void **out) {
+    auto it = ctx->twiddles.find(key);
+    if (it != ctx->twiddles.end()) {
+        *out = it->second;
+        return HZSDR_OK;
+    }
+    void *d = nullptr;
+    HZ_HIP(ctx, hipMalloc(&d, t.size() * sizeof(float) + 16));
+    hipError_t e = hipMemcpy(d, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return hip_fail(ctx, e, "twiddle upload", __FILE__, __LINE__);
+    }
+    ctx->twiddles[key] = d;
+    *out = d;
+    return HZSDR_OK;
+}
+
+int get_fv_tables(hzsdr_ctx *ctx, size_t n, fv::FvTabs *out) {
+    if (!fv::ok((int)n)) return HZSDR_ERR_INVALID_ARGUMENT;
+    const size_t kf = (n << 8) | 0x10, kb = (n << 8) | 0x11;
+    const void *f = nullptr, *b = nullptr;
+    auto itf = ctx->twiddles.find(kf), itb = ctx->twiddles.find(kb);
+    if (itf != ctx->twiddles.end() && itb != ctx->twiddles.end()) {
+        out->fwd = (const fv::cf4 *)itf->second;
+        out->bwd = (const fv::cf4 *)itb->second;
+        return HZSDR_OK;
+    }
+    const int N = (int)n, R0 = fv::first_radix(N);
+    std::vector<float> tf, tb;
+    for (int ns = R0; ns < N; ns *= 16) fv_pass16_table(tf, ns, -1.0);  // forward: (16, R0), (16, 16 R0), ...
+    int ns = 16;
+    for (; ns * R0 < N; ns *= 16) fv_pass16_table(tb, ns, +1.0);       // backward: (16, 16), (16, 256), ...
+    if (R0 == 16) fv_pass16_table(tb, N / 16, +1.0);                    // ... then (R0, N / R0)
+    else fv_small_table(tb, R0, N / R0, +1.0);
+    if ((int)(tf.size() / 4) != fv::fwd_tab_len(N) || (int)(tb.size() / 4) != fv::bwd_tab_len(N))
+        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "fft: twiddle table geometry");
+    HZ_TRY(fv_upload(ctx, kf, tf, &f));
+    HZ_TRY(fv_upload(ctx, kb, tb, &b));
+    out->fwd = (const fv::cf4 *)f;
+    out->bwd = (const fv::cf4 *)b;
+    return HZSDR_OK;
+}
+
+// the polyphase analysis (hz_chain_dev.h, fold_poly): branch transforms of M = n / fold points
+// with plan 16, R2 = n/256, RL = 16/fold
+int get_fv_poly_tables(hzsdr_ctx *ctx, size_t n, unsigned fold, fv::PolyTabs *out) {
+    const size_t k2 = (n << 8) | 0x20, k3 = (n << 8) | 0x40 | fold;
+    const int N = (int)n, R2 = N / 256, RL = 16 / (int)fold, TPT = N / 16;
+    std::vector<float> t2, t3;
+    fv_rows_table(t2, R2, 16, -1.0);
+    for (int lane = 0; lane < TPT; lane++)
+        for (int i = 0; i < RL; i++) fv_entry(t3, -2.0 * M_PI * (double)i * (double)lane / ((double)RL * TPT));
+    const void *p2 = nullptr, *p3 = nullptr;
+    HZ_TRY(fv_upload(ctx, k2, t2, &p2));
+    HZ_TRY(fv_upload(ctx, k3, t3, &p3));
+    out->p2 = (const fv::cf4 *)p2;
+    out->p3 = (const fv::cf4 *)p3;
     return HZSDR_OK;
 }
 

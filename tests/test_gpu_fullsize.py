@@ -16,7 +16,7 @@ import importlib
 import numpy as np
 import pytest
 
-from util import assert_fir_close, rand_c64, rand_u8, zeros
+from util import CROSS_REL_L2, assert_fir_close, rand_c64, rand_u8, zeros
 
 pytestmark = pytest.mark.gpu
 
@@ -77,7 +77,7 @@ def test_north_star_full_size(hz, dev, orc):
         outs[in_order] = got
         ch.close()
     d = outs[False].astype(np.complex128) - outs[True]
-    assert np.linalg.norm(d) <= 2e-7 * np.linalg.norm(want.astype(np.complex128))
+    assert np.linalg.norm(d) <= CROSS_REL_L2 * np.linalg.norm(want.astype(np.complex128))
 
 
 @pytest.mark.parametrize("with_shift", [False, True])
