@@ -91,6 +91,38 @@ __device__ __forceinline__ void ew_apply_n(const EwProgram &P, float2 (&v)[W], u
     }
 }
 
+// The late mixer over W filter outputs at time indices idx[l] + lane of a block whose first
+// input sample is p0 (output i sits at stream position p0 + i*D): ew_apply_n<W, true> with a
+// position per slot instead of a common stride.
+template <int W>
+__device__ __forceinline__ void ew_apply_at(const EwProgram &P, float2 (&v)[W], int64_t p0, int lane,
+                                            const unsigned (&idx)[W], unsigned D, NcoWin w) {
+    double ts[W];
+    bool have_ts = false;
+#pragma unroll 1
+    for (int i = 0; i < P.n; i++) {  // uniform
+        const EwOp &o = P.op[i];
+        if (o.kind == EW_SCALE) {
+#pragma unroll
+            for (int l = 0; l < W; l++) v[l] = make_float2(__fmul_rn(v[l].x, o.a), __fmul_rn(v[l].y, o.a));
+        } else if (o.kind == EW_ROTATE) {
+#pragma unroll
+            for (int l = 0; l < W; l++) v[l] = go_cmul(v[l], make_float2(o.a, o.b));
+        } else {
+            if (!have_ts) {
+#pragma unroll
+                for (int l = 0; l < W; l++) ts[l] = nco_ts(P.segs, w, (uint64_t)(p0 + (int64_t)(idx[l] + lane) * D));
+                have_ts = true;
+            }
+            double s[W], c[W];
+#pragma unroll
+            for (int l = 0; l < W; l++) sincos_late(__dmul_rn(o.tau_shift, ts[l]), s[l], c[l]);
+#pragma unroll
+            for (int l = 0; l < W; l++) v[l] = go_cmul(v[l], make_float2((float)c[l], (float)s[l]));
+        }
+    }
+}
+
 // The two most common programs -- Shift, and Shift then Gain (BASELINE config 2) -- spelt
 // out, without the op loop: same operations in the same order, but straight-line code the
 // scheduler can overlap with the loads and stores around it.  SHAPE 0 = interpret.
@@ -427,7 +459,10 @@ __device__ __forceinline__ cf *fv_lds() {
 }
 
 // stage_block for the padded LDS image of the workgroup core
-template <int N, int FMT>
+// FILTERED: the staged samples feed a FIR whose outputs are held to an error bound (the
+// north-star FIR-decimate), so Shift may use sincos_late; the reference's own
+// ConvolutionReader chain keeps the operation-for-operation math.Sincos.
+template <int N, int FMT, bool FILTERED = false>
 __device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const EwProgram &P, int64_t p0,
                                               size_t n_in, const float2 *hist, unsigned off, int lane,
                                               bool live, float2 *new_hist = nullptr) {
@@ -472,7 +507,7 @@ __device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const
             // third inlined copy of the float64 Sincos on a divergent path.
             const bool in0 = p >= 0 && (size_t)p < n_in, in1 = p + 1 >= 0 && (size_t)(p + 1) < n_in;
             float2 ab[2] = {Raw<FMT>::cvt(x.v[0]), Raw<FMT>::cvt(x.v[1])};
-            ew_apply_n<2>(P, ab, (uint64_t)p, w);  // (uint64)(-1) + 1 wraps to sample 0
+            ew_apply_n<2, FILTERED>(P, ab, (uint64_t)p, w);  // (uint64)(-1) + 1 wraps to sample 0
             if (in0) a = ab[0]; else if (p < 0 && hist) a = hist[p + off];
             if (in1) b = ab[1]; else if (p + 1 < 0 && hist) b = hist[p + 1 + off];
         }
@@ -587,7 +622,10 @@ constexpr int fir_occupancy(int n, int fold, bool late) {
     return !late ? 1 : fv::block(n) >= 512 ? 2 : fold != 0 ? 4 : 3;
 }
 
-template <int N, int FMT, int FOLD, bool LATE>
+// EXP: ablation switches for tools/fir_ablate.hip (0 in the library): 1 = no input loads,
+// 2 = no filter loads, 4 = no output store, 8 = no pass-3 LDS reads, 16 = no pass-1/2 LDS
+// traffic.  Results are wrong by construction with any of them set.
+template <int N, int FMT, int FOLD, bool LATE, int EXP = 0>
 __global__ __launch_bounds__(fv::block(N), fir_occupancy(N, FOLD, LATE)) void fir_decimate_kernel16(
     const void *in, float2 *out, const float2 *__restrict__ hist, float2 *__restrict__ new_hist,
     const float2 *__restrict__ hfreq, FvTabs tabs, float2 *__restrict__ spec, size_t nblocks, size_t n_in,
@@ -634,6 +672,13 @@ __global__ __launch_bounds__(fv::block(N), fir_occupancy(N, FOLD, LATE)) void fi
     if constexpr (LATE) mix_late = late_block(P, late, p0, N, off, n_in, &run);
     const float2 *__restrict__ hf = mix_late ? late.h[run.lo] : hfreq;
     cf v[16];
+    // polyphase form: this lane's entry of pass 2's twiddle rows, fetched before anything else
+    // (it goes to LDS after pass 1; asked for there, its L2 round trip stood in front of the
+    // first barrier of every block)
+    cf4 p2_entry = cf4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (fold_poly(N, FOLD)) {
+        if (lane < 16 * (N / 256)) p2_entry = ptabs.p2[lane];
+    }
     const bool direct = LATE && mix_late;  // workgroup-uniform
     // register image of the first pass: radix-16 edge for the polyphase form, the N-point
     // plan's first radix otherwise
@@ -646,11 +691,11 @@ __global__ __launch_bounds__(fv::block(N), fir_occupancy(N, FOLD, LATE)) void fi
         const R *src = (const R *)in + p0 + lane;
         R raw[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) raw[q] = src[fv::edge_off<N, RIN>(q)];
+        for (int q = 0; q < 16; q++) raw[q] = (EXP & 1) ? (R)(lane * 3 + q) : src[fv::edge_off<N, RIN>(q)];
 #pragma unroll
         for (int q = 0; q < 16; q++) v[q] = fv::from2(Raw<FMT>::cvt(raw[q]));
     } else {
-        stage_block16<N, FMT>((float2 *)lds, in, P, p0, n_in, hist, off, lane, live, new_hist);
+        stage_block16<N, FMT, true>((float2 *)lds, in, P, p0, n_in, hist, off, lane, live, new_hist);
         __syncthreads();
         fv::load_lds<N, RIN>(v, lds, lane);
     }
@@ -665,18 +710,18 @@ __global__ __launch_bounds__(fv::block(N), fir_occupancy(N, FOLD, LATE)) void fi
         // pass 2's twiddle rows (16 rows of R2 entries, a few KB) live in LDS behind the data,
         // rows one entry apart in bank space: 16-byte reads at immediate offsets
         cf4 *ltab = reinterpret_cast<cf4 *>(lds + fv::lds_elems(N) + 32);
-        if (lane < 16 * R2) ltab[(lane / R2) * (R2 + 1) + lane % R2] = ptabs.p2[lane];
+        if (lane < 16 * R2) ltab[(lane / R2) * (R2 + 1) + lane % R2] = p2_entry;
         // pass 1 of every branch: radix 16 at Ns = 1 over u_r[bl + (M/16) q] = x[lane + TPT q]
         fv::butterflies<16, false>(v);
         if (!direct) __syncthreads();  // the staged block has been read by everybody
-        fv::store_lds<M, 16, 1>(v, ldb, bl);
+        if constexpr (!(EXP & 16)) fv::store_lds<M, 16, 1>(v, ldb, bl);
         {  // pass 2: radix N/256 at Ns = 16, inside the branch
             __syncthreads();
-            fv::load_lds<M, R2>(v, ldb, bl);
+            if constexpr (!(EXP & 16)) fv::load_lds<M, R2>(v, ldb, bl);
             fv::twiddle_rows<M, R2, 16, R2 + 1>(v, (const cf4 *)ltab, bl);
             fv::butterflies<R2, false>(v);
             __syncthreads();
-            fv::store_lds<M, R2, 16>(v, ldb, bl);
+            if constexpr (!(EXP & 16)) fv::store_lds<M, R2, 16>(v, ldb, bl);
         }
         // last pass (radix RL at Ns = N/16) of ALL branches at bins lane + TPT i, times the
         // branch's filter spectrum, summed over the branches
@@ -693,12 +738,12 @@ __global__ __launch_bounds__(fv::block(N), fir_occupancy(N, FOLD, LATE)) void fi
         for (int r2 = 0; r2 < FOLD; r2++) {
             cf u[RL];
 #pragma unroll
-            for (int i = 0; i < RL; i++) u[i] = pb[r2 * LE + fv::pad(TPT * i)];
+            for (int i = 0; i < RL; i++) u[i] = (EXP & 8) ? v[(r2 * RL + i) & 15] : pb[r2 * LE + fv::pad(TPT * i)];
 #pragma unroll
             for (int i = 1; i < RL; i++) u[i] = fv::cmul4(u[i], wl[i - 1]);
             if constexpr (RL > 1) fv::dft<RL, false>(u);
 #pragma unroll
-            for (int i = 0; i < RL; i++) fv::cacc(zp[i], zq[i], u[i], hl[r2 * M + TPT * i]);
+            for (int i = 0; i < RL; i++) fv::cacc(zp[i], zq[i], u[i], (EXP & 2) ? cf{0.5f, 0.25f} : hl[r2 * M + TPT * i]);
         }
         if (live) {
             cf *sp = (cf *)spec + b * M + lane;
@@ -812,25 +857,36 @@ __global__ __launch_bounds__((SynthGeom<N, FOLD>::BS)) void fir_synth_kernel16(
         }
     }
     if constexpr (LATE) {
-        __syncthreads();  // every group's last-pass reads are done: its region can take the outputs
         if (mix_late) {
+            // The mixer straight from the last pass's registers: slot q holds time index
+            // i = edge_index<M, RM>(q, l2) = l2 + const(q); output i sits at stream position
+            // p0 + i*FOLD.  Four slots at a time (four interleaved float64 Sincos chains), fixed
+            // registers; groups with no valid output (uniform test) are skipped.
+            const int64_t p0 = (int64_t)(b * hop) - (int64_t)off;
 #pragma unroll
-            for (int q = 0; q < 16; q++) lds[fv::edge_index<M, RM>(q, l2)] = w[q];
-        }
-        __syncthreads();
-        if (mix_late) {
-            // four outputs per lane per trip: four independent Sincos chains in flight
-            constexpr int W = 4;
-            const float2 *ldf = (const float2 *)lds;
-#pragma unroll 1
-            for (unsigned t0 = l2; t0 < per; t0 += W * TPTM) {
-                float2 y[W];
+            for (int g = 0; g < 4; g++) {
+                // slots in ascending time order: the m-th smallest offset is m * TPTM, held by
+                // slot q = (m % (16/RM)) * RM + m / (16/RM); four consecutive m per group, so a
+                // group below i_lo (the block's overlap) is skipped whole
+                float2 y[4];
+                unsigned idx[4];
+                int qs[4];
+                bool any = false;
 #pragma unroll
-                for (int l = 0; l < W; l++) y[l] = ldf[i_lo + (t0 + l * TPTM < per ? t0 + l * TPTM : t0)];
-                ew_apply_n<W, true>(P, y, (uint64_t)b * hop + (uint64_t)t0 * FOLD, run, (uint64_t)TPTM * FOLD);
+                for (int l = 0; l < 4; l++) {
+                    const int m = 4 * g + l;
+                    qs[l] = (m % (16 / RM)) * RM + m / (16 / RM);
+                    idx[l] = fv::edge_off<M, RM>(qs[l]);
+                    y[l] = fv::to2(w[qs[l]]);
+                    any = any || (idx[l] + TPTM > i_lo && idx[l] < i_hi);
+                }
+                if (!any) continue;  // compile-time offsets, uniform bounds
+                ew_apply_at<4>(P, y, p0, l2, idx, FOLD, run);
 #pragma unroll
-                for (int l = 0; l < W; l++)
-                    if (t0 + l * TPTM < per) out[b * per + t0 + l * TPTM] = y[l];
+                for (int l = 0; l < 4; l++) {
+                    const unsigned i = idx[l] + l2;
+                    if (i >= i_lo && i < i_hi) out[b * per + (i - i_lo)] = y[l];
+                }
             }
         }
     }
