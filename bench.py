@@ -316,6 +316,7 @@ def main():
         for name, row in extra.items():
             if name != "device_copy_c64":
                 row["frac_of_device_copy"] = round(row["GBps"] / copy_gbps, 4)
+        extra["small_buffers"] = small_buffers_gpu(hz, ctx, torch, local_rank)
         result["extra"] = extra
 
     # ---- Beamform, 4 channels, on sub-groups of 1 / 2 / 4 ranks (the other half of the metric) ----
@@ -438,8 +439,122 @@ def main():
     return 0 if parity_ok else 3
 
 
+# The reference's own benchmark sizes: us per call, one call at a time.
+#   iq_u8_test.go:170-182 (u8 -> c64, 16 Ki), internal/simd/mult_test.go:80-102 (Scale / Rotate,
+#   16 Ki), stream/add_test.go:137-191 (Add, 8 Ki x K), stream/multiply_test.go:114-187
+#   (Multiply u8 / i8 / c64, 64 Ki), plus ConvertBuffer at the 32 Ki Reader block
+#   (stream/convert.go:43-44).
+SMALL_CASES = [("convert_u8_c64", 16 * 1024), ("convert_u8_c64", 32 * 1024), ("scale_c64", 16 * 1024),
+               ("rotate_c64", 16 * 1024), ("add_x2", 8 * 1024), ("add_x4", 8 * 1024), ("add_x16", 8 * 1024),
+               ("multiply_u8", 64 * 1024), ("multiply_i8", 64 * 1024), ("multiply_c64", 64 * 1024)]
+
+
+def _small_op(hz, ctx, name, n, mk_in, mk_out):
+    """-> a zero-argument callable running `name` once on buffers made by mk_in / mk_out."""
+    m = 0.6 + 0.8j
+    if name == "convert_u8_c64":
+        src, dst = mk_in(hz.FMT_U8, n, 1), mk_out(hz.FMT_C64, n)
+        return lambda: ctx.convert(dst, src)
+    if name == "scale_c64":
+        buf = mk_in(hz.FMT_C64, n, 2)
+        return lambda: ctx.scale(buf, 0.999)
+    if name in ("rotate_c64", "multiply_c64"):
+        buf = mk_in(hz.FMT_C64, n, 3)
+        return lambda: ctx.rotate(buf, m)
+    if name.startswith("add_x"):
+        k = int(name[5:])
+        bufs, out = [mk_in(hz.FMT_C64, n, 10 + i) for i in range(k)], mk_out(hz.FMT_C64, n)
+        return lambda: ctx.sum(out, bufs)
+    fmt = hz.FMT_U8 if name == "multiply_u8" else hz.FMT_I8
+    tab, buf = ctx.rotlut(fmt, m), mk_in(fmt, n, 4)
+    return lambda: tab.apply(buf)
+
+
+def small_buffers_gpu(hz, dctx, torch, device):
+    rows = {}
+    hctx = hz.Context(device, hz.MEM_HOST)
+
+    def np_in(fmt, n, seed):
+        return synth_c64(seed, n).copy() if fmt == hz.FMT_C64 else synth_u8(seed, n).view(
+            np.uint8 if fmt == hz.FMT_U8 else np.int8)
+
+    def np_out(fmt, n):
+        return np.zeros(n, np.complex64)
+
+    def pin_in(fmt, n, seed):
+        a = hctx.pinned_samples(fmt, n)
+        a[...] = np_in(fmt, n, seed)
+        return a
+
+    def dev_in(fmt, n, seed):
+        return torch.from_numpy(np_in(fmt, n, seed)).cuda()
+
+    for name, n in SMALL_CASES:
+        row = {"samples": n}
+        for label, ctx, mk_in, mk_out in (("host_us", hctx, np_in, np_out),
+                                          ("host_pinned_us", hctx, pin_in, lambda f, k: hctx.pinned_samples(f, k))):
+            fn = _small_op(hz, ctx, name, n, mk_in, mk_out)
+            for _ in range(20):
+                fn()
+            t = []
+            for _ in range(200):
+                t0 = time.perf_counter()
+                fn()
+                t.append(time.perf_counter() - t0)
+            row[label] = round(float(np.median(t)) * 1e6, 2)
+        fn = _small_op(hz, dctx, name, n, dev_in, lambda f, k: torch.zeros(k, dtype=torch.complex64, device="cuda"))
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        row["device_us"] = round(e0.elapsed_time(e1) / 200 * 1e3, 2)
+        rows[f"{name}_{n // 1024}Ki"] = row
+    hctx.close()
+    rows["note"] = ("us per call: host = HZSDR_MEM_HOST on pageable numpy buffers (copy in, kernel over the pinned "
+                    "staging area, copy out; what a cgo caller with Go slices pays, plus ~2 us of ctypes), "
+                    "host_pinned = the same call on hzsdr_malloc_pinned buffers (no staging), device = "
+                    "HZSDR_MEM_DEVICE back to back on one stream (HIP events / 200), cpu = the oracle, one thread")
+    return rows
+
+
 def small_buffers_cpu(orc, table):
-    """Placeholder until the small-buffer table exists."""
+    """The oracle (one thread) on the same sizes, beside the GPU columns."""
+    import oracle as o
+    m = 0.6 + 0.8j
+    for name, n in SMALL_CASES:
+        if name == "convert_u8_c64":
+            src, dst = synth_u8(1, n), np.zeros(n, np.complex64)
+            fn = lambda: o.convert(dst, src)  # noqa: E731
+        elif name == "scale_c64":
+            buf = synth_c64(2, n).copy()
+            fn = lambda: o.scale(buf, 0.999)  # noqa: E731
+        elif name in ("rotate_c64", "multiply_c64"):
+            buf = synth_c64(3, n).copy()
+            fn = lambda: o.rotate(buf, m)  # noqa: E731
+        elif name.startswith("add_x"):
+            k = int(name[5:])
+            bufs, out = [synth_c64(10 + i, n).copy() for i in range(k)], np.zeros(n, np.complex64)
+            fn = lambda: o.sum_(out, bufs)  # noqa: E731
+        else:
+            u8 = name == "multiply_u8"
+            tab = o.rotate_table_u8(m) if u8 else o.rotate_table_i8(m)
+            buf = synth_u8(4, n) if u8 else synth_u8(4, n).view(np.int8)
+            fn = (lambda: o.rotate_u8_apply(tab, buf)) if u8 else None
+            if fn is None:
+                continue
+        for _ in range(5):
+            fn()
+        t = []
+        for _ in range(50):
+            t0 = time.perf_counter()
+            fn()
+            t.append(time.perf_counter() - t0)
+        table[f"{name}_{n // 1024}Ki"]["cpu_us"] = round(float(np.median(t)) * 1e6, 2)
 
 
 if __name__ == "__main__":

@@ -202,11 +202,15 @@ class Context:
         _check(lib.hzsdr_open(device, memspace, C.byref(self._h)))
         self.device = device
         self.memspace = memspace
+        self._pinned = []
         if stream is not None:
             self.set_stream(stream)
 
     def close(self):
         if self._h:
+            for p in self._pinned:
+                lib.hzsdr_free_pinned(self._h, C.c_void_p(p))
+            self._pinned = []
             lib.hzsdr_close(self._h)
             self._h = C.c_void_p()
 
@@ -247,6 +251,14 @@ class Context:
 
     def i16_shift_lsb_to_msb(self, buf, bits):
         self._ck(lib.hzsdr_i16_shift_lsb_to_msb(self._h, _ptr(buf), length(buf), bits))
+
+    # -- stream.RingBufferOptions.IQBufferAllocator (stream/ring.go:60-68): sample buffers in
+    # pinned, GPU-visible memory the library owns; HOST-space calls on them skip all staging --
+    def pinned_samples(self, fmt, n):
+        p = C.c_void_p()
+        self._ck(lib.hzsdr_malloc_pinned(self._h, max(1, n * format_size(fmt)), C.byref(p)))
+        self._pinned.append(p.value)
+        return _view(p.value, fmt, n)
 
     # -- SamplesC64.Scale / Multiply / Add (iq_c64.go:122-136) --
     def scale(self, buf, r):

@@ -932,6 +932,12 @@ int hzsdr_ring_free(hzsdr_ring *r) {
         if (s.done) (void)hipEventDestroy(s.done);
         if (s.down) (void)hipEventDestroy(s.down);
     }
+    for (char *p : {r->pin_in, r->pin_out})
+        for (size_t i = 0; p && i < r->ctx->pinned_ranges.size(); i++)
+            if (r->ctx->pinned_ranges[i].first == p) {
+                r->ctx->pinned_ranges.erase(r->ctx->pinned_ranges.begin() + (long)i);
+                break;
+            }
     if (r->pin_in) (void)hipHostFree(r->pin_in);
     if (r->pin_out) (void)hipHostFree(r->pin_out);
     if (r->dev_in) (void)hipFree(r->dev_in);
@@ -976,6 +982,9 @@ int hzsdr_ring_create(hzsdr_chain *c, size_t slot_length, int slots, hzsdr_ring 
     HZ_RING(hipHostMalloc((void **)&r->pin_out, r->out_bytes() * slots, hipHostMallocDefault));
     HZ_RING(hipMalloc((void **)&r->dev_in, r->in_bytes() * slots));
     HZ_RING(hipMalloc((void **)&r->dev_out, r->out_bytes() * slots));
+    // ring slots are pinned and GPU-visible: any HOST-space call on them skips its staging
+    ctx->pinned_ranges.push_back({r->pin_in, r->in_bytes() * slots});
+    ctx->pinned_ranges.push_back({r->pin_out, r->out_bytes() * slots});
     for (auto &s : r->slots) {
         HZ_RING(hipEventCreateWithFlags(&s.up, hipEventDisableTiming));
         HZ_RING(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));

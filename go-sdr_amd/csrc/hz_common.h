@@ -25,10 +25,18 @@ struct hzsdr_ctx {
         void *ptr = nullptr;
         size_t cap = 0;
     };
-    Slot slots[12];
+    Slot slots[24];
     // small pinned buffer for per-call parameter tables (pointer lists, ...)
     void *pinned = nullptr;
     size_t pinned_cap = 0;
+    // HOST memory space, small calls: one pinned, GPU-visible staging area.  Kernels read
+    // and write it directly over PCIe (no DMA launch on either side of the kernel), the
+    // CPU copies in and out of it; see Stage.
+    void *hstage = nullptr;
+    size_t hstage_cap = 0;
+    // host ranges that are already pinned and GPU-visible (hzsdr_malloc_pinned, ring slots):
+    // buffers inside them are handed to the kernels as they are, no staging at all
+    std::vector<std::pair<const char *, size_t>> pinned_ranges;
     // FFT twiddle tables exp(-2 pi i m / N), m < N, keyed by N (device memory)
     std::map<size_t, void *> twiddles;
 };
@@ -99,15 +107,29 @@ int ensure_pinned(hzsdr_ctx *ctx, size_t bytes);
 // Staging helpers.  In a DEVICE context they return the caller's pointer; in a
 // HOST context they return device scratch (copying in when asked) and remember
 // what must be copied back.
+// Three routes for a HOST-space buffer (picked per buffer):
+//   * inside a range the library pinned itself (hzsdr_malloc_pinned, ring slots): the kernel
+//     gets the pointer as it is -- zero copies;
+//   * up to kZeroCopyMax bytes per call in total: the CPU copies it into / out of the
+//     context's pinned staging area and the kernel reads / writes that area over PCIe
+//     directly -- no DMA launches, one stream wait.  (A 32 Ki-sample reader block is all
+//     latency: two hipMemcpyAsync launches cost more than moving its 320 KB.)
+//   * larger: device scratch + hipMemcpyAsync each way, as before.
+constexpr size_t kZeroCopyMax = (size_t)2 << 20;
+
 struct Stage {
     hzsdr_ctx *ctx;
     struct Back {
         void *host;
         const void *dev;
         size_t bytes;
+        bool cpu;  // copy back with memcpy after the stream wait (staging area) instead of a DMA
     };
     std::vector<Back> backs;
+    size_t used = 0;  // bytes of the staging area handed out so far
     explicit Stage(hzsdr_ctx *c) : ctx(c) {}
+    bool pinned_by_us(const void *p, size_t bytes) const;
+    void *stage_small(size_t bytes);
     bool host() const { return ctx->memspace == HZSDR_MEM_HOST; }
     // read-only input
     int in(int slot, const void *p, size_t bytes, const void **dev);

@@ -33,9 +33,39 @@ int ensure_pinned(hzsdr_ctx *ctx, size_t bytes) {
     return HZSDR_OK;
 }
 
+bool Stage::pinned_by_us(const void *p, size_t bytes) const {
+    const char *c = (const char *)p;
+    for (auto &r : ctx->pinned_ranges)
+        if (c >= r.first && c + bytes <= r.first + r.second) return true;
+    return false;
+}
+
+// `bytes` of the context's pinned staging area (256-byte aligned), or nullptr if the call
+// has outgrown the small-call route
+void *Stage::stage_small(size_t bytes) {
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (used + need > kZeroCopyMax) return nullptr;
+    if (!ctx->hstage) {
+        if (hipHostMalloc(&ctx->hstage, kZeroCopyMax, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->hstage = nullptr;
+            return nullptr;
+        }
+        ctx->hstage_cap = kZeroCopyMax;
+    }
+    void *p = (char *)ctx->hstage + used;
+    used += need;
+    return p;
+}
+
 int Stage::in(int slot, const void *p, size_t bytes, const void **dev) {
-    if (!host() || bytes == 0) {
+    if (!host() || bytes == 0 || pinned_by_us(p, bytes)) {
         *dev = p;
+        return HZSDR_OK;
+    }
+    if (void *s = stage_small(bytes)) {
+        memcpy(s, p, bytes);
+        *dev = s;
         return HZSDR_OK;
     }
     HZ_TRY(ensure_slot(ctx, slot, bytes));
@@ -45,25 +75,36 @@ int Stage::in(int slot, const void *p, size_t bytes, const void **dev) {
 }
 
 int Stage::out(int slot, void *p, size_t bytes, void **dev) {
-    if (!host() || bytes == 0) {
+    if (!host() || bytes == 0 || pinned_by_us(p, bytes)) {
         *dev = p;
+        return HZSDR_OK;
+    }
+    if (void *s = stage_small(bytes)) {
+        *dev = s;
+        backs.push_back({p, s, bytes, true});
         return HZSDR_OK;
     }
     HZ_TRY(ensure_slot(ctx, slot, bytes));
     *dev = ctx->slots[slot].ptr;
-    backs.push_back({p, *dev, bytes});
+    backs.push_back({p, *dev, bytes, false});
     return HZSDR_OK;
 }
 
 int Stage::inout(int slot, void *p, size_t bytes, void **dev) {
-    if (!host() || bytes == 0) {
+    if (!host() || bytes == 0 || pinned_by_us(p, bytes)) {
         *dev = p;
+        return HZSDR_OK;
+    }
+    if (void *s = stage_small(bytes)) {
+        memcpy(s, p, bytes);
+        *dev = s;
+        backs.push_back({p, s, bytes, true});
         return HZSDR_OK;
     }
     HZ_TRY(ensure_slot(ctx, slot, bytes));
     HZ_HIP(ctx, hipMemcpyAsync(ctx->slots[slot].ptr, p, bytes, hipMemcpyHostToDevice, ctx->stream));
     *dev = ctx->slots[slot].ptr;
-    backs.push_back({p, *dev, bytes});
+    backs.push_back({p, *dev, bytes, false});
     return HZSDR_OK;
 }
 
@@ -71,8 +112,10 @@ int Stage::finish() {
     HZ_HIP(ctx, hipGetLastError());
     if (!host()) return HZSDR_OK;
     for (auto &b : backs)
-        HZ_HIP(ctx, hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if (!b.cpu) HZ_HIP(ctx, hipMemcpyAsync(b.host, b.dev, b.bytes, hipMemcpyDeviceToHost, ctx->stream));
     HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &b : backs)
+        if (b.cpu) memcpy(b.host, b.dev, b.bytes);
     return HZSDR_OK;
 }
 
@@ -136,6 +179,7 @@ int hzsdr_close(hzsdr_ctx *ctx) {
     for (auto &s : ctx->slots)
         if (s.ptr) (void)hipFree(s.ptr);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->hstage) (void)hipHostFree(ctx->hstage);
     for (auto &kv : ctx->twiddles) (void)hipFree(kv.second);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -185,11 +229,18 @@ int hzsdr_malloc_pinned(hzsdr_ctx *ctx, size_t bytes, void **out) {
     HZ_TRY(hz::enter(ctx));
     if (!out) return HZSDR_ERR_INVALID_ARGUMENT;
     HZ_HIP(ctx, hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    ctx->pinned_ranges.push_back({(const char *)*out, bytes ? bytes : 1});
     return HZSDR_OK;
 }
 
 int hzsdr_free_pinned(hzsdr_ctx *ctx, void *ptr) {
     HZ_TRY(hz::enter(ctx));
+    HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));  // a kernel may still be reading it
+    for (size_t i = 0; i < ctx->pinned_ranges.size(); i++)
+        if (ctx->pinned_ranges[i].first == (const char *)ptr) {
+            ctx->pinned_ranges.erase(ctx->pinned_ranges.begin() + (long)i);
+            break;
+        }
     HZ_HIP(ctx, hipHostFree(ptr));
     return HZSDR_OK;
 }

@@ -338,7 +338,6 @@ int hzsdr_sum(hzsdr_ctx *ctx, int format, void *out, const void *const *bufs, in
     PtrList pl{};
     for (int c = 0; c < count; c++) {
         if (!bufs[c]) return HZSDR_ERR_INVALID_ARGUMENT;
-        if (ctx->memspace == HZSDR_MEM_HOST && c + 1 >= 12) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "sum: at most 11 host buffers");
         HZ_TRY(st.in(1 + c, bufs[c], bytes, &pl.p[c]));
     }
     void *dout;
@@ -367,7 +366,6 @@ int hzsdr_beamform_partial(hzsdr_ctx *ctx, void *out, int format, const void *co
     WeightList wl{};
     for (int c = 0; c < count; c++) {
         if (!channels[c]) return HZSDR_ERR_INVALID_ARGUMENT;
-        if (ctx->memspace == HZSDR_MEM_HOST && c + 1 >= 12) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "beamform: at most 11 host channels");
         HZ_TRY(st.in(1 + c, channels[c], n * sz, &pl.p[c]));
         wl.w[c] = make_float2(weights[2 * c], weights[2 * c + 1]);
         wl.identity[c] = (weights[2 * c] == 1.0f && weights[2 * c + 1] == 0.0f) ? 1 : 0;
