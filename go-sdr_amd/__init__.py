@@ -593,6 +593,65 @@ class Chain:
             self._h = C.c_void_p()
 
 
+class _ShardCtx(Context):
+    """A shard's context, owned by its MultiGpu (closing the MultiGpu closes it)."""
+
+    def __init__(self, handle, device):
+        self._h = handle
+        self.device = device
+        self.memspace = MEM_DEVICE
+        self._pinned = []
+
+    def close(self):
+        self._h = C.c_void_p()
+
+
+MGPU_ORDERED, MGPU_RCCL = 0, 1
+
+
+class MultiGpu:
+    """hzsdr_mgpu_*: Beamform sharded over GPUs from one process (stream/beamform.go:148-171
+    with one channel range per GPU).  devices may repeat a GPU (several shards on one)."""
+
+    def __init__(self, devices):
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        _check(lib.hzsdr_mgpu_open(arr, len(devices), C.byref(self._h)))
+        self.devices = list(devices)
+        self.shards = []
+        for s in range(len(devices)):
+            h = C.c_void_p()
+            _check(lib.hzsdr_mgpu_ctx(self._h, s, C.byref(h)))
+            self.shards.append(_ShardCtx(h, devices[s]))
+
+    @staticmethod
+    def shard_channels(k, g, s):
+        lo, hi = C.c_int(0), C.c_int(0)
+        _check(lib.hzsdr_mgpu_shard_channels(k, g, s, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def beamform(self, out, channels, weights, dst_shard=0, mode=MGPU_ORDERED):
+        k = len(channels)
+        fmt = fmt_of(channels[0])
+        arr = (C.c_void_p * k)(*[_ptr(c) for c in channels])
+        w = np.ascontiguousarray(weights, np.complex64)
+        rc = lib.hzsdr_mgpu_beamform(self._h, _ptr(out), dst_shard, fmt, arr, w.ctypes.data_as(C.POINTER(C.c_float)),
+                                     k, length(out), mode)
+        if rc != 0:
+            msg = lib.hzsdr_mgpu_last_error(self._h)
+            raise _ERRORS.get(rc, HzsdrError)(f"hzsdr: {lib.hzsdr_strerror(rc).decode()}: {msg.decode() if msg else ''}")
+
+    def synchronize(self):
+        _check(lib.hzsdr_mgpu_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            lib.hzsdr_mgpu_close(self._h)
+            self._h = C.c_void_p()
+            for s in self.shards:
+                s.close()
+
+
 def _view(ptr, fmt, n):
     """yikes.Samples(base, len, fmt) (yikes/bytes.go:50-71): numpy over foreign memory."""
     dt = {FMT_C64: np.complex64, FMT_U8: np.uint8, FMT_I16: np.int16, FMT_I8: np.int8}[fmt]

@@ -140,6 +140,14 @@ SIGNATURES = {
     "hzsdr_chain_mix_in_order": (i32, [vp, i32]),
     "hzsdr_chain_plan": (i32, [vp, sz, psz, psz]),
     "hzsdr_chain_run": (i32, [vp, vp, sz, vp, sz, psz, psz]),
+    "hzsdr_mgpu_open": (i32, [C.POINTER(C.c_int), i32, pvp]),
+    "hzsdr_mgpu_close": (i32, [vp]),
+    "hzsdr_mgpu_shards": (i32, [vp]),
+    "hzsdr_mgpu_ctx": (i32, [vp, i32, pvp]),
+    "hzsdr_mgpu_shard_channels": (i32, [i32, i32, i32, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "hzsdr_mgpu_beamform": (i32, [vp, vp, i32, i32, C.POINTER(C.c_void_p), C.POINTER(C.c_float), i32, sz, i32]),
+    "hzsdr_mgpu_synchronize": (i32, [vp]),
+    "hzsdr_mgpu_last_error": (C.c_char_p, [vp]),
     "hzsdr_chain_reset": (i32, [vp]),
     "hzsdr_chain_set_time": (i32, [vp, f64]),
     "hzsdr_chain_time": (i32, [vp, C.POINTER(f64)]),

@@ -20,6 +20,11 @@ the GPU box, "gloo" in the CPU tests):
                    overlap.  Bit-identical to the single-GPU / reference result;
                    the final sum lands on the LAST rank.
 
+A program that is ONE process with a context per GPU (cgo) does the same exchange behind
+the C ABI: hzsdr_mgpu_beamform (csrc/hz_mgpu.hip; `MultiGpu` in this package), ordered
+all-to-all by peer copies or ncclReduce.  This module is the one-process-per-GPU form the
+benchmark contract asks for (torch.distributed ranks).
+
 Nothing here touches sample values on the host; `partial_fn` is the only thing
 that computes, and on the GPU box it is the HIP kernel.  (Only when the backend
 is gloo AND the tensors live on a GPU -- a 1-GPU debugging set-up -- are the

@@ -371,6 +371,39 @@ int hzsdr_chain_set_time(hzsdr_chain *c, double ts);
 int hzsdr_chain_time(const hzsdr_chain *c, double *ts);
 int hzsdr_chain_free(hzsdr_chain *c);
 
+/* ---- Beamform sharded over GPUs from one process ------------------ */
+/* The reference sums its coherent channels in one place (stream/beamform.go:148-171 ->
+ * the ordered add of stream/add.go:115-119).  A cgo caller is ONE process with one context
+ * per GPU: hzsdr_mgpu_open makes one DEVICE-space context (and stream) per entry of
+ * `devices` -- the same GPU may appear more than once, which is how a 1-GPU box exercises
+ * the exchange -- and hzsdr_mgpu_beamform runs the weighted sum with channel c resident on
+ * shard owner(c) (contiguous ranges: hzsdr_mgpu_shard_channels).
+ *   channels[c]  device pointer ON owner(c)'s GPU, `format` samples
+ *   weights_c64  n_channels complex64 values in HOST memory
+ *   out_c64      device pointer on shard `dst_shard`'s GPU
+ * HZSDR_MGPU_ORDERED: bit-identical to hzsdr_beamform on one GPU (shard s owns slice s of
+ *   the output, receives slice s of every weighted channel by peer copy and adds the K
+ *   pieces in channel order from +0); HZSDR_MGPU_RCCL: per-shard partial sums + one
+ *   ncclReduce (float sum) over xGMI: faster, RCCL's summation order (a few ULP), needs one
+ *   shard per GPU; librccl is loaded at run time.
+ * Nothing waits on the host: later work on the destination shard's stream is ordered
+ * behind the result; hzsdr_mgpu_synchronize waits for every shard. */
+#define HZSDR_MGPU_ORDERED 0
+#define HZSDR_MGPU_RCCL 1
+typedef struct hzsdr_mgpu hzsdr_mgpu;
+int hzsdr_mgpu_open(const int *devices, int n_devices, hzsdr_mgpu **out);
+int hzsdr_mgpu_close(hzsdr_mgpu *m);
+int hzsdr_mgpu_shards(const hzsdr_mgpu *m);
+/* the DEVICE-space context of a shard (allocate / upload its channels through it) */
+int hzsdr_mgpu_ctx(hzsdr_mgpu *m, int shard, hzsdr_ctx **ctx);
+/* channels [*lo, *hi) live on `shard` when n_channels are spread over n_shards */
+int hzsdr_mgpu_shard_channels(int n_channels, int n_shards, int shard, int *lo, int *hi);
+int hzsdr_mgpu_beamform(hzsdr_mgpu *m, void *out_c64, int dst_shard, int format,
+                        const void *const *channels, const float *weights_c64, int n_channels,
+                        size_t n, int mode);
+int hzsdr_mgpu_synchronize(hzsdr_mgpu *m);
+const char *hzsdr_mgpu_last_error(const hzsdr_mgpu *m);
+
 /* ---- pinned ring in front of a chain -------------------- */
 
 /* The streaming form of a chain for live input: what stream.RingBuffer

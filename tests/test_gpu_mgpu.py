@@ -1,0 +1,73 @@
+"""hzsdr_mgpu_*: Beamform sharded over several contexts of ONE process (what a Go program
+has).  A 1-GPU box exercises the exchange by opening K shards on device 0 (the peer copies
+degenerate to device-to-device copies; the schedule, the slices and the ordered sum are the
+same code).  stream/beamform.go:148-171, stream/add.go:115-119."""
+import importlib
+
+import numpy as np
+import pytest
+
+from util import bits_equal, rand_c64, rand_i16, rand_u8, zeros
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hz():
+    return importlib.import_module("go-sdr_amd")
+
+
+def _run(hz, orc, torch, g, k, n, fmt, mode, dst):
+    gen = {"c64": rand_c64, "u8": rand_u8, "i16": rand_i16}[fmt]
+    chans = [gen(30 + c, n) for c in range(k)]
+    weights = hz.beamform_angles(433e6, 30.0, [0.1 * c for c in range(k)])
+    conv = []
+    for x in chans:  # the per-channel ConvertReader of stream/beamform.go:151
+        y = zeros("c64", n)
+        if fmt == "c64":
+            y[:] = x
+        else:
+            orc.convert(y, x)
+        conv.append(y)
+    want = zeros("c64", n)
+    orc.beamform(want, conv, weights)
+    mg = hz.MultiGpu([0] * g)
+    try:
+        # channel c goes to its owner's context (all on cuda:0 here)
+        dev = [torch.from_numpy(np.ascontiguousarray(c)).cuda() for c in chans]
+        out = torch.zeros(n, dtype=torch.complex64, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(2):  # twice: the second call reuses scratch the first one's sums read
+            mg.beamform(out, dev, weights, dst_shard=dst, mode=mode)
+        mg.synchronize()
+        got = out.cpu().numpy()
+    finally:
+        mg.close()
+    return got, want
+
+
+@pytest.mark.parametrize("g,k", [(2, 4), (4, 4), (3, 7), (4, 2), (1, 4)])
+@pytest.mark.parametrize("fmt", ["c64", "u8"])
+def test_ordered_exchange_is_bit_identical(hz, orc, g, k, fmt):
+    import torch
+    for n, dst in ((100_003, 0), (4096, g - 1), (3, 0)):
+        got, want = _run(hz, orc, torch, g, k, n, fmt, hz.MGPU_ORDERED, dst)
+        assert bits_equal(got, want), (g, k, fmt, n, dst)
+
+
+def test_shard_channels_matches_the_python_partition(hz):
+    mg = importlib.import_module("go-sdr_amd.multigpu")
+    for k in (1, 4, 5, 16):
+        for g in (1, 2, 3, 4, 8):
+            for s in range(g):
+                assert hz.MultiGpu.shard_channels(k, g, s) == mg.shard_channels(k, g, s)
+
+
+def test_rccl_path_single_rank_and_duplicate_gpus(hz, orc):
+    """One shard: ncclCommInitAll over one GPU and a one-rank ncclReduce really run (librccl
+    loaded at run time); several shards on ONE GPU are refused (RCCL wants distinct GPUs)."""
+    import torch
+    got, want = _run(hz, orc, torch, 1, 4, 50_000, "c64", hz.MGPU_RCCL, 0)
+    assert np.allclose(got, want, rtol=0, atol=4e-6)
+    with pytest.raises(hz.ErrInvalidArgument):
+        _run(hz, orc, torch, 2, 4, 1000, "c64", hz.MGPU_RCCL, 0)
