@@ -159,3 +159,36 @@ def test_product_does_not_link_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in text and "import oracle" not in text, os.path.join(dirpath, f)
                 assert "hzsdr_oracle" not in text or f.endswith(".h") and "oracle/hzsdr_oracle.c" in text, f
+
+
+def _header_symbols():
+    import re
+    text = open(os.path.join(ROOT, "include", "hzsdr.h")).read()
+    return sorted(set(re.findall(r"\b(hzsdr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_go_package_binds_every_declaration():
+    """go/hip (cgo, build tag sdr.hip; uncompiled here: no Go toolchain) calls every function
+    include/hzsdr.h declares, and nothing the header does not declare."""
+    import glob
+    import re
+    src = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(ROOT, "go", "hip", "*.go"))))
+    assert "//go:build sdr.hip" in src
+    used = set(re.findall(r"C\.(hzsdr_[a-z0-9_]+)\(", src))
+    declared = set(_header_symbols())
+    assert declared - used == set(), sorted(declared - used)
+    assert used - declared - {"hzsdr_nco_segment"} == set(), sorted(used - declared)
+
+
+def test_plain_c_walkthrough_compiles_as_c99_and_covers_the_header():
+    """tests/c/test_c_abi.c compiles with gcc -std=c99 -Werror against the header alone (no
+    GPU needed to compile) and names every declared function."""
+    import re
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "tests", "c", "test_c_abi.c")
+    with tempfile.TemporaryDirectory() as d:
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                               "-c", src, "-o", os.path.join(d, "t.o")])
+    used = set(re.findall(r"\b(hzsdr_[a-z0-9_]+)\s*\(", open(src).read()))
+    assert set(_header_symbols()) - used == set(), sorted(set(_header_symbols()) - used)

@@ -290,3 +290,21 @@ def test_cxx_host_mirror_runs_reference_kats():
     p = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "all host-mirror tests passed" in p.stdout
+
+
+def test_plain_c_abi_walkthrough():
+    """tests/c/test_c_abi.c: the call sequences of the cgo package go/hip, compiled by gcc as
+    C99 (the compiler cgo hands its preambles to) and run against libhzsdr_hip.so."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "build", "test_c_abi")
+    src = os.path.join(ROOT, "tests", "c", "test_c_abi.c")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-O1", "-I" + os.path.join(ROOT, "include"), src,
+                           "-L" + os.path.join(ROOT, "go-sdr_amd"), "-lhzsdr_hip", "-lm",
+                           "-Wl,-rpath," + os.path.join(ROOT, "go-sdr_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "go-sdr_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    p = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "c-abi ok" in p.stdout
