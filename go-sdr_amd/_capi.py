@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhzsdr_hip.so")
+# HZSDR_LIB: another build of the same library (A/B measurements of two kernels in one GPU call)
+LIB_PATH = os.environ.get("HZSDR_LIB") or os.path.join(_HERE, "libhzsdr_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -371,6 +371,7 @@ static int late_filters(hzsdr_chain *c, const EwProgram &P, size_t n, LateFilter
 static void slow_blocks(const hzsdr_chain *c, const EwProgram &P, const LateFilters &late, size_t n,
                         size_t nblocks, SlowBlocks *out) {
     out->n = 0;
+    if (getenv("HZ_NO_SLOW_FIRST")) return;  // measurement aid (tools/wrap_probe.py): stream order
     const int64_t N = c->nfft, hop = c->hop, off = c->off;
     std::vector<unsigned> v;
     auto add_range = [&](int64_t lo, int64_t hi) {  // blocks lo .. hi inclusive, clipped
@@ -400,6 +401,15 @@ static void slow_blocks(const hzsdr_chain *c, const EwProgram &P, const LateFilt
     if (v.size() > (size_t)kMaxSlowBlocks) return;
     out->n = (int)v.size();
     for (size_t i = 0; i < v.size(); i++) out->idx[i] = v[i];
+    if (getenv("HZ_DEBUG_LATE")) {
+        int nh = 0;
+        for (int r = 0; r < nr; r++) nh += late.h[r] != nullptr;
+        fprintf(stderr, "hzsdr: %d runs, %d with a late filter, %d of %zu blocks listed as reference-order:", nr, nh, out->n, nblocks);
+        for (int i = 0; i < out->n; i++) fprintf(stderr, " %u", out->idx[i]);
+        fprintf(stderr, "\n");
+        for (int r = 0; r < nr; r++)
+            fprintf(stderr, "   run %d first %llu step %.17g filter %p\n", r, (unsigned long long)P.segs.first[r], P.segs.step[r], (const void *)late.h[r]);
+    }
 }
 
 template <int FMT>

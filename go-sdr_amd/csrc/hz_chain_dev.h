@@ -604,11 +604,22 @@ constexpr bool fold_poly(int n, int fold) {
 constexpr bool late_capable(unsigned nfft) { return nfft >= 1024 && nfft <= 8192; }
 
 // workgroup-uniform: does block b (input span [p0, p0 + N)) take the late-mixer path?
+// `group`: lanes per block when they are a whole 32- or 64-lane group of the wave (the run
+// lookup is then one vector load + ballot, nco_window_ballot), 0 = scalar scan.
 __device__ __forceinline__ bool late_block(const EwProgram &P, const LateFilters &late, int64_t p0, int N,
-                                           unsigned off, size_t n_in, NcoWin *run) {
+                                           unsigned off, size_t n_in, NcoWin *run, int group = 0) {
     *run = NcoWin{0, 0};
-    if (p0 < 0 || (uint64_t)p0 + (uint64_t)N + off > n_in) return false;
-    *run = nco_window(P.segs, (uint64_t)p0, (uint64_t)p0 + N - 1);
+    const bool inside = !(p0 < 0 || (uint64_t)p0 + (uint64_t)N + off > n_in);
+    // (a table of a few runs is scanned faster than the vector load's round trip)
+    if (group != 0 && P.segs.big_n == 0 && P.segs.n > 4) {
+        // every lane takes part in the ballot, also those of blocks outside the buffer
+        const NcoWin w = nco_window_ballot(P.segs, inside ? (uint64_t)p0 : 0, inside ? (uint64_t)p0 + N - 1 : 0, group);
+        if (!inside) return false;
+        *run = w;
+    } else {
+        if (!inside) return false;
+        *run = nco_window(P.segs, (uint64_t)p0, (uint64_t)p0 + N - 1);
+    }
     return run->lo == run->hi && late.h[run->lo] != nullptr;
 }
 
@@ -657,19 +668,42 @@ __global__ __launch_bounds__(fv::block(N), fir_occupancy(N, FOLD, LATE)) void fi
         static_assert(fv::xpb(N) == 1, "block reordering assumes one block per workgroup");
         if (b < (size_t)slow.n) {
             b = slow.idx[b];
-        } else if (slow.n > 0) {
-            size_t c = b - slow.n;  // the c-th block that is not in the list
+        } else if (slow.n > 0 && slow.n <= 4) {
+            size_t c = b - slow.n;  // the c-th block that is not in the list: a short scalar scan
 #pragma unroll 1
             for (int i = 0; i < slow.n; i++)
                 if ((size_t)slow.idx[i] <= c) c++;
             b = c;
+        } else if (slow.n > 0) {
+            // the c-th block that is not in the (ascending) list L is c + #{i : L[i] - i <= c}:
+            // lanes compare two entries each (one vector load), a ballot counts -- instead of a
+            // scalar scan with a dependent load per entry in front of every block
+            const size_t c = b - slow.n;
+            const int l = (int)(threadIdx.x & 63u);
+            static_assert(kMaxSlowBlocks <= 128, "two entries per lane");
+            const bool v0 = l < slow.n, v1 = l + 64 < slow.n;
+            const unsigned e0 = slow.idx[v0 ? l : 0], e1 = slow.idx[v1 ? l + 64 : 0];
+            const int k = __popcll(__ballot(v0 && (size_t)(e0 - (unsigned)l) <= c)) +
+                          __popcll(__ballot(v1 && (size_t)(e1 - (unsigned)(l + 64)) <= c));
+            b = c + (size_t)k;
         }
+        // b is the same for the whole workgroup (one block per workgroup), but after the list
+        // lookup the compiler no longer knows: say so, or everything derived from it -- the
+        // block's clock-run window, the per-trip windows of the reference-order staging --
+        // becomes per-lane loops of VECTOR loads from the kernel arguments, each behind
+        // s_waitcnt vmcnt(0) (measured: a reference-order block of a launch whose clock table
+        // has 25 runs took 45 us instead of 14)
+        b = ((size_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)b);
     }
     const bool live = b < nblocks;
     const int64_t p0 = (int64_t)(b * hop) - (int64_t)off;
     bool mix_late = false;  // workgroup-uniform
     NcoWin run{0, 0};
-    if constexpr (LATE) mix_late = late_block(P, late, p0, N, off, n_in, &run);
+    if constexpr (LATE) {
+        mix_late = late_block(P, late, p0, N, off, n_in, &run, 64);
+        run = NcoWin{__builtin_amdgcn_readfirstlane(run.lo), __builtin_amdgcn_readfirstlane(run.hi)};
+    }
     const float2 *__restrict__ hf = mix_late ? late.h[run.lo] : hfreq;
     cf v[16];
     // polyphase form: this lane's entry of pass 2's twiddle rows, fetched before anything else
@@ -845,7 +879,11 @@ __global__ __launch_bounds__((SynthGeom<N, FOLD>::BS)) void fir_synth_kernel16(
     const unsigned i_lo = off / FOLD, i_hi = (off + hop) / FOLD, per = hop / FOLD;
     bool mix_late = false;  // uniform per block (= per group of TPTM lanes)
     NcoWin run{0, 0};
-    if constexpr (LATE) mix_late = live && late_block(P, late, (int64_t)(b * hop) - (int64_t)off, N, off, n_in, &run);
+    if constexpr (LATE) {
+        constexpr int GROUP = (TPTM == 32 || TPTM == 64) ? TPTM : TPTM > 64 ? 64 : 0;
+        const bool lb = late_block(P, late, (int64_t)(b * hop) - (int64_t)off, N, off, live ? n_in : 0, &run, GROUP);
+        mix_late = live && lb;
+    }
     if (live && !mix_late) {
 #pragma unroll
         for (int q = 0; q < 16; q++) {

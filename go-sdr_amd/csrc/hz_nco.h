@@ -65,6 +65,25 @@ __device__ __forceinline__ NcoWin nco_window(const NcoSegs &sg, uint64_t j_lo, u
     return w;
 }
 
+// The run that holds sample j and the run that holds sample j2 >= j, found by the lanes
+// together: lane i compares entry i (ONE vector load of the table, 32 entries), a ballot counts
+// the entries at or below.  `group` lanes (32 or 64, a power of two) starting at a multiple of
+// `group` must call with the same j, j2 (a block's lanes); the inline table only.  The scalar
+// scan of nco_window waits for a dependent scalar load per entry: 24 x ~200 cycles in front
+// of EVERY block of a launch whose clock wraps (25 runs) -- measured, 44 us instead of 34.
+__device__ __forceinline__ NcoWin nco_window_ballot(const NcoSegs &sg, uint64_t j, uint64_t j2, int group) {
+    const int l = (int)(threadIdx.x & (unsigned)(group - 1));
+    const bool valid = l < sg.n && l < kNcoMaxSegs;
+    const uint64_t f = sg.first[valid ? l : 0];
+    const uint64_t le1 = __ballot(valid && f <= j), le2 = __ballot(valid && f <= j2);
+    const int sh = (int)((threadIdx.x & 63u) & ~(unsigned)(group - 1));  // this group's bits of the wave mask
+    const uint64_t m = group >= 64 ? ~0ull : ((1ull << group) - 1);
+    NcoWin w;
+    w.lo = __popcll((le1 >> sh) & m) - 1;  // first[0] = 0 <= j: at least one bit
+    w.hi = __popcll((le2 >> sh) & m) - 1;
+    return w;
+}
+
 // every run: for callers whose sample index is not confined to a span
 __device__ __forceinline__ NcoWin nco_window_all(const NcoSegs &sg) {
     return NcoWin{0, (sg.big_n ? sg.big_n : sg.n) - 1};
