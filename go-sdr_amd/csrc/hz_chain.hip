@@ -43,6 +43,7 @@ struct hzsdr_chain {
     size_t flen = 0;
     // fir-decimate
     void *hfreq = nullptr;  // device, nfft bins (FFT(taps)/nfft)
+    void *hfreq_late = nullptr;  // the same times late_scale() (chains without a Shift; see late_scale)
     void *hist[2] = {nullptr, nullptr};
     int hist_cur = 0;
     size_t ntaps = 0;
@@ -234,7 +235,7 @@ static void host_fft(std::vector<double> &re, std::vector<double> &im, size_t of
 // fold_poly).  `taps`: ntaps complex values (real, imaginary) in host memory, float64;
 // `dst`: N complex64 of device memory.  Uploaded through the context's stream; returns
 // after the copy has completed (the staging vector is local).
-static int filter_spectrum(hzsdr_chain *c, const double *taps, void *dst) {
+static int filter_spectrum(hzsdr_chain *c, const double *taps, void *dst, double extra_scale = 1.0) {
     hzsdr_ctx *ctx = c->ctx;
     const unsigned nfft = c->nfft;
     std::vector<double> re(nfft, 0.0), im(nfft, 0.0);
@@ -258,7 +259,7 @@ static int filter_spectrum(hzsdr_chain *c, const double *taps, void *dst) {
     }
     for (size_t t = 0; t < batch; t++) host_fft(re, im, t * len, len);
     std::vector<float> h(2 * (size_t)nfft);
-    const double scale = 1.0 / (double)len;
+    const double scale = extra_scale / (double)len;
     for (size_t i = 0; i < nfft; i++) {
         h[2 * i] = (float)(re[i] * scale);
         h[2 * i + 1] = (float)(im[i] * scale);
@@ -267,6 +268,13 @@ static int filter_spectrum(hzsdr_chain *c, const double *taps, void *dst) {
     HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HZSDR_OK;
 }
+
+// LATE blocks of a u8 source feed the transform b - 127.5 (exact in float32) instead of the
+// converter's (b - 127.5) / 127.5: the division's scale moves into the late filters' spectra
+// (formed in float64), three packed instructions per sample instead of five in the analysis
+// kernel.  The converter's per-sample rounding (half an ulp, which the reference-order path
+// and the oracle do perform) is thereby skipped: ~3e-8 relative, inside the FIR's error bound.
+static double late_scale(const hzsdr_chain *c) { return c->src_fmt == HZSDR_FMT_U8 ? 1.0 / 127.5 : 1.0; }
 
 // The spectrum of taps[k] * exp(-i * omega * k * step) for one clock step.  A miss uploads,
 // transforms and WAITS (filter_spectrum), so callers on the streaming path only look up
@@ -295,7 +303,7 @@ static int late_filter_for(hzsdr_chain *c, double step, double omega, void **dev
     }
     void *h = nullptr;
     HZ_HIP(ctx, hipMalloc(&h, (size_t)c->nfft * 8));
-    int rc = filter_spectrum(c, mod.data(), h);
+    int rc = filter_spectrum(c, mod.data(), h, late_scale(c));
     if (rc != HZSDR_OK) {
         (void)hipFree(h);
         return rc;
@@ -345,7 +353,7 @@ static int late_filters(hzsdr_chain *c, const EwProgram &P, size_t n, LateFilter
     if (!c->has_shift) {
         // no clock involved: Gain / Multiply commute with the filter everywhere, with the
         // taps as they are (the kernel sees an empty run table: run 0)
-        out->h[0] = (const float2 *)c->hfreq;
+        out->h[0] = (const float2 *)(c->hfreq_late ? c->hfreq_late : c->hfreq);
         *any = true;
         return HZSDR_OK;
     }
@@ -675,12 +683,16 @@ int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps, size_t n_taps, u
         HZ_HIP(ctx, hipMemsetAsync(c->hist[0], 0, hb, ctx->stream));
         HZ_HIP(ctx, hipMemsetAsync(c->hist[1], 0, hb, ctx->stream));
         HZ_TRY(filter_spectrum(c, c->taps_host.data(), c->hfreq));
+        if (late_scale(c) != 1.0) {
+            HZ_HIP(ctx, hipMalloc(&c->hfreq_late, (size_t)nfft * 8));
+            HZ_TRY(filter_spectrum(c, c->taps_host.data(), c->hfreq_late, late_scale(c)));
+        }
         return prepare_late_filters(c, c->ts);
     };
     const int rc = build();
     if (rc != HZSDR_OK) {
         (void)hipStreamSynchronize(ctx->stream);
-        for (void **p : {&c->hfreq, &c->hist[0], &c->hist[1]}) {
+        for (void **p : {&c->hfreq, &c->hfreq_late, &c->hist[0], &c->hist[1]}) {
             if (*p) (void)hipFree(*p);
             *p = nullptr;
         }
@@ -782,6 +794,7 @@ int hzsdr_chain_free(hzsdr_chain *c) {
     (void)hipStreamSynchronize(c->ctx->stream);
     if (c->filt) (void)hipFree(c->filt);
     if (c->hfreq) (void)hipFree(c->hfreq);
+    if (c->hfreq_late) (void)hipFree(c->hfreq_late);
     if (c->hist[0]) (void)hipFree(c->hist[0]);
     if (c->hist[1]) (void)hipFree(c->hist[1]);
     for (auto &kv : c->late_cache) (void)hipFree(kv.second);

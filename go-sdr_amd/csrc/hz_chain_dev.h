@@ -148,18 +148,25 @@ template <int FMT> struct Raw;
 template <> struct Raw<HZSDR_FMT_C64> {
     using t = float2;
     static __device__ __forceinline__ float2 cvt(float2 r) { return r; }
+    static __device__ __forceinline__ float2 cvt_late(float2 r) { return r; }
 };
 template <> struct Raw<HZSDR_FMT_U8> {
     using t = uint16_t;
     static __device__ __forceinline__ float2 cvt(uint16_t r) { return make_float2(u8_to_f32(r & 0xFF), u8_to_f32(r >> 8)); }
+    // b - 127.5, the converter without its division (late blocks: the 1/127.5 is in the filter)
+    static __device__ __forceinline__ float2 cvt_late(uint16_t r) {
+        return make_float2(__fsub_rn((float)(r & 0xFF), 127.5f), __fsub_rn((float)(r >> 8), 127.5f));
+    }
 };
 template <> struct Raw<HZSDR_FMT_I8> {
     using t = uint16_t;
     static __device__ __forceinline__ float2 cvt(uint16_t r) { return make_float2(i8_to_f32((int8_t)(r & 0xFF)), i8_to_f32((int8_t)(r >> 8))); }
+    static __device__ __forceinline__ float2 cvt_late(uint16_t r) { return cvt(r); }
 };
 template <> struct Raw<HZSDR_FMT_I16> {
     using t = uint32_t;
     static __device__ __forceinline__ float2 cvt(uint32_t r) { return make_float2(i16_to_f32((int16_t)(r & 0xFFFF)), i16_to_f32((int16_t)(r >> 16))); }
+    static __device__ __forceinline__ float2 cvt_late(uint32_t r) { return cvt(r); }
 };
 
 // sample j of the buffer after conversion and the elementwise stages
@@ -727,7 +734,7 @@ __global__ __launch_bounds__(fv::block(N), fir_occupancy(N, FOLD, LATE)) void fi
 #pragma unroll
         for (int q = 0; q < 16; q++) raw[q] = (EXP & 1) ? (R)(lane * 3 + q) : src[fv::edge_off<N, RIN>(q)];
 #pragma unroll
-        for (int q = 0; q < 16; q++) v[q] = fv::from2(Raw<FMT>::cvt(raw[q]));
+        for (int q = 0; q < 16; q++) v[q] = fv::from2(Raw<FMT>::cvt_late(raw[q]));
     } else {
         stage_block16<N, FMT, true>((float2 *)lds, in, P, p0, n_in, hist, off, lane, live, new_hist);
         __syncthreads();
