@@ -1,11 +1,10 @@
 // hz_fft.hip -- fft.Planner / fft.Plan (fft/fft.go:45-59) and the two-input
 // fft.Convolve / fft.CrossCorrelate closures (fft/convolution.go:30-138).
 //
-// N in [4, 8192]: one LDS-resident kernel per Transform (hz_fft.h).  Other
-// powers of two (1, 2, > 8192) take a plain global-memory Stockham radix-2 path:
-// correct, unoptimised (the 64 Ki-point kerberos sizes are a "next" row).
+// N in [4, 8192]: one LDS-resident kernel per Transform (hz_fft.h below 256 points, the
+// packed-math core hz_fftv.h from 256 up); 2^14 .. 2^24 (kerberos: 64 Ki, graft: 256 Ki) in
+// two steps, N = N1 * N2, two passes over HBM; N = 1, 2 by a plain global-memory radix-2 pass.
 #include "hz_fft.h"
-#include "hz_fft16.h"
 #include "hz_fftv.h"
 
 #include <math.h>
@@ -183,54 +182,65 @@ __global__ __launch_bounds__(fft_block(N), fft_waves(N)) void fft_plan_kernel(co
     }
 }
 
-// radix-16 core (hz_fft16.h), N = 256 .. 4096
+// packed-math core (hz_fftv.h), N = 256 .. 8192; dynamic LDS (N = 8192 needs 68 KiB)
 template <int N, bool FWD>
-__global__ __launch_bounds__(f16::block(N)) void fft_plan_kernel16(const float2 *__restrict__ in,
-                                                                   float2 *__restrict__ out,
-                                                                   const float2 *__restrict__ tw,
-                                                                   size_t batch) {
-    constexpr int TPT = f16::tpt(N), XPB = f16::xpb(N), R0 = f16::first_radix(N);
-    __shared__ float2 lds_all[XPB * f16::lds_elems(N)];
+__global__ __launch_bounds__(fv::block(N)) void fft_plan_kernel16(const float2 *__restrict__ in,
+                                                                  float2 *__restrict__ out, fv::FvTabs tabs,
+                                                                  size_t batch) {
+    using fv::cf;
+    constexpr int TPT = fv::tpt(N), XPB = fv::xpb(N), R0 = fv::first_radix(N);
+    extern __shared__ __attribute__((aligned(16))) unsigned char hz_dyn_lds_fft[];
     const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
-    float2 *lds = lds_all + sub * f16::lds_elems(N);
+    cf *lds = reinterpret_cast<cf *>(hz_dyn_lds_fft) + sub * fv::lds_elems(N);
     const size_t t = (size_t)blockIdx.x * XPB + sub;
     const bool live = t < batch;
-    const float2 *src = in + t * N;
-    float2 *dst = out + t * N;
-    float2 v[16];
+    const cf *src = (const cf *)in + t * N + lane;
+    cf *dst = (cf *)out + t * N + lane;
+    cf v[16];
     // time side = radix-R0 edge layout, frequency side = radix-16 edge layout
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const int idx = FWD ? f16::edge_index<N, R0>(q, lane) : f16::edge_index<N, 16>(q, lane);
-        v[q] = live ? src[idx] : make_float2(0.f, 0.f);
-    }
-    if constexpr (FWD) f16::forward<N>(v, lds, tw, lane); else f16::backward<N>(v, lds, tw, lane);
+    for (int q = 0; q < 16; q++) v[q] = live ? src[FWD ? fv::edge_off<N, R0>(q) : fv::edge_off<N, 16>(q)] : cf{0.f, 0.f};
+    if constexpr (FWD) fv::forward<N>(v, lds, tabs.fwd, lane); else fv::backward<N>(v, lds, tabs.bwd, lane);
     if (live) {
 #pragma unroll
-        for (int q = 0; q < 16; q++)
-            dst[FWD ? f16::edge_index<N, 16>(q, lane) : f16::edge_index<N, R0>(q, lane)] = v[q];
+        for (int q = 0; q < 16; q++) dst[FWD ? fv::edge_off<N, 16>(q) : fv::edge_off<N, R0>(q)] = v[q];
     }
 }
 
-template <int N>
-static void launch_plan_n(hzsdr_ctx *ctx, const float2 *in, float2 *out, const float2 *tw, size_t batch,
-                          bool fwd) {
-    if constexpr (f16::ok(N)) {
-        constexpr int XPB16 = f16::xpb(N);
-        const dim3 grid16((unsigned)((batch + XPB16 - 1) / XPB16)), block16(f16::block(N));
-        if (fwd)
-            hipLaunchKernelGGL((fft_plan_kernel16<N, true>), grid16, block16, 0, ctx->stream, in, out, tw, batch);
-        else
-            hipLaunchKernelGGL((fft_plan_kernel16<N, false>), grid16, block16, 0, ctx->stream, in, out, tw, batch);
-        return;
+template <class K, class... A>
+static void launch_dyn(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, A... args) {
+    if (lds > 48 * 1024) {
+        static bool raised = false;  // per kernel instantiation
+        if (!raised) {
+            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            raised = true;
+        }
     }
-    constexpr int XPB = fft_xpb(N);
-    size_t groups = (batch + XPB - 1) / XPB;
-    unsigned grid = (unsigned)groups;
-    if (fwd)
-        hipLaunchKernelGGL((fft_plan_kernel<N, true>), dim3(grid), dim3(fft_block(N)), 0, ctx->stream, in, out, tw, batch);
-    else
-        hipLaunchKernelGGL((fft_plan_kernel<N, false>), dim3(grid), dim3(fft_block(N)), 0, ctx->stream, in, out, tw, batch);
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
+}
+
+template <int N>
+static int launch_plan_n(hzsdr_ctx *ctx, const float2 *in, float2 *out, const float2 *tw, size_t batch,
+                         bool fwd) {
+    if constexpr (fv::ok(N)) {
+        fv::FvTabs tabs{};
+        HZ_TRY(get_fv_tables(ctx, N, &tabs));
+        constexpr int XPB16 = fv::xpb(N);
+        const dim3 grid16((unsigned)((batch + XPB16 - 1) / XPB16)), block16(fv::block(N));
+        const size_t lds = (size_t)XPB16 * fv::lds_elems(N) * sizeof(fv::cf);
+        if (fwd) launch_dyn(fft_plan_kernel16<N, true>, grid16, block16, lds, ctx->stream, in, out, tabs, batch);
+        else launch_dyn(fft_plan_kernel16<N, false>, grid16, block16, lds, ctx->stream, in, out, tabs, batch);
+        return HZSDR_OK;
+    } else {
+        constexpr int XPB = fft_xpb(N);
+        size_t groups = (batch + XPB - 1) / XPB;
+        unsigned grid = (unsigned)groups;
+        if (fwd)
+            hipLaunchKernelGGL((fft_plan_kernel<N, true>), dim3(grid), dim3(fft_block(N)), 0, ctx->stream, in, out, tw, batch);
+        else
+            hipLaunchKernelGGL((fft_plan_kernel<N, false>), dim3(grid), dim3(fft_block(N)), 0, ctx->stream, in, out, tw, batch);
+        return HZSDR_OK;
+    }
 }
 
 // ---- generic global-memory path ---------------------------------------------------------
@@ -285,7 +295,7 @@ static int fft_global(hzsdr_ctx *ctx, const float2 *in, float2 *out, size_t n, s
 //   X[k1 + N1*k2] = sum_n2 W_N2^(n2 k2) * [ W_N^(n2 k1) * sum_n1 x[N2*n1 + n2] W_N1^(n1 k1) ]
 //
 // Kernel 1 ("columns"): a workgroup takes C = 4096/N1 adjacent columns n2, runs their
-// N1-point transforms on the radix-16 core, applies the W_N^(n2 k1) twiddle and writes
+// N1-point transforms on the packed-math core, applies the W_N^(n2 k1) twiddle and writes
 // A[k1][n2].  Lanes are mapped column-fastest, so both the strided input rows and the
 // A rows are touched in C*8-byte contiguous pieces.
 // Kernel 2 ("rows"): a workgroup takes C = 4096/N2 adjacent rows k1 of A (contiguous
@@ -301,66 +311,106 @@ struct BigTw {
 
 __device__ __forceinline__ float2 big_twiddle(const BigTw &t, uint32_t m, bool inv) {
     const float2 a = t.hi[m >> t.s], b = t.lo[m & ((1u << t.s) - 1)];
-    float2 w = f16::cmul(a, b);
+    float2 w = cmulf(a, b);
     if (inv) w.y = -w.y;
     return w;
 }
 
 template <int N1, bool FWD>
 __global__ __launch_bounds__(256) void fft2_cols_kernel(const float2 *__restrict__ in, float2 *__restrict__ a_out,
-                                                        const float2 *__restrict__ tw1, BigTw bt,
-                                                        uint32_t n2_total) {
-    constexpr int C = 4096 / N1, TPT = f16::tpt(N1), R0 = f16::first_radix(N1);
+                                                        fv::FvTabs tabs, BigTw bt, uint32_t n2_total) {
+    using fv::cf;
+    constexpr int C = 4096 / N1, TPT = fv::tpt(N1), R0 = fv::first_radix(N1);
     static_assert(C * TPT == 256, "one 256-lane workgroup per column tile");
-    __shared__ float2 lds_all[C * f16::lds_elems(N1)];
+    __shared__ cf lds_all[C * fv::lds_elems(N1)];
     const int sub = threadIdx.x % C, lane = threadIdx.x / C;  // column-fastest
-    float2 *lds = lds_all + sub * f16::lds_elems(N1);
+    cf *lds = lds_all + sub * fv::lds_elems(N1);
     const uint32_t n2 = blockIdx.x * C + sub;
     const size_t base = (size_t)blockIdx.y * N1 * n2_total;  // batch
-    float2 v[16];
+    cf v[16];
 #pragma unroll
     for (int q = 0; q < 16; q++) {
-        const int n1 = FWD ? f16::edge_index<N1, R0>(q, lane) : f16::edge_index<N1, 16>(q, lane);
-        v[q] = in[base + (size_t)n1 * n2_total + n2];
+        const int n1 = FWD ? fv::edge_index<N1, R0>(q, lane) : fv::edge_index<N1, 16>(q, lane);
+        v[q] = fv::from2(in[base + (size_t)n1 * n2_total + n2]);
     }
-    if constexpr (FWD) f16::forward<N1>(v, lds, tw1, lane); else f16::backward<N1>(v, lds, tw1, lane);
+    if constexpr (FWD) fv::forward<N1>(v, lds, tabs.fwd, lane); else fv::backward<N1>(v, lds, tabs.bwd, lane);
 #pragma unroll
     for (int q = 0; q < 16; q++) {
-        const uint32_t k1 = FWD ? f16::edge_index<N1, 16>(q, lane) : f16::edge_index<N1, R0>(q, lane);
+        const uint32_t k1 = FWD ? fv::edge_index<N1, 16>(q, lane) : fv::edge_index<N1, R0>(q, lane);
         const float2 w = big_twiddle(bt, n2 * k1, !FWD);
-        a_out[base + (size_t)k1 * n2_total + n2] = f16::cmul(v[q], w);
+        a_out[base + (size_t)k1 * n2_total + n2] = fv::to2(fv::cmul(v[q], fv::from2(w)));
     }
 }
 
 template <int N2, bool FWD>
 __global__ __launch_bounds__(256) void fft2_rows_kernel(const float2 *__restrict__ a_in, float2 *__restrict__ out,
-                                                        const float2 *__restrict__ tw2, uint32_t n1_total) {
-    constexpr int C = 4096 / N2, TPT = f16::tpt(N2), R0 = f16::first_radix(N2);
+                                                        fv::FvTabs tabs, uint32_t n1_total) {
+    using fv::cf;
+    constexpr int C = 4096 / N2, TPT = fv::tpt(N2), R0 = fv::first_radix(N2);
     static_assert(C * TPT == 256, "one 256-lane workgroup per row tile");
-    __shared__ float2 lds_all[C * f16::lds_elems(N2)];
+    __shared__ cf lds_all[C * fv::lds_elems(N2)];
     const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;  // lane-fastest: rows are contiguous
-    float2 *lds = lds_all + sub * f16::lds_elems(N2);
+    cf *lds = lds_all + sub * fv::lds_elems(N2);
     const uint32_t k1 = blockIdx.x * C + sub;
     const size_t base = (size_t)blockIdx.y * N2 * n1_total;
-    float2 v[16];
+    cf v[16];
 #pragma unroll
     for (int q = 0; q < 16; q++) {
-        const int n2 = FWD ? f16::edge_index<N2, R0>(q, lane) : f16::edge_index<N2, 16>(q, lane);
-        v[q] = a_in[base + (size_t)k1 * N2 + n2];
+        const int n2 = FWD ? fv::edge_index<N2, R0>(q, lane) : fv::edge_index<N2, 16>(q, lane);
+        v[q] = fv::from2(a_in[base + (size_t)k1 * N2 + n2]);
     }
-    if constexpr (FWD) f16::forward<N2>(v, lds, tw2, lane); else f16::backward<N2>(v, lds, tw2, lane);
+    if constexpr (FWD) fv::forward<N2>(v, lds, tabs.fwd, lane); else fv::backward<N2>(v, lds, tabs.bwd, lane);
     __syncthreads();  // the transform's last LDS reads are done
 #pragma unroll
     for (int q = 0; q < 16; q++) {
-        const int k2 = FWD ? f16::edge_index<N2, 16>(q, lane) : f16::edge_index<N2, R0>(q, lane);
-        lds[f16::pad(k2)] = v[q];
+        const int k2 = FWD ? fv::edge_index<N2, 16>(q, lane) : fv::edge_index<N2, R0>(q, lane);
+        lds[fv::pad(k2)] = v[q];
     }
     __syncthreads();
     // X[k1 + N1*k2]: C adjacent k1 per k2
     for (int e = threadIdx.x; e < C * N2; e += 256) {
         const int s2 = e % C, k2 = e / C;
-        out[base + (size_t)k2 * n1_total + blockIdx.x * C + s2] = lds_all[s2 * f16::lds_elems(N2) + f16::pad(k2)];
+        out[base + (size_t)k2 * n1_total + blockIdx.x * C + s2] = fv::to2(lds_all[s2 * fv::lds_elems(N2) + fv::pad(k2)]);
     }
+}
+
+// rows of 64 or 128 points (N = 2^14, 2^15: N1 = 256 columns on the packed-math core, the
+// short rows on the radix-4 core of hz_fft.h, four points per lane)
+template <int N2, bool FWD>
+__global__ __launch_bounds__(256) void fft2_rows_small_kernel(const float2 *__restrict__ a_in, float2 *__restrict__ out,
+                                                              const float2 *__restrict__ tw2, uint32_t n1_total) {
+    constexpr int TPT = fft_tpt(N2), C = 256 / TPT, CNT = N2 / TPT;
+    __shared__ float2 lds_all[C * N2];
+    const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
+    float2 *lds = lds_all + sub * N2;
+    const uint32_t k1 = blockIdx.x * C + sub;
+    const size_t base = (size_t)blockIdx.y * N2 * n1_total;
+    FftRegs<N2> R;
+#pragma unroll
+    for (int q = 0; q < CNT; q++) {
+        const int n2 = FWD ? (fft_odd(N2) ? edge2_index<N2>(q, lane) : edge4_index<N2>(q, lane)) : edge4_index<N2>(q, lane);
+        R.v[q] = a_in[base + (size_t)k1 * N2 + n2];
+    }
+    if constexpr (FWD) fft_forward_regs<N2>(R, lds, tw2, lane); else fft_backward_regs<N2>(R, lds, tw2, lane);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < CNT; q++) {
+        const int k2 = FWD ? edge4_index<N2>(q, lane) : (fft_odd(N2) ? edge2_index<N2>(q, lane) : edge4_index<N2>(q, lane));
+        lds[k2] = R.v[q];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C * N2; e += 256) {
+        const int s2 = e % C, k2 = e / C;
+        out[base + (size_t)k2 * n1_total + blockIdx.x * C + s2] = lds_all[s2 * N2 + k2];
+    }
+}
+
+template <int N2> static void launch_rows_small(hzsdr_ctx *ctx, const float2 *a, float2 *out, const float2 *tw2,
+                                                size_t n1, size_t batch, bool fwd) {
+    constexpr int C = 256 / fft_tpt(N2);
+    dim3 grid((unsigned)(n1 / C), (unsigned)batch);
+    if (fwd) hipLaunchKernelGGL((fft2_rows_small_kernel<N2, true>), grid, dim3(256), 0, ctx->stream, a, out, tw2, (uint32_t)n1);
+    else hipLaunchKernelGGL((fft2_rows_small_kernel<N2, false>), grid, dim3(256), 0, ctx->stream, a, out, tw2, (uint32_t)n1);
 }
 
 static int get_big_twiddles(hzsdr_ctx *ctx, size_t n, BigTw *bt) {
@@ -397,14 +447,14 @@ static int get_big_twiddles(hzsdr_ctx *ctx, size_t n, BigTw *bt) {
     return HZSDR_OK;
 }
 
-template <int N1> static void launch_cols(hzsdr_ctx *ctx, const float2 *in, float2 *a, const float2 *tw1,
+template <int N1> static void launch_cols(hzsdr_ctx *ctx, const float2 *in, float2 *a, const fv::FvTabs &tw1,
                                           const BigTw &bt, size_t n2, size_t batch, bool fwd) {
     constexpr int C = 4096 / N1;
     dim3 grid((unsigned)(n2 / C), (unsigned)batch);
     if (fwd) hipLaunchKernelGGL((fft2_cols_kernel<N1, true>), grid, dim3(256), 0, ctx->stream, in, a, tw1, bt, (uint32_t)n2);
     else hipLaunchKernelGGL((fft2_cols_kernel<N1, false>), grid, dim3(256), 0, ctx->stream, in, a, tw1, bt, (uint32_t)n2);
 }
-template <int N2> static void launch_rows(hzsdr_ctx *ctx, const float2 *a, float2 *out, const float2 *tw2,
+template <int N2> static void launch_rows(hzsdr_ctx *ctx, const float2 *a, float2 *out, const fv::FvTabs &tw2,
                                           size_t n1, size_t batch, bool fwd) {
     constexpr int C = 4096 / N2;
     dim3 grid((unsigned)(n1 / C), (unsigned)batch);
@@ -412,19 +462,21 @@ template <int N2> static void launch_rows(hzsdr_ctx *ctx, const float2 *a, float
     else hipLaunchKernelGGL((fft2_rows_kernel<N2, false>), grid, dim3(256), 0, ctx->stream, a, out, tw2, (uint32_t)n1);
 }
 
-static bool fft_two_step_ok(size_t n) { return n >= ((size_t)1 << 16) && n <= ((size_t)1 << 24) && (n & (n - 1)) == 0; }
+static bool fft_two_step_ok(size_t n) { return n >= ((size_t)1 << 14) && n <= ((size_t)1 << 24) && (n & (n - 1)) == 0; }
 
 static int fft_two_step(hzsdr_ctx *ctx, const float2 *in, float2 *out, size_t n, size_t batch, bool fwd) {
     int L = 0;
     while (((size_t)1 << L) < n) L++;
-    // N1 as small as the radix-16 core allows (best column coalescing), N2 = N / N1 <= 4096
+    // N1 as small as the packed-math core allows (best column coalescing), N2 = N / N1 <= 4096
     int l1 = 8;
     while (L - l1 > 12) l1++;
     const size_t n1 = (size_t)1 << l1, n2 = n >> l1;
-    const float2 *tw1, *tw2;
+    fv::FvTabs tw1{}, tw2{};
+    const float2 *tw2s = nullptr;
     BigTw bt;
-    HZ_TRY(get_twiddles(ctx, n1, &tw1));
-    HZ_TRY(get_twiddles(ctx, n2, &tw2));
+    HZ_TRY(get_fv_tables(ctx, n1, &tw1));
+    if (n2 >= 256) HZ_TRY(get_fv_tables(ctx, n2, &tw2));
+    else HZ_TRY(get_twiddles(ctx, n2, &tw2s));
     HZ_TRY(get_big_twiddles(ctx, n, &bt));
     HZ_TRY(ensure_slot(ctx, 10, n * batch * sizeof(float2)));
     float2 *a = (float2 *)ctx->slots[10].ptr;
@@ -436,6 +488,8 @@ static int fft_two_step(hzsdr_ctx *ctx, const float2 *in, float2 *out, size_t n,
     default: launch_cols<4096>(ctx, in, a, tw1, bt, n2, batch, fwd); break;
     }
     switch (n2) {
+    case 64: launch_rows_small<64>(ctx, a, out, tw2s, n1, batch, fwd); break;
+    case 128: launch_rows_small<128>(ctx, a, out, tw2s, n1, batch, fwd); break;
     case 256: launch_rows<256>(ctx, a, out, tw2, n1, batch, fwd); break;
     case 512: launch_rows<512>(ctx, a, out, tw2, n1, batch, fwd); break;
     case 1024: launch_rows<1024>(ctx, a, out, tw2, n1, batch, fwd); break;
@@ -452,24 +506,23 @@ int fft_device(hzsdr_ctx *ctx, const void *in, void *out, size_t n, size_t batch
     float2 *o = (float2 *)out;
     if (fft_two_step_ok(n)) return fft_two_step(ctx, i, o, n, batch, fwd);
     if (!fft_lds_ok(n)) return fft_global(ctx, i, o, n, batch, fwd);
-    const float2 *tw;
-    HZ_TRY(get_twiddles(ctx, n, &tw));
+    const float2 *tw = nullptr;
+    if (!fv::ok((int)n)) HZ_TRY(get_twiddles(ctx, n, &tw));
     switch (n) {
-    case 4: launch_plan_n<4>(ctx, i, o, tw, batch, fwd); break;
-    case 8: launch_plan_n<8>(ctx, i, o, tw, batch, fwd); break;
-    case 16: launch_plan_n<16>(ctx, i, o, tw, batch, fwd); break;
-    case 32: launch_plan_n<32>(ctx, i, o, tw, batch, fwd); break;
-    case 64: launch_plan_n<64>(ctx, i, o, tw, batch, fwd); break;
-    case 128: launch_plan_n<128>(ctx, i, o, tw, batch, fwd); break;
-    case 256: launch_plan_n<256>(ctx, i, o, tw, batch, fwd); break;
-    case 512: launch_plan_n<512>(ctx, i, o, tw, batch, fwd); break;
-    case 1024: launch_plan_n<1024>(ctx, i, o, tw, batch, fwd); break;
-    case 2048: launch_plan_n<2048>(ctx, i, o, tw, batch, fwd); break;
-    case 4096: launch_plan_n<4096>(ctx, i, o, tw, batch, fwd); break;
-    case 8192: launch_plan_n<8192>(ctx, i, o, tw, batch, fwd); break;
+    case 4: return launch_plan_n<4>(ctx, i, o, tw, batch, fwd);
+    case 8: return launch_plan_n<8>(ctx, i, o, tw, batch, fwd);
+    case 16: return launch_plan_n<16>(ctx, i, o, tw, batch, fwd);
+    case 32: return launch_plan_n<32>(ctx, i, o, tw, batch, fwd);
+    case 64: return launch_plan_n<64>(ctx, i, o, tw, batch, fwd);
+    case 128: return launch_plan_n<128>(ctx, i, o, tw, batch, fwd);
+    case 256: return launch_plan_n<256>(ctx, i, o, tw, batch, fwd);
+    case 512: return launch_plan_n<512>(ctx, i, o, tw, batch, fwd);
+    case 1024: return launch_plan_n<1024>(ctx, i, o, tw, batch, fwd);
+    case 2048: return launch_plan_n<2048>(ctx, i, o, tw, batch, fwd);
+    case 4096: return launch_plan_n<4096>(ctx, i, o, tw, batch, fwd);
+    case 8192: return launch_plan_n<8192>(ctx, i, o, tw, batch, fwd);
     default: return HZSDR_ERR_INVALID_ARGUMENT;
     }
-    return HZSDR_OK;
 }
 
 // f1[i] = f1[i] * f2[i] or f1[i] * conj(f2[i]) with Go complex64 semantics
@@ -510,8 +563,12 @@ int hzsdr_fft_plan_batch(hzsdr_ctx *ctx, void *iq, void *freq, size_t n, size_t 
     if (batch == 0 || !iq || !freq) return HZSDR_ERR_INVALID_ARGUMENT;
     if (direction != HZSDR_FFT_FORWARD && direction != HZSDR_FFT_BACKWARD) return HZSDR_ERR_INVALID_ARGUMENT;
     HZ_TRY(enter(ctx));
-    const float2 *tw;
-    if (n > 1) HZ_TRY(get_twiddles(ctx, n, &tw));  // plan-time cost, like any planner
+    if (n > 1) {  // plan-time cost, like any planner
+        const float2 *tw;
+        fv::FvTabs tabs{};
+        if (fv::ok((int)n)) HZ_TRY(get_fv_tables(ctx, n, &tabs));
+        else if (n <= 128) HZ_TRY(get_twiddles(ctx, n, &tw));
+    }
     *out = new hzsdr_fft{ctx, iq, freq, n, batch, direction == HZSDR_FFT_FORWARD};
     return HZSDR_OK;
 }

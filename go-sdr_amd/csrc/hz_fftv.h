@@ -1,6 +1,6 @@
 // hz_fftv.h -- workgroup FFT core, third generation, N = 256 .. 8192.
 //
-// Same decomposition as hz_fft16.h -- sixteen points per lane, N/16 lanes per transform,
+// Sixteen points per lane, N/16 lanes per transform,
 // Stockham passes of radix 16 (4 x 4) with one smaller first (forward) / last (backward)
 // pass, LDS padded one element per 16:
 //
