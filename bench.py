@@ -238,15 +238,15 @@ def main():
     chain.close()
     # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc
     # passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_summary.py), not from this process.
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
     if n == (1 << 24) and os.path.exists(tpath):
         try:
             tk = json.load(open(tpath))["kernels"]
-            keys = [k for k in tk if "fir_decimate_kernel16<4096, 2, 8, true>" in k
+            keys = [k for k in tk if "fir_decimate_kernel16<4096, 2, 8, true" in k
                     or "fir_synth_kernel16<4096, 8, true>" in k]
             if len(keys) == 2:
                 result["roofline"]["traffic"] = sum(tk[k]["hbm_bytes"] for k in keys)
-                result["roofline"]["traffic_source"] = ("profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + "
+                result["roofline"]["traffic_source"] = ("profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + "
                                                         "WRITE_SIZE, both kernels of a chain_run)")
         except (StopIteration, KeyError, ValueError):
             pass

@@ -420,6 +420,14 @@ static void slow_blocks(const hzsdr_chain *c, const EwProgram &P, const LateFilt
     }
 }
 
+// workgroups of fir_decimate_kernel16: with the late mixer, the listed blocks first, then the
+// rest in eight contiguous runs (one per XCD), padded to whole rounds of eight
+static unsigned fir_grid(size_t nblocks, int xpb, bool late, int n_slow) {
+    if (!late) return (unsigned)((nblocks + xpb - 1) / xpb);
+    const size_t rest = nblocks - (size_t)n_slow;
+    return (unsigned)(n_slow + 8 * ((rest + 7) / 8));
+}
+
 template <int FMT>
 static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, size_t n_out,
                    const EwProgram &P) {
@@ -451,7 +459,7 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
         SlowBlocks slow{};
 // packed-math core: fold when D is a power of two <= 16 and N/D is itself a core size
 #define HZ_FIR16_L(N, FOLD, LATE, SPEC)                                                                        \
-    launch_fv(fir_decimate_kernel16<N, FMT, FOLD, LATE>, dim3((unsigned)((nblocks + fv::xpb(N) - 1) / fv::xpb(N))), \
+    launch_fv(fir_decimate_kernel16<N, FMT, FOLD, LATE>, dim3(fir_grid(nblocks, fv::xpb(N), LATE, slow.n)),      \
               dim3(fv::block(N)), fir_lds_bytes(N, FOLD), ctx->stream, in,                                      \
               (float2 *)out, hist, nhist, (const float2 *)c->hfreq, tabs, SPEC, nblocks, n_cons, c->hop, c->off, D, \
               P, late, ptabs, slow)

@@ -680,6 +680,18 @@ __global__ __launch_bounds__(fv::block(N), fir_occupancy(N, FOLD, LATE)) void fi
         // stream order they would be the kernel's tail whenever a boundary falls late in the
         // buffer, so the host lists them (sorted) and they are dispatched first
         static_assert(fv::xpb(N) == 1, "block reordering assumes one block per workgroup");
+        // The other blocks go to the XCDs in contiguous runs: workgroups are dealt round-robin
+        // over the eight XCDs (a placement used for speed only), so workgroup i takes the
+        // (i / 8)-th block of run i % 8 and stream neighbours share an L2 -- the N - hop
+        // samples two consecutive blocks have in common are then fetched from HBM once, not
+        // twice (measured at the fabric: 45.5 MB read for 33.5 MB of input before).  The grid
+        // is padded to a whole number of rounds; the surplus workgroups leave at once.
+        if (b >= (size_t)slow.n) {
+            const size_t rest = nblocks - slow.n, chunk = (rest + 7) / 8, i = b - slow.n;
+            const size_t c = (i % 8) * chunk + i / 8;
+            if (i / 8 >= chunk || c >= rest) return;  // whole workgroup
+            b = c + slow.n;
+        }
         if (b < (size_t)slow.n) {
             b = slow.idx[b];
         } else if (slow.n > 0 && slow.n <= 4) {

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Collects the round's evidence on the GPU box into gpurun_out/prof_$1 (copy what is to be
+# judged into profiles/ afterwards):  kernel stats of the bench command, HBM traffic
+# (FETCH_SIZE / WRITE_SIZE in separate passes), SQ wave-state counters, big-FFT timings.
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02'
+set -u
+tag=${1:-r02}
+out=gpurun_out/prof_$tag
+export TMPDIR=/tmp
+mkdir -p $out
+python3 bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_trace -- python3 bench.py --steps 20 --warmup 5 --no-oracle > $out/bench_profiled.json 2> /dev/null
+K="chain convert shift_gain conv chain_c64 beamform downsample"
+REPS=6 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 tools/prof_kernels.py $K > /dev/null 2>&1
+REPS=6 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 tools/prof_kernels.py $K > /dev/null 2>&1
+python3 tools/pmc_summary.py $out/pmc_fetch $out/pmc_write $out/traffic.json > /dev/null
+REPS=6 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $out/sq1 -- python3 tools/prof_kernels.py chain conv chain_c64 > /dev/null 2>&1
+REPS=6 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_LDS_UNALIGNED_STALL --output-format csv -d $out/sq2 -- python3 tools/prof_kernels.py chain conv chain_c64 > /dev/null 2>&1
+python3 tools/pmc_sq.py $out/sq1 $out/sq2 > $out/sq_counters.txt
+REPS=6 rocprofv3 --kernel-trace --stats --output-format csv -d $out/fft_trace -- python3 tools/prof_kernels.py fft1024 fft4096 fftbig13 fftbig14 fftbig15 fftbig16 fftbig18 > /dev/null 2>&1
+REPS=10 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kern_trace -- python3 tools/prof_kernels.py $K shift scale rotate > /dev/null 2>&1
+python3 tools/host_path_bench.py > $out/host_path.txt 2>&1
+./build/tools/fir_ablate > $out/fir_ablate.txt 2>&1
+for f in $out/bench_trace/*/*kernel_stats.csv $out/fft_trace/*/*kernel_stats.csv $out/kern_trace/*/*kernel_stats.csv; do echo "== $f"; cut -d, -f1-4 $f | cut -c1-160 | head -14; done
+cat $out/sq_counters.txt | head -60
+tail -3 $out/bench.err

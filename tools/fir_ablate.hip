@@ -34,7 +34,7 @@ template <int EXP> static float run(const void *in, float2 *spec, const float2 *
     float best = 1e9f, sum = 0;
     for (int r = 0; r < reps + 3; r++) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k, dim3((unsigned)nblocks), dim3(256), lds, 0, in, spec + (n / 3072 + 2) * 512, (const float2 *)nullptr,
+        hipLaunchKernelGGL(k, dim3((unsigned)(2 + 8 * ((nblocks - 2 + 7) / 8))), dim3(256), lds, 0, in, spec + (n / 3072 + 2) * 512, (const float2 *)nullptr,
                            (float2 *)nullptr, hf, tabs, spec, nblocks, n, hop, off, (unsigned)D, P, late, pt, slow);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));

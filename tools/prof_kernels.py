@@ -49,6 +49,11 @@ def main():
         elif w == "fft4096":
             p = ctx.fft_plan(xc, out, hz.FFT_FORWARD, batch=n // 4096)
             fn = p.transform
+        elif w.startswith("fftbig"):  # fftbig14, fftbig16, ...: one transform size, 2^24 points in all
+            lg = int(w[6:])
+            p = ctx.fft_plan(xc, out, hz.FFT_FORWARD, batch=n >> lg)
+            # Context.fft_plan(batch=) takes the block length from len // batch
+            fn = p.transform
         elif w == "shift":
             nco = ctx.nco(fs)
             fn = lambda: nco(2.5e6, xc)
