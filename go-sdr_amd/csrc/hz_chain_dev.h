@@ -123,6 +123,46 @@ __device__ __forceinline__ void ew_apply_at(const EwProgram &P, float2 (&v)[W], 
     }
 }
 
+// The late mixer over the outputs of ONE lane that are equally spaced in time: slot m
+// (m0 <= m < W, v[m] valid from m0 on) sits at stream position pos0 + m*stride, all inside the
+// clock run `w` (a late block lies in one run), where the clock is exactly linear.  A Shift
+// stage is then a geometric sequence, exp(i tau ts_m) = exp(i tau ts_m0) * exp(i tau stride step)^(m-m0):
+// two Sincos per lane and stage and one float64 complex product per output, instead of a
+// Sincos per output.  The phases are those of exact arithmetic on the run's (t0, step); the
+// reference rounds tau*ts_m per sample (|tau ts| * 1e-16 <= 4e-8 rad), a difference of a few
+// 1e-8 relative in an output held to an FFT error bound of 6e-7.
+template <int W>
+__device__ __forceinline__ void ew_apply_seq(const EwProgram &P, float2 (&v)[W], int m0, uint64_t pos0,
+                                             uint64_t stride, NcoWin w) {
+#pragma unroll 1
+    for (int i = 0; i < P.n; i++) {  // uniform
+        const EwOp &o = P.op[i];
+        if (o.kind == EW_SCALE) {
+#pragma unroll
+            for (int m = 0; m < W; m++) v[m] = make_float2(__fmul_rn(v[m].x, o.a), __fmul_rn(v[m].y, o.a));
+        } else if (o.kind == EW_ROTATE) {
+#pragma unroll
+            for (int m = 0; m < W; m++) v[m] = go_cmul(v[m], make_float2(o.a, o.b));
+        } else {
+            // z = exp(i tau ts(pos0 + m0 stride)), q = exp(i tau stride step)
+            double zs, zc, qs, qc;
+            const double ts0 = nco_ts(P.segs, w, pos0 + (uint64_t)m0 * stride);
+            const double step = P.segs.big_n ? P.segs.big[w.lo].step : P.segs.step[w.lo];
+            sincos_late(__dmul_rn(o.tau_shift, ts0), zs, zc);
+            sincos_late(__dmul_rn(o.tau_shift, __dmul_rn((double)stride, step)), qs, qc);
+#pragma unroll
+            for (int m = 0; m < W; m++) {
+                if (m >= m0) {  // uniform
+                    v[m] = go_cmul(v[m], make_float2((float)zc, (float)zs));
+                    const double nc = __fma_rn(zc, qc, -(zs * qs)), ns = __fma_rn(zc, qs, zs * qc);
+                    zc = nc;
+                    zs = ns;
+                }
+            }
+        }
+    }
+}
+
 // The two most common programs -- Shift, and Shift then Gain (BASELINE config 2) -- spelt
 // out, without the op loop: same operations in the same order, but straight-line code the
 // scheduler can overlap with the loads and stores around it.  SHAPE 0 = interpret.
@@ -922,35 +962,21 @@ __global__ __launch_bounds__((SynthGeom<N, FOLD>::BS)) void fir_synth_kernel16(
     }
     if constexpr (LATE) {
         if (mix_late) {
-            // The mixer straight from the last pass's registers: slot q holds time index
-            // i = edge_index<M, RM>(q, l2) = l2 + const(q); output i sits at stream position
-            // p0 + i*FOLD.  Four slots at a time (four interleaved float64 Sincos chains), fixed
-            // registers; groups with no valid output (uniform test) are skipped.
+            // The mixer straight from the last pass's registers.  In ascending time order the m-th
+            // slot is q(m) = (m % (16/RM)) * RM + m / (16/RM), time index i = m*TPTM + l2, stream
+            // position p0 + i*FOLD: a lane's outputs are equally spaced (TPTM*FOLD samples), so
+            // the Shift stages run as a phase recurrence (ew_apply_seq) from the first slot that
+            // can hold a valid output.
             const int64_t p0 = (int64_t)(b * hop) - (int64_t)off;
+            float2 y[16];
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                // slots in ascending time order: the m-th smallest offset is m * TPTM, held by
-                // slot q = (m % (16/RM)) * RM + m / (16/RM); four consecutive m per group, so a
-                // group below i_lo (the block's overlap) is skipped whole
-                float2 y[4];
-                unsigned idx[4];
-                int qs[4];
-                bool any = false;
+            for (int m = 0; m < 16; m++) y[m] = fv::to2(w[(m % (16 / RM)) * RM + m / (16 / RM)]);
+            const int m0 = (int)(i_lo / TPTM);  // uniform: slots below hold only the block's overlap
+            ew_apply_seq<16>(P, y, m0, (uint64_t)(p0 + (int64_t)l2 * FOLD), (uint64_t)TPTM * FOLD, run);
 #pragma unroll
-                for (int l = 0; l < 4; l++) {
-                    const int m = 4 * g + l;
-                    qs[l] = (m % (16 / RM)) * RM + m / (16 / RM);
-                    idx[l] = fv::edge_off<M, RM>(qs[l]);
-                    y[l] = fv::to2(w[qs[l]]);
-                    any = any || (idx[l] + TPTM > i_lo && idx[l] < i_hi);
-                }
-                if (!any) continue;  // compile-time offsets, uniform bounds
-                ew_apply_at<4>(P, y, p0, l2, idx, FOLD, run);
-#pragma unroll
-                for (int l = 0; l < 4; l++) {
-                    const unsigned i = idx[l] + l2;
-                    if (i >= i_lo && i < i_hi) out[b * per + (i - i_lo)] = y[l];
-                }
+            for (int m = 0; m < 16; m++) {
+                const unsigned i = m * TPTM + l2;
+                if (i >= i_lo && i < i_hi) out[b * per + (i - i_lo)] = y[m];
             }
         }
     }
