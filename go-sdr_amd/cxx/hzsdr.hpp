@@ -145,39 +145,6 @@ private:
     size_t max_, pos_ = 0;
 };
 
-// sdr.Writer (writer.go:31-43)
-struct Writer {
-    virtual ~Writer() = default;
-    virtual size_t Write(Samples s) = 0;
-    virtual int SampleFormat() const = 0;
-    virtual unsigned SampleRate() const = 0;
-};
-using WriterPtr = std::shared_ptr<Writer>;
-
-// an in-memory sink: the read end of an sdr.Pipe in the reference's writer tests
-class BufferWriter : public Writer {
-public:
-    BufferWriter(int format, unsigned rate) : fmt_(format), rate_(rate) {}
-    size_t Write(Samples s) override {
-        if (s.format != fmt_) throw Error(HZSDR_ERR_FORMAT_MISMATCH, hzsdr_strerror(HZSDR_ERR_FORMAT_MISMATCH));
-        const unsigned char *p = (const unsigned char *)s.data;
-        bytes.insert(bytes.end(), p, p + s.size());
-        return s.length;
-    }
-    int SampleFormat() const override { return fmt_; }
-    unsigned SampleRate() const override { return rate_; }
-    size_t Length() const { return bytes.size() / (size_t)hzsdr_format_size(fmt_); }
-    std::vector<unsigned char> bytes;
-
-private:
-    int fmt_;
-    unsigned rate_;
-};
-
-namespace stream {
-
-constexpr size_t kBlock = 32 * 1024;  // stream/convert.go:43-44
-
 // stream.ReadTransformer (stream/read_transformer.go:45-137), pull-driven
 class ReadTransformer : public Reader {
 public:
@@ -215,40 +182,13 @@ private:
     bool done_ = false;
 };
 
+constexpr size_t kBlock = 32 * 1024;  // stream/convert.go:43-44
+
 // stream.ConvertReader (stream/convert.go:37-51)
 inline ReaderPtr ConvertReader(const Context &x, ReaderPtr in, int to) {
     unsigned rate = in->SampleRate();
     return std::make_shared<ReadTransformer>(std::move(in), kBlock, kBlock, to, rate,
                                              [&x](Samples i, Samples o) { return x.ConvertBuffer(o, i); });
-}
-
-// stream.ConvertWriter (stream/convert.go:53-118)
-class ConvertWriterImpl : public Writer {
-public:
-    ConvertWriterImpl(const Context &x, WriterPtr out, int input_format)
-        : x_(x), out_(std::move(out)), in_fmt_(input_format), buf_(out_->SampleFormat(), kBlock) {}
-    size_t Write(Samples in) override {
-        if (in.format != in_fmt_) throw Error(HZSDR_ERR_FORMAT_MISMATCH, hzsdr_strerror(HZSDR_ERR_FORMAT_MISMATCH));
-        size_t n = 0;
-        for (size_t i = 0; i < in.length; i += kBlock) {
-            const size_t ie = i + kBlock < in.length ? i + kBlock : in.length;
-            const size_t got = x_.ConvertBuffer(buf_.view, in.slice(i, ie));
-            if (got != ie - i) throw Error(HZSDR_ERR_INVALID_ARGUMENT, "ConvertWriter: Conversion mismatch");
-            n += out_->Write(buf_.view.slice(0, got));
-        }
-        return n;
-    }
-    int SampleFormat() const override { return in_fmt_; }
-    unsigned SampleRate() const override { return out_->SampleRate(); }
-
-private:
-    const Context &x_;
-    WriterPtr out_;
-    int in_fmt_;
-    Buffer buf_;
-};
-inline WriterPtr ConvertWriter(const Context &x, WriterPtr out, int input_format) {
-    return std::make_shared<ConvertWriterImpl>(x, std::move(out), input_format);
 }
 
 // stream.DownsampleReader (stream/downsample.go:47-64)
@@ -414,10 +354,6 @@ inline ClosurePtr CrossCorrelate(const Context &x, Samples dst, Samples iq1, Sam
 }
 // fft.ConvolveOnce (fft/convolution.go:200-211)
 inline void ConvolveOnce(const Context &x, Samples dst, Samples iq1, Samples iq2) { (*Convolve(x, dst, iq1, iq2))(); }
-// fft.Shift (fft/result.go:230-236, :84-98): 0 Hz to the centre of the buffer and back
-inline void Shift(const Context &x, Samples frequency) {
-    check(x.raw(), hzsdr_fftshift_scale(x.raw(), frequency.data, frequency.length, 1.0f));
-}
 // fft.ConvolveFreq (fft/convolution.go:150-192)
 inline ClosurePtr ConvolveFreq(const Context &x, Samples dst, Samples src, Samples freq) {
     hzsdr_conv *c = nullptr;
