@@ -182,6 +182,8 @@ private:
     bool done_ = false;
 };
 
+namespace stream {
+
 constexpr size_t kBlock = 32 * 1024;  // stream/convert.go:43-44
 
 // stream.ConvertReader (stream/convert.go:37-51)
