@@ -20,6 +20,7 @@
 #include <algorithm>
 
 #include "hz_chain_dev.h"
+#include "hz_firmm.h"
 #include "hz_fft_api.h"
 
 // =============================================================================
@@ -54,6 +55,18 @@ struct hzsdr_chain {
     std::map<uint64_t, void *> late_cache;
     bool mix_in_order = false;
     bool poly = false;  // hfreq / late_cache hold the polyphase layout (fold_poly)
+    // int8 matrix form (hz_firmm.h): geometry, the taps on the device (fix-up workgroups) and
+    // one digit table per distinct clock step (key 0: no Shift stage)
+    bool mm_ok = false;
+    hz::mm::Geom mmg{};
+    void *taps_dev = nullptr;
+    std::map<uint64_t, void *> mm_cache;
+    // the last `off` RAW samples of the previous call (two buffers, flipped with hist[]): valid
+    // after a call on the matrix path; rh_step / rh_len describe the clock run they end in
+    void *rhist[2] = {nullptr, nullptr};
+    bool rh_valid = false;
+    double rh_step = 0.0;
+    uint64_t rh_len = 0;
 };
 
 struct hzsdr_conv {
@@ -345,6 +358,201 @@ static int prepare_late_filters(hzsdr_chain *c, double ts0) {
     return HZSDR_OK;
 }
 
+// ---- int8 matrix form (hz_firmm.h) -------------------------------------------------------------
+
+static double mm_scale(const hzsdr_chain *c) { return c->src_fmt == HZSDR_FMT_U8 ? 1.0 / 127.5 : 1.0 / 128.0; }
+
+// Byte sources with a decimation of 8 or 16 and a filter the tile geometry holds.  Environment
+// HZ_FIR_FFT=1 keeps every chain on the transform kernels (A/B measurements, tests of that path).
+static bool mm_eligible(const hzsdr_chain *c) {
+    if (getenv("HZ_FIR_FFT")) return false;
+    if (c->src_fmt != HZSDR_FMT_U8 && c->src_fmt != HZSDR_FMT_I8) return false;
+    if (c->factor != 8 && c->factor != 16) return false;
+    return c->ntaps >= 64 && c->ntaps <= 4096;
+}
+
+static void mm_geometry(hzsdr_chain *c) {
+    mm::Geom &g = c->mmg;
+    const int D = (int)c->factor;
+    g.ntaps = (int)c->ntaps;
+    g.w0 = (g.ntaps - 1 + 7) / 8 * 8;
+    const int window = g.w0 + D * (mm::kT - 1) + 1;  // samples a tile's outputs reach back over
+    g.ks = (2 * window + 31) / 32;
+    g.ks = (g.ks + D - 1) / D * D;  // whole groups of PPT / 2 = D steps (hz_firmm.h)
+    g.e0 = 2 * (g.ks + 4);
+    g.ne = g.e0 + (D / 8) * (mm::kT - 1) + 1;
+    g.off = c->off;
+    // q = round(h' 2^S) with |q| <= 2^30: |h'[k]| <= |h[k]| * scale for every modulation
+    double hmax = 0.0;
+    for (size_t k = 0; k < c->ntaps; k++) hmax = std::max(hmax, hypot(c->taps_host[2 * k], c->taps_host[2 * k + 1]));
+    hmax *= mm_scale(c);
+    int S = 0;
+    if (hmax > 0.0) {
+        int e;
+        frexp(hmax, &e);  // hmax < 2^e
+        S = 30 - e;
+    }
+    g.shift = S < -900 ? -900 : S > 900 ? 900 : S;
+}
+
+// The digit table of taps[k] * exp(-i omega k step) * scale (hz_firmm.h: F[digit][E][part][16],
+// then the constant term).  Like late_filter_for: a miss builds, uploads and WAITS unless
+// `make` is false.
+static int mm_table_for(hzsdr_chain *c, double step, double omega, void **dev, bool make) {
+    hzsdr_ctx *ctx = c->ctx;
+    *dev = nullptr;
+    uint64_t key;
+    memcpy(&key, &step, 8);
+    auto it = c->mm_cache.find(key);
+    if (it != c->mm_cache.end()) {
+        *dev = it->second;
+        return HZSDR_OK;
+    }
+    if (!make || c->mm_cache.size() >= kLateCacheMax) return HZSDR_OK;
+    const mm::Geom &g = c->mmg;
+    const double sc = mm_scale(c);
+    std::vector<int64_t> qr(c->ntaps), qi(c->ntaps);
+    int64_t sr = 0, si = 0;
+    for (size_t k = 0; k < c->ntaps; k++) {
+        const double ph = -omega * ((double)k * step);
+        const double cr = cos(ph), ci = sin(ph);
+        const double hr = c->taps_host[2 * k], hi = c->taps_host[2 * k + 1];
+        qr[k] = llround(ldexp((hr * cr - hi * ci) * sc, g.shift));
+        qi[k] = llround(ldexp((hr * ci + hi * cr) * sc, g.shift));
+        sr += qr[k];
+        si += qi[k];
+    }
+    std::vector<uint8_t> tab(mm::table_bytes(g.ne), 0);
+    for (int E = 0; E < g.ne; E++)
+        for (int pout = 0; pout < 2; pout++)
+            for (int e = 0; e < 16; e++) {
+                const int kap = 8 * (E - g.e0) + g.w0 - (e >> 1), pin = e & 1;
+                if (kap < 0 || kap >= g.ntaps) continue;
+                // y_re = h_re x_re - h_im x_im ; y_im = h_im x_re + h_re x_im
+                int64_t q = pout == 0 ? (pin == 0 ? qr[kap] : -qi[kap]) : (pin == 0 ? qi[kap] : qr[kap]);
+                for (int d = 3; d >= 0; d--) {  // balanced base-256 digits, d = 0 most significant
+                    const int64_t r = ((q + 128) & 255) - 128;
+                    tab[(((size_t)d * g.ne + E) * 2 + pout) * 16 + e] = (uint8_t)(int8_t)r;
+                    q = (q - r) >> 8;
+                }
+            }
+    // u8: x = (b - 128) + 0.5 (1 + i): the constant part of every output, in units of 2^-S
+    double dc[2] = {0.0, 0.0};
+    if (c->src_fmt == HZSDR_FMT_U8) {
+        dc[0] = 0.5 * (double)(sr - si);
+        dc[1] = 0.5 * (double)(sr + si);
+    }
+    memcpy(tab.data() + (size_t)4 * g.ne * 32, dc, 16);
+    void *d = nullptr;
+    HZ_HIP(ctx, hipMalloc(&d, tab.size()));
+    hipError_t e = hipMemcpyAsync(d, tab.data(), tab.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        HZ_HIP(ctx, e);
+    }
+    c->mm_cache[key] = d;
+    *dev = d;
+    return HZSDR_OK;
+}
+
+// Tables for every long run the clock can produce from ts0 on (see prepare_late_filters).
+static int prepare_mm_tables(hzsdr_chain *c, double ts0) {
+    if (!c->mm_ok) return HZSDR_OK;
+    void *dev;
+    if (!c->has_shift) return mm_table_for(c, 0.0, 0.0, &dev, true);
+    const double omega = chain_omega(c);
+    const uint64_t period = (uint64_t)(6.283185307179586 * (double)c->sample_rate) + 2;
+    for (int pass = 0; pass < 2; pass++) {
+        std::vector<hzsdr_nco_segment> segs(96);
+        size_t need = 0;
+        double ts_end = 0.0;
+        if (hzsdr_nco_segments(c->sample_rate, pass == 0 ? ts0 : 0.0, period, segs.data(), segs.size(), &need,
+                               &ts_end) != HZSDR_OK)
+            continue;
+        const size_t have = need < segs.size() ? need : segs.size();
+        for (size_t q = 0; q < have; q++) {
+            if (segs[q].count < 8 * (uint64_t)c->ntaps) continue;
+            HZ_TRY(mm_table_for(c, segs[q].step, omega, &dev, true));
+        }
+    }
+    return HZSDR_OK;
+}
+
+// Splits the outputs of one call between the matrix path (per clock run) and the fix-up
+// workgroups.  false: the call stays on the transform kernels.
+static bool mm_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in, const void *out, mm::Runs *R,
+                    mm::Fix *F) {
+    memset(R, 0, sizeof *R);
+    memset(F, 0, sizeof *F);
+    if (!c->mm_ok || c->mix_in_order || P.segs.big_n != 0 || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) return false;
+    const uint64_t D = c->factor, n_out = n / D, nt = c->ntaps;
+    if (n_out < 2 * (uint64_t)mm::kChunkOut || n_out >= (1ull << 31)) return false;
+    for (int i = 0; i < P.n; i++)
+        if (P.op[i].kind == EW_SHIFT && !(fabs(P.op[i].tau_shift) * 6.2832 < 1073741824.0)) return false;
+    const int nr = c->has_shift ? P.segs.n : 1;
+    if (nr < 1 || nr > mm::kMaxRuns) return false;
+    R->n = nr;
+    // does run 0 continue the run the previous call ended in (same step, no reset in between)?  Then
+    // the clock is exactly linear across the call boundary and the first windows may reach back
+    // into the raw history instead of going to the fix-up workgroups.
+    R->cont = c->rh_valid && (!c->has_shift || (P.segs.step[0] == c->rh_step && c->rh_len >= nt)) ? 1 : 0;
+    uint64_t cur = 0, fix_total = 0;
+    auto add_fix = [&](uint64_t a, uint64_t b) {
+        if (b <= a || F->n >= mm::kMaxFix) return;
+        F->m_a[F->n] = (uint32_t)a;
+        F->m_b[F->n] = (uint32_t)b;
+        F->wg_first[F->n] = F->n_wg;
+        F->n_wg += (int)((b - a + mm::kFixOut - 1) / mm::kFixOut);
+        F->n++;
+        fix_total += b - a;
+    };
+    for (int r = 0; r < nr; r++) {
+        const uint64_t a = c->has_shift ? P.segs.first[r] : 0;
+        const uint64_t b = (c->has_shift && r + 1 < nr) ? P.segs.first[r + 1] : (uint64_t)n;
+        void *dev = nullptr;
+        (void)mm_table_for(c, c->has_shift ? P.segs.step[r] : 0.0, 0.0, &dev, false);
+        uint64_t lo = (r == 0 && R->cont) ? 0 : (a + nt - 1 + D - 1) / D, hi = std::min((b + D - 1) / D, n_out);
+        lo += lo & 1;  // 16-byte output stores: chunks start on even outputs
+        R->wg_first[r] = R->n_wg;
+        R->m_lo[r] = R->m_hi[r] = 0;
+        if (!dev || hi < lo + 64) continue;  // a run without a table, or too short to bother
+        add_fix(cur, lo);
+        cur = hi;
+        R->tab[r] = dev;
+        R->m_lo[r] = (uint32_t)lo;
+        R->m_hi[r] = (uint32_t)hi;
+        R->n_wg += (int)((hi - lo + mm::kChunkOut - 1) / mm::kChunkOut);
+    }
+    add_fix(cur, n_out);
+    // the fix-up workgroups are the slow way: a call that is mostly boundaries keeps the transforms
+    return R->n_wg > 0 && fix_total <= 16384 && fix_total * 4 <= n_out;
+}
+
+template <int FMT>
+static int mm_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const EwProgram &P, const mm::Runs &R,
+                     const mm::Fix &F) {
+    hzsdr_ctx *ctx = c->ctx;
+    const float2 *hist = (const float2 *)c->hist[c->hist_cur];
+    float2 *nhist = (float2 *)c->hist[c->hist_cur ^ 1];
+    const uint8_t *rh = (const uint8_t *)c->rhist[c->hist_cur];
+    uint8_t *nrh = (uint8_t *)c->rhist[c->hist_cur ^ 1];
+    const mm::Geom &g = c->mmg;
+    const int D = (int)c->factor;
+    const size_t lds = std::max(mm::chunk_bytes(D, g.ks), (size_t)(2 * g.ntaps + D * (mm::kFixOut - 1)) * 8);
+    const unsigned grid = (unsigned)(F.n_wg + (int)((g.off + mm::kThreads - 1) / mm::kThreads) + R.n_wg);
+    if constexpr (FMT == HZSDR_FMT_U8 || FMT == HZSDR_FMT_I8) {
+        if (D == 8)
+            launch_fv(mm::fir_mm_kernel<FMT, 8>, dim3(grid), dim3(mm::kThreads), lds, ctx->stream, in, (float2 *)out, hist,
+                      nhist, rh, nrh, (const float2 *)c->taps_dev, n, g, P, R, F);
+        else
+            launch_fv(mm::fir_mm_kernel<FMT, 16>, dim3(grid), dim3(mm::kThreads), lds, ctx->stream, in, (float2 *)out, hist,
+                      nhist, rh, nrh, (const float2 *)c->taps_dev, n, g, P, R, F);
+        return HZSDR_OK;
+    }
+    return HZSDR_ERR_INVALID_ARGUMENT;
+}
+
 // The modulated filter of every clock run long enough to hold a whole block (lookups only).
 static int late_filters(hzsdr_chain *c, const EwProgram &P, size_t n, LateFilters *out, bool *any) {
     *any = false;
@@ -451,6 +659,25 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
         const float2 *hist = (const float2 *)c->hist[c->hist_cur];
         float2 *nhist = (float2 *)c->hist[c->hist_cur ^ 1];
         const unsigned D = c->factor;
+        if (c->mm_ok) {
+            // byte source, D = 8 / 16: the int8 matrix form (hz_firmm.h), one launch
+            mm::Runs R;
+            mm::Fix F;
+            if (mm_plan(c, P, n_cons, in, out, &R, &F)) {
+                HZ_TRY(mm_launch<FMT>(c, in, out, n_cons, P, R, F));
+                c->hist_cur ^= 1;
+                // the raw history now ends in this call's last clock run
+                const bool was = c->rh_valid;
+                c->rh_valid = n_cons >= c->off || was;
+                if (c->has_shift) {
+                    const int last = P.segs.n - 1;
+                    const uint64_t len = n_cons - P.segs.first[last];
+                    c->rh_len = (last == 0 && R.cont) ? c->rh_len + len : len;
+                    c->rh_step = P.segs.step[last];
+                }
+                break;
+            }
+        }
         if (!fv::ok((int)c->nfft)) return HZSDR_ERR_INVALID_ARGUMENT;
         FvTabs tabs{}, tabs_m{};
         PolyTabs ptabs{};
@@ -525,6 +752,7 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
 #undef HZ_FIR16_L
 #undef HZ_SYNTH16
         c->hist_cur ^= 1;  // the kernel wrote the next run's history into nhist
+        c->rh_valid = false;  // (the transform kernels keep no raw history)
         break;
     }
     }
@@ -695,17 +923,33 @@ int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps, size_t n_taps, u
             HZ_HIP(ctx, hipMalloc(&c->hfreq_late, (size_t)nfft * 8));
             HZ_TRY(filter_spectrum(c, c->taps_host.data(), c->hfreq_late, late_scale(c)));
         }
-        return prepare_late_filters(c, c->ts);
+        HZ_TRY(prepare_late_filters(c, c->ts));
+        c->mm_ok = mm_eligible(c);
+        if (c->mm_ok) {
+            mm_geometry(c);
+            std::vector<float> tf(2 * n_taps);
+            for (size_t i = 0; i < 2 * n_taps; i++) tf[i] = taps[i];
+            HZ_HIP(ctx, hipMalloc(&c->rhist[0], hb));
+            HZ_HIP(ctx, hipMalloc(&c->rhist[1], hb));
+            HZ_HIP(ctx, hipMalloc(&c->taps_dev, 8 * n_taps));
+            HZ_HIP(ctx, hipMemcpyAsync(c->taps_dev, tf.data(), 8 * n_taps, hipMemcpyHostToDevice, ctx->stream));
+            HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            HZ_TRY(prepare_mm_tables(c, c->ts));
+        }
+        return HZSDR_OK;
     };
     const int rc = build();
     if (rc != HZSDR_OK) {
         (void)hipStreamSynchronize(ctx->stream);
-        for (void **p : {&c->hfreq, &c->hfreq_late, &c->hist[0], &c->hist[1]}) {
+        for (void **p : {&c->hfreq, &c->hfreq_late, &c->hist[0], &c->hist[1], &c->taps_dev, &c->rhist[0], &c->rhist[1]}) {
             if (*p) (void)hipFree(*p);
             *p = nullptr;
         }
         for (auto &kv : c->late_cache) (void)hipFree(kv.second);
         c->late_cache.clear();
+        for (auto &kv : c->mm_cache) (void)hipFree(kv.second);
+        c->mm_cache.clear();
+        c->mm_ok = false;
         c->taps_host.clear();
         return rc;
     }
@@ -772,6 +1016,7 @@ int hzsdr_chain_reset(hzsdr_chain *c) {
     hzsdr_ctx *ctx = c->ctx;
     HZ_TRY(hz::enter(ctx));
     c->ts = 0.0;
+    c->rh_valid = false;
     if (c->term == TERM_FIR) {
         const size_t hb = (size_t)(c->off ? c->off : 1) * 8;
         HZ_HIP(ctx, hipMemsetAsync(c->hist[0], 0, hb, ctx->stream));
@@ -786,7 +1031,11 @@ int hzsdr_chain_set_time(hzsdr_chain *c, double ts) {
         return hz::fail(c->ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: clock outside [0, 2*pi]");
     HZ_TRY(hz::enter(c->ctx));
     c->ts = ts;
-    if (c->term == TERM_FIR) HZ_TRY(hz::prepare_late_filters(c, ts));
+    c->rh_valid = false;  // the clock no longer continues the previous call's run
+    if (c->term == TERM_FIR) {
+        HZ_TRY(hz::prepare_late_filters(c, ts));
+        HZ_TRY(hz::prepare_mm_tables(c, ts));
+    }
     return HZSDR_OK;
 }
 
@@ -806,6 +1055,10 @@ int hzsdr_chain_free(hzsdr_chain *c) {
     if (c->hist[0]) (void)hipFree(c->hist[0]);
     if (c->hist[1]) (void)hipFree(c->hist[1]);
     for (auto &kv : c->late_cache) (void)hipFree(kv.second);
+    for (auto &kv : c->mm_cache) (void)hipFree(kv.second);
+    if (c->taps_dev) (void)hipFree(c->taps_dev);
+    if (c->rhist[0]) (void)hipFree(c->rhist[0]);
+    if (c->rhist[1]) (void)hipFree(c->rhist[1]);
     delete c;
     return HZSDR_OK;
 }

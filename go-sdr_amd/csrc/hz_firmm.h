@@ -1,0 +1,452 @@
+// hz_firmm.h -- the FIR-decimate terminal of a chain over RAW 8-bit IQ as an int8 MFMA product.
+//
+// For a u8 / i8 source and a decimation D that is a multiple of 8 the filter runs in the time
+// domain on the matrix cores instead of through overlap-save transforms (hz_chain_dev.h):
+//
+//   * the late mixer (see fir_decimate_kernel16) already filters the CONVERTED samples with the
+//     run's modulated taps h'[k] = h[k] exp(-i Omega k step) / scale and mixes afterwards.  The
+//     converted samples of a byte source are integers: x = (b - 128) + 0.5 (1 + i) for u8, b for
+//     i8.  The taps become 32-bit fixed point q[k] = round(h'[k] 2^S) (|q| <= 2^30: 2^-30 of the
+//     largest tap, far below float32), split into four balanced base-256 digits.  Then
+//         y[m] 2^S = sum_d 256^(3-d) sum_k digit_d(q[k]) xi8[D m - k]  +  0.5 (1 + i) sum_k q[k]
+//     is FOUR int8 matrix products with int32 accumulation -- EXACT integer arithmetic -- one
+//     float64 combination and one rounding to float32: the filter output is the correctly
+//     rounded value for the quantised taps (measured 2.6e-8 relative L2 against the float64
+//     direct form; the transform path has 1.7e-7).
+//   * the product: a tile = 16 consecutive outputs x (re, im) = 32 rows of a Toeplitz matrix
+//     A[(i, part), k] over the window's bytes k = (sample a, part), tap D i + w0 - a; the other
+//     operand is the raw byte stream itself (u8: XOR 0x80), column n = the window of tile n,
+//     256 bytes further on (D = 8).  v_mfma_i32_32x32x32_i8: 32 rows x 32 tiles x 32 bytes per
+//     instruction.  Every A fragment is an entry of ONE small table F[digit][E][part] (16 bytes:
+//     eight taps x (coefficient of re, of im)), E = (D/8) i - h - 2 s: 21 KB per clock run,
+//     read coalesced (a wave's 64 lanes read ~544 consecutive bytes) and L1-resident.
+//   * a workgroup = two waves over the same 2048 outputs (128 tiles, 34 KB of input in LDS,
+//     16-byte pieces XOR-swizzled by the tile index so that a fragment read is conflict-free
+//     without padding): wave 0 multiplies by digits 0-1, wave 1 by digits 2-3 (128 accumulator
+//     registers each, two waves per SIMD); they exchange halves through LDS and each finishes
+//     1024 outputs: float64 combination, the elementwise program as a phase recurrence (the
+//     clock is exactly linear inside the run), store.
+//   * outputs whose window crosses a boundary of the clock's runs, the start of the stream or a
+//     run without a table are computed in reference order by the same launch's FIX-UP workgroups
+//     (direct form, float64 accumulation), and the history for the next call (the last `off`
+//     samples after the elementwise program, the format the transform kernels share) by its
+//     HISTORY workgroups.  The int8 form needs no FFT, no spectrum round trip and one launch.
+//
+// Measured (tools/mfma_fir.hip, MI355X): the matrix loop of 2^24 samples, 1024 taps, D = 8 runs
+// at ~3.1 Pop/s (the chip holds ~1.6 GHz under this load) -- see DESIGN.md section 4.
+#pragma once
+#include "hz_chain_dev.h"
+
+namespace hz {
+namespace mm {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int kT = 16;                        // outputs per tile
+constexpr int kNB = 4;                        // 32-tile column blocks per workgroup
+constexpr int kChunkTiles = 32 * kNB;         // 128
+constexpr int kChunkOut = kChunkTiles * kT;   // 2048 outputs per chunk workgroup
+constexpr int kThreads = 128;                 // two waves
+constexpr int kFixOut = 8;                    // outputs per fix-up workgroup
+constexpr int kMaxRuns = kNcoMaxSegs;
+constexpr int kMaxFix = kMaxRuns + 2;
+
+// geometry of one chain (host: mm_geometry)
+struct Geom {
+    int ntaps;
+    int w0;      // window start before the tile's first output sample: ntaps-1 rounded up to 8
+    int ks;      // 32-byte steps over a tile's window (a multiple of D: whole groups of the matrix loop)
+    int ne;      // entries E of one digit of the table
+    int e0;      // E of (i = 0, h = 0, s = 0): 2 (ks + 4), the prefetch runs four steps past the end
+    int shift;   // S: taps are q = round(h' 2^S)
+    unsigned off;  // history length (the chain's `off`)
+};
+
+// per clock run: the table, the outputs that take the matrix path and the first chunk workgroup
+struct Runs {
+    int n;
+    int n_wg;                 // chunk workgroups in total
+    int cont;                 // run 0 continues the previous call's last run: windows may reach into the raw history
+    const void *tab[kMaxRuns];
+    uint32_t m_lo[kMaxRuns], m_hi[kMaxRuns];
+    int wg_first[kMaxRuns];
+};
+// the output ranges computed in reference order, and the first fix-up workgroup of each
+struct Fix {
+    int n;
+    int n_wg;
+    uint32_t m_a[kMaxFix], m_b[kMaxFix];
+    int wg_first[kMaxFix];
+};
+
+constexpr int tile_bytes(int D) { return 2 * D * kT; }
+constexpr int pieces_per_tile(int D) { return tile_bytes(D) / 16; }
+constexpr size_t chunk_bytes(int D, int ks) { return (size_t)(kChunkTiles - 1) * tile_bytes(D) + 32 * (size_t)ks; }
+// table bytes: 4 digits x ne x 2 parts x 16, then (dc_re, dc_im) as two doubles
+constexpr size_t table_bytes(int ne) { return (size_t)4 * ne * 32 + 16; }
+
+// LDS image of a chunk: 16-byte piece p of tile t at TB t + 16 (p ^ (t & 15)).  A fragment read
+// (same piece, 32 consecutive tiles; ds_read_b128 serves 16 lanes per cycle) then touches 16
+// different 16-byte bank groups in every lane group.
+template <int D> __device__ __forceinline__ int sw(int tile, int piece) {
+    return tile_bytes(D) * tile + 16 * (piece ^ (tile & 15));
+}
+
+// the index of the last entry <= key in an ascending table of n <= 64 ints held in the kernel
+// arguments: one vector load + a ballot (a scalar scan waits for a dependent load per entry)
+__device__ __forceinline__ int find_le(const int *tab, int n, int key) {
+    const int l = (int)(threadIdx.x & 63u);
+    const bool valid = l < n;
+    const int v = tab[valid ? l : 0];
+    return __popcll(__ballot(valid && v <= key)) - 1;
+}
+
+// One post-elementwise sample in reference order: position p of the buffer (p < 0: history).
+template <int FMT>
+__device__ __forceinline__ float2 ordered_sample(const void *in, const EwProgram &P, int64_t p, const float2 *hist,
+                                                 unsigned off) {
+    using R = typename Raw<FMT>::t;
+    if (p < 0) return hist ? hist[p + (int64_t)off] : make_float2(0.f, 0.f);
+    float2 v[1] = {Raw<FMT>::cvt(((const R *)in)[p])};
+    ew_apply_n<1, true>(P, v, (uint64_t)p, nco_window_all(P.segs));
+    return v[0];
+}
+
+// EXP: ablation switches for tools/mfma_fir.hip (0 in the library): 1 = no input loads, 2 = no
+// matrix loop, 4 = no elementwise program, 8 = no stores.  Results are wrong with any of them set.
+template <int FMT, int D, int EXP = 0>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_mm_kernel(
+    const void *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ hist,
+    float2 *__restrict__ new_hist, const uint8_t *__restrict__ rhist, uint8_t *__restrict__ new_rhist,
+    const float2 *__restrict__ taps, size_t n_in, Geom G, EwProgram P, Runs R, Fix F) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t mm_lds[];
+    static_assert(D % 8 == 0, "windows start on 16-byte pieces");
+    constexpr int TB = tile_bytes(D), PPT = pieces_per_tile(D);
+    const int tid = threadIdx.x;
+    int wb = blockIdx.x;
+    // (the short fix-up and history workgroups come LAST in the grid: 1024 chunk workgroups fill the
+    // chip's 1024 slots exactly at 2^21 outputs, and a chunk that waits for a second round costs a
+    // quarter of the kernel)
+    if (wb >= R.n_wg) {
+        wb -= R.n_wg;
+    // ---- fix-up workgroups: reference order, direct form ----------------------------------
+        if (wb < F.n_wg) {
+            const int k = find_le(F.wg_first, F.n, wb);
+            const uint32_t m0 = F.m_a[k] + (uint32_t)(wb - F.wg_first[k]) * kFixOut;
+            const int cnt = (int)min((uint32_t)kFixOut, F.m_b[k] - m0);
+            float2 *xs = reinterpret_cast<float2 *>(mm_lds);   // the window's samples, in reference order
+            float2 *tl = xs + (G.ntaps + D * (kFixOut - 1));    // the taps
+            const int64_t p_lo = (int64_t)D * m0 - (G.ntaps - 1);
+            const int n_s = G.ntaps + D * (cnt - 1);
+            for (int idx = tid; idx < G.ntaps; idx += kThreads) tl[idx] = taps[idx];
+            // three samples per lane and trip: their loads, then their Sincos chains side by side
+            using RW = typename Raw<FMT>::t;
+            constexpr int W = 3;
+#pragma unroll 1
+            for (int i0 = tid; i0 < n_s; i0 += W * kThreads) {
+                float2 v[W];
+#pragma unroll
+                for (int u = 0; u < W; u++) {
+                    const int64_t pu = p_lo + i0 + u * kThreads;
+                    const bool ok = i0 + u * kThreads < n_s && pu >= 0;
+                    v[u] = Raw<FMT>::cvt(ok ? ((const RW *)in)[pu] : RW{});
+                }
+                const int64_t pj = p_lo + i0;
+                // (positions before the buffer wrap around in uint64 and come back: their values are discarded)
+                ew_apply_n<W, true>(P, v, (uint64_t)pj, nco_window_all(P.segs), (uint64_t)kThreads);
+#pragma unroll
+                for (int u = 0; u < W; u++) {
+                    const int idx = i0 + u * kThreads;
+                    const int64_t pu = p_lo + idx;
+                    if (idx < n_s) xs[idx] = pu >= 0 ? v[u] : (hist ? hist[pu + (int64_t)G.off] : make_float2(0.f, 0.f));
+                }
+            }
+            __syncthreads();
+            const int o = tid >> 4, sl = tid & 15;  // output, tap slice (k = sl mod 16)
+            double ar = 0.0, ai = 0.0;
+            if (o < cnt) {
+                const float2 *xo = xs + D * o + (G.ntaps - 1);
+#pragma unroll 1
+                for (int k0 = sl; k0 < G.ntaps; k0 += 16 * 8) {
+                    float2 hh[8], xx[8];  // eight taps in flight
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int kk = k0 + 16 * u, kc = kk < G.ntaps ? kk : 0;
+                        hh[u] = tl[kc];
+                        xx[u] = xo[-kc];
+                        if (kk >= G.ntaps) hh[u] = make_float2(0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const double xr = xx[u].x, xi = xx[u].y, hr = hh[u].x, hi = hh[u].y;
+                        ar = __fma_rn(xr, hr, ar);
+                        ar = __fma_rn(-xi, hi, ar);
+                        ai = __fma_rn(xr, hi, ai);
+                        ai = __fma_rn(xi, hr, ai);
+                    }
+                }
+            }
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                ar += __shfl_xor(ar, d);
+                ai += __shfl_xor(ai, d);
+            }
+            if (o < cnt && sl == 0) out[m0 + o] = make_float2((float)ar, (float)ai);
+            return;
+        }
+        wb -= F.n_wg;
+
+        // ---- history workgroups: the last `off` samples after the elementwise program ------------
+        const int n_hist_wg = new_hist ? (int)((G.off + kThreads - 1) / kThreads) : 0;
+        if (wb < n_hist_wg) {
+            const unsigned idx = (unsigned)wb * kThreads + tid;
+            if (idx < G.off) {
+                const int64_t p = (int64_t)n_in - (int64_t)G.off + idx;
+                new_hist[idx] = ordered_sample<FMT>(in, P, p, hist, G.off);
+                // the same samples as raw bytes: the next call's windows reach back into them when
+                // the clock run continues across the call boundary (Runs::cont)
+                using RW = typename Raw<FMT>::t;
+                reinterpret_cast<RW *>(new_rhist)[idx] = p >= 0 ? ((const RW *)in)[p] : reinterpret_cast<const RW *>(rhist)[p + (int64_t)G.off];
+            }
+            return;
+        }
+        wb -= n_hist_wg;
+        return;
+    }
+
+
+    // ---- chunk workgroups: 2048 outputs of one clock run ---------------------------------------
+    const int r = __builtin_amdgcn_readfirstlane(find_le(R.wg_first, R.n, wb));
+    const uint32_t m_start = R.m_lo[r] + (uint32_t)(wb - R.wg_first[r]) * kChunkOut;
+    const uint32_t count = min((uint32_t)kChunkOut, R.m_hi[r] - m_start);
+    const int wave = tid >> 6, l = tid & 63, n = l & 31, h = l >> 5, i = n >> 1, part = n & 1;
+    const int64_t n_bytes = 2 * (int64_t)n_in;
+    {
+        // the chunk's input bytes: from the window start of its first tile
+        const int64_t p0 = 2 * ((int64_t)D * m_start - G.w0);
+        const int pieces = (int)(chunk_bytes(D, G.ks) / 16);
+        const uint8_t *src = (const uint8_t *)in;
+        constexpr int U = 9;  // loads in flight per lane and trip
+#pragma unroll 1
+        for (int q0 = tid; q0 < pieces; q0 += U * kThreads) {
+            v4i x[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int q = q0 + u * kThreads;
+                const int64_t p = p0 + (int64_t)q * 16;
+                x[u] = v4i{0, 0, 0, 0};
+                if (q < pieces) {
+                    if ((EXP & 1) == 0 && p >= 0 && p + 16 <= n_bytes) {
+                        x[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(src + p));
+                    } else if (p < 0 && R.cont && p + 2 * (int64_t)G.off >= 0) {
+                        // before the buffer: the previous call's last samples (2 off is a multiple of 16)
+                        x[u] = *reinterpret_cast<const v4i *>(rhist + (p + 2 * (int64_t)G.off));
+                    } else if (p + 16 > 0 && p < n_bytes) {  // straddles the buffer's end: byte by byte
+                        union { v4i v; uint8_t b[16]; } t;
+                        t.v = v4i{0, 0, 0, 0};
+                        for (int e = 0; e < 16; e++)
+                            if (p + e >= 0 && p + e < n_bytes) t.b[e] = src[p + e];
+                        x[u] = t.v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int q = q0 + u * kThreads;
+                if (q < pieces) {
+                    if constexpr (FMT == HZSDR_FMT_U8) x[u] ^= (int)0x80808080;  // b - 128 as int8
+                    *reinterpret_cast<v4i *>(mm_lds + sw<D>(q / PPT, q % PPT)) = x[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // A fragments: entry (D/8) i - h - 2 s + e0 of this wave's two digits, parts interleaved
+    const v4i *ftab = (const v4i *)R.tab[r];
+    const v4i *fa = ftab + (size_t)(2 * wave) * 2 * G.ne + 2 * ((D / 8) * i - h + G.e0) + part;
+    const int dstride = 2 * G.ne;
+    v16i acc[2][kNB];
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int j = 0; j < kNB; j++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[d][j][q] = 0;
+    // Step s of the window reads piece 2 s + h of tile n (+ 32 j): with GS = PPT / 2 steps per group
+    // the tile is n + g and the piece 2 j + h for step j of group g -- the swizzled address is
+    // 16 ((2 j) ^ xh) past the group's base, xh = ((n + g) & 15) ^ h: two instructions per step.
+    constexpr int GS = PPT / 2;
+    auto load_b = [&](v4i(&b)[kNB], int base, int xh, int j) {
+        const uint8_t *bp = mm_lds + base + 16 * ((2 * j) ^ xh);
+#pragma unroll
+        for (int q = 0; q < kNB; q++) b[q] = *reinterpret_cast<const v4i *>(bp + q * 32 * TB);
+    };
+    auto load_a = [&](v4i(&a)[2], int s) {
+#pragma unroll
+        for (int d = 0; d < 2; d++) a[d] = fa[d * dstride - 4 * s];
+    };
+    auto mma = [&](const v4i(&a)[2], const v4i(&b)[kNB]) {
+#pragma unroll
+        for (int d = 0; d < 2; d++)
+#pragma unroll
+            for (int q = 0; q < kNB; q++) acc[d][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d], b[q], acc[d][q], 0, 0, 0);
+    };
+    {
+        // Operands ahead of the MFMAs that use them: the bytes one step (LDS), the taps FOUR steps
+        // (the table shares the L1 with the chunk's streaming loads and often comes from L2, 500+
+        // cycles against the 256 of a step's MFMAs: one step ahead left the matrix pipe idle half
+        // of the loop).  Inside a step the loads go between the MFMAs (sched_group_barrier): issued
+        // as a clump after them, the wave's own MFMA stream had a ~100-cycle hole per step.
+        // ks is a multiple of GS and the table is padded by four steps in front.
+        v4i a[4][2], b[2][kNB];
+#pragma unroll
+        for (int q = 0; q < 4; q++) load_a(a[q], q);
+        int t = n, base = TB * t, xh = (t & 15) ^ h;
+        load_b(b[0], base, xh, 0);
+        const int groups = ((EXP & 2) ? 0 : G.ks) / GS;
+#pragma unroll 1
+        for (int g = 0; g < groups; g++) {
+            const int tn = t + 1, base_n = TB * tn, xh_n = (tn & 15) ^ h;
+#pragma unroll
+            for (int j = 0; j < GS; j++) {
+                if (j + 1 < GS) load_b(b[(j + 1) & 1], base, xh, j + 1);
+                else load_b(b[(j + 1) & 1], base_n, xh_n, 0);  // (past the window after the last group: unused)
+                mma(a[j & 3], b[j & 1]);
+                load_a(a[j & 3], g * GS + j + 4);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // the address of the step's reads
+#pragma unroll
+                for (int q = 0; q < kNB; q++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // LDS read
+                }
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // table load
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * kNB - kNB - 2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            t = tn;
+            base = base_n;
+            xh = xh_n;
+        }
+    }
+    // The halves meet: wave 0 (digits 0-1) finishes column blocks 0-1, wave 1 (digits 2-3) blocks 2-3.
+    // hi = acc0 * 256 + acc1 is exact in float64; the low pair's weight is 2^-16: float32 is enough.
+    __syncthreads();  // both waves are done with the chunk's bytes
+    double *xhi = reinterpret_cast<double *>(mm_lds);              // [2][16][64]
+    float *xlo = reinterpret_cast<float *>(mm_lds + 2 * 16 * 64 * 8);  // [2][16][64]
+    if (wave == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                xhi[(j * 16 + q) * 64 + l] = __fma_rn((double)acc[0][2 + j][q], 256.0, (double)acc[1][2 + j][q]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                xlo[(j * 16 + q) * 64 + l] = __fmaf_rn((float)acc[0][j][q], 256.0f, (float)acc[1][j][q]);
+    }
+    __syncthreads();
+    const double *dc = reinterpret_cast<const double *>((const uint8_t *)R.tab[r] + (size_t)4 * G.ne * 32);
+    const double dcr = dc[0], dci = dc[1];
+    const double scale = __hiloint2double((1023 - G.shift) << 20, 0);  // 2^-S
+    float2 y[2][8];  // [own block][4 q4 + ... ]: outputs 4 q4 + 2 h + e of tile 32 (2 wave + j) + n
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++)
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                float c2[2];
+#pragma unroll
+                for (int pt = 0; pt < 2; pt++) {
+                    const int q = 4 * q4 + 2 * e + pt;
+                    double hi, lo;
+                    if (wave == 0) {
+                        hi = __fma_rn((double)acc[0][j][q], 256.0, (double)acc[1][j][q]);
+                        lo = (double)xlo[(j * 16 + q) * 64 + l];
+                    } else {
+                        hi = xhi[(j * 16 + q) * 64 + l];
+                        lo = (double)__fmaf_rn((float)acc[0][2 + j][q], 256.0f, (float)acc[1][2 + j][q]);
+                    }
+                    const double v = __fma_rn(hi, 65536.0, lo) + (pt ? dci : dcr);
+                    c2[pt] = (float)(v * scale);
+                }
+                y[j][2 * q4 + e] = make_float2(c2[0], c2[1]);
+            }
+    // The elementwise program over this lane's 16 outputs m = mb + 512 j + 4 q4 + e: equally spaced
+    // in three directions inside one exactly-linear clock run, so a Shift stage is
+    // z0 * wB^j * wA^q4 * wE^e (see ew_apply_seq for the error argument).
+    const uint32_t mb = m_start + (uint32_t)(32 * 2 * wave + n) * kT + 2 * h;
+    const NcoWin w{r, r};
+#pragma unroll 1
+    for (int oi = 0; oi < ((EXP & 4) ? 0 : P.n); oi++) {  // uniform
+        const EwOp &o = P.op[oi];
+        if (o.kind == EW_SCALE) {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int q = 0; q < 8; q++) y[j][q] = make_float2(__fmul_rn(y[j][q].x, o.a), __fmul_rn(y[j][q].y, o.a));
+        } else if (o.kind == EW_ROTATE) {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int q = 0; q < 8; q++) y[j][q] = go_cmul(y[j][q], make_float2(o.a, o.b));
+        } else {
+            const double ts0 = nco_ts(P.segs, w, (uint64_t)D * mb);
+            const double step = P.segs.step[r];
+            double z0s, z0c, es, ec, as, ac, bs, bc;
+            sincos_late(__dmul_rn(o.tau_shift, ts0), z0s, z0c);
+            sincos_late(__dmul_rn(o.tau_shift, __dmul_rn((double)D, step)), es, ec);
+            sincos_late(__dmul_rn(o.tau_shift, __dmul_rn((double)(4 * D), step)), as, ac);
+            sincos_late(__dmul_rn(o.tau_shift, __dmul_rn((double)(32 * kT * D), step)), bs, bc);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                double zc = z0c, zs = z0s;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) {
+                    y[j][2 * q4] = go_cmul(y[j][2 * q4], make_float2((float)zc, (float)zs));
+                    const double ze_c = __fma_rn(zc, ec, -(zs * es)), ze_s = __fma_rn(zc, es, zs * ec);
+                    y[j][2 * q4 + 1] = go_cmul(y[j][2 * q4 + 1], make_float2((float)ze_c, (float)ze_s));
+                    const double nc = __fma_rn(zc, ac, -(zs * as)), ns = __fma_rn(zc, as, zs * ac);
+                    zc = nc;
+                    zs = ns;
+                }
+                const double nc = __fma_rn(z0c, bc, -(z0s * bs)), ns = __fma_rn(z0c, bs, z0s * bc);
+                z0c = nc;
+                z0s = ns;
+            }
+        }
+    }
+    // Stores: a lane holds eight outputs of each of its tiles, 128 bytes apart from the next lane's --
+    // through LDS (16-byte pieces swizzled by the tile index) a wave writes whole 1 KiB rows instead
+    // (direct 8-byte stores cost 10 us of the kernel's 46).
+    __syncthreads();  // the exchange buffers have been read
+    {
+        float4 *yl = reinterpret_cast<float4 *>(mm_lds) + wave * (2 * 32 * 8);  // [2 blocks][32 tiles][8 pieces]
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++)
+                yl[(j * 32 + n) * 8 + ((2 * q4 + h) ^ (n & 7))] =
+                    make_float4(y[j][2 * q4].x, y[j][2 * q4].y, y[j][2 * q4 + 1].x, y[j][2 * q4 + 1].y);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int idx = it * 64 + l, tile = idx >> 3, piece = idx & 7;  // tile = 32 j + n
+            const float4 v = yl[tile * 8 + (piece ^ (tile & 7))];
+            const uint32_t rel = (uint32_t)(64 * wave + tile) * kT + 2 * piece;
+            if (rel + 1 < ((EXP & 8) ? 0u : count)) *reinterpret_cast<float4 *>(out + m_start + rel) = v;
+            else if (rel < ((EXP & 8) ? 0u : count)) out[m_start + rel] = make_float2(v.x, v.y);
+        }
+    }
+}
+
+}  // namespace mm
+}  // namespace hz

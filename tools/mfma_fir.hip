@@ -1,0 +1,110 @@
+// mfma_fir.hip -- times hz::mm::fir_mm_kernel<u8, 8> (hz_firmm.h) in isolation on 12 rotating
+// 2^24-sample buffers (384 MiB: every launch reads its input from HBM), with phases switched
+// off (template parameter EXP).  Tables hold constants: the instruction stream is the real one,
+// the results are not.  (The first version of this file was the prototype that pinned the lane
+// maps of v_mfma_i32_*_i8 with exact integer data against a float64 direct form.)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I go-sdr_amd/csrc tools/mfma_fir.hip -o tools/bin/mfma_fir
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "hz_firmm.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+using namespace hz;
+
+template <int EXP> static void run(void *const *in, float2 *out, const float2 *taps, const void *tab, size_t n, int ntaps,
+                                   bool shift) {
+    constexpr int D = 8;
+    mm::Geom g{};
+    g.ntaps = ntaps;
+    g.w0 = (ntaps - 1 + 7) / 8 * 8;
+    g.ks = ((2 * (g.w0 + D * (mm::kT - 1) + 1) + 31) / 32 + D - 1) / D * D;
+    g.e0 = 2 * (g.ks + 4);
+    g.ne = g.e0 + (D / 8) * (mm::kT - 1) + 1;
+    g.shift = 40;
+    g.off = (unsigned)((ntaps - 1 + D - 1) / D * D);
+    EwProgram P{};
+    if (shift) {
+        P.n = 1;
+        P.op[0].kind = EW_SHIFT;
+        P.op[0].tau_shift = -1.5707963e7;
+        P.segs.n = 1;
+        P.segs.first[0] = 0;
+        P.segs.t0[0] = 0.25;
+        P.segs.step[0] = 5e-8;
+    }
+    mm::Runs R{};
+    mm::Fix F{};
+    const uint32_t n_out = (uint32_t)(n / D), lo = (uint32_t)((ntaps - 1 + D - 1) / D);
+    R.n = 1;
+    R.tab[0] = tab;
+    // steady state: run 0 continues the previous call's run (no fix-up workgroups); FIX=1: a first call
+    const bool fix = getenv("FIX") != nullptr;
+    R.cont = fix ? 0 : 1;
+    R.m_lo[0] = fix ? lo : 0;
+    R.m_hi[0] = n_out;
+    R.n_wg = (int)((n_out - R.m_lo[0] + mm::kChunkOut - 1) / mm::kChunkOut);
+    if (fix) {
+        F.n = 1;
+        F.m_a[0] = 0;
+        F.m_b[0] = lo;
+        F.n_wg = (int)((lo + mm::kFixOut - 1) / mm::kFixOut);
+    }
+    const size_t lds = mm::chunk_bytes(D, g.ks);
+    const unsigned grid = (unsigned)(R.n_wg + F.n_wg + (g.off + mm::kThreads - 1) / mm::kThreads);
+    auto k = mm::fir_mm_kernel<HZSDR_FMT_U8, D, EXP>;
+    CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e9f, sum = 0;
+    const int reps = 24;
+    for (int r = 0; r < reps + 4; r++) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(k, dim3(grid), dim3(mm::kThreads), lds, 0, (const void *)in[r % 12], out, (const float2 *)nullptr,
+                           out + n_out, (const uint8_t *)taps, (uint8_t *)(out + n_out + 4096), taps, n, g, P, R, F);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r >= 4) { best = ms < best ? ms : best; sum += ms; }
+    }
+    CK(hipGetLastError());
+    printf("EXP %2d%s: grid %u, LDS %zu, min %.1f us  avg %.1f us\n", EXP, shift ? " +Shift" : "       ", grid, lds, best * 1e3f,
+           sum / reps * 1e3f);
+}
+
+int main(int argc, char **argv) {
+    const size_t n = (size_t)1 << 24;
+    const int ntaps = argc > 1 ? atoi(argv[1]) : 1024;
+    void *in[12];
+    float2 *out, *taps;
+    void *tab;
+    std::vector<unsigned char> h(n * 2);
+    for (int b = 0; b < 12; b++) {
+        CK(hipMalloc(&in[b], n * 2 + 65536));
+        for (size_t i = 0; i < h.size(); i++) h[i] = (unsigned char)((i + b) * 2654435761u >> 24);
+        CK(hipMemcpy(in[b], h.data(), h.size(), hipMemcpyHostToDevice));
+    }
+    CK(hipMalloc(&out, (n / 8 + 8192) * 8));
+    CK(hipMalloc(&taps, ntaps * 8 + 65536));
+    CK(hipMemset(taps, 0, ntaps * 8 + 65536));
+    std::vector<unsigned char> t(1 << 20);
+    for (size_t i = 0; i < t.size(); i++) t[i] = (unsigned char)(i * 40503u >> 8);
+    CK(hipMalloc(&tab, t.size()));
+    CK(hipMemcpy(tab, t.data(), t.size(), hipMemcpyHostToDevice));
+    printf("fir_mm_kernel<u8, 8>, 2^24 samples, %d taps; EXP 1 = no input loads, 2 = no matrix loop, 4 = no elementwise program, 8 = no stores\n", ntaps);
+    run<0>(in, out, taps, tab, n, ntaps, true);
+    run<0>(in, out, taps, tab, n, ntaps, false);
+    run<1>(in, out, taps, tab, n, ntaps, true);
+    run<2>(in, out, taps, tab, n, ntaps, true);
+    run<8>(in, out, taps, tab, n, ntaps, true);
+    run<1 + 8>(in, out, taps, tab, n, ntaps, true);
+    run<1 + 4 + 8>(in, out, taps, tab, n, ntaps, true);
+    run<2 + 4>(in, out, taps, tab, n, ntaps, true);
+    run<1 + 2 + 4 + 8>(in, out, taps, tab, n, ntaps, true);
+    return 0;
+}
