@@ -495,38 +495,89 @@ static bool mm_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in
     R->n = nr;
     // does run 0 continue the run the previous call ended in (same step, no reset in between)?  Then
     // the clock is exactly linear across the call boundary and the first windows may reach back
-    // into the raw history instead of going to the fix-up workgroups.
+    // into the raw history instead of going to the fix-up tasks.
     R->cont = c->rh_valid && (!c->has_shift || (P.segs.step[0] == c->rh_step && c->rh_len >= nt)) ? 1 : 0;
-    uint64_t cur = 0, fix_total = 0;
-    auto add_fix = [&](uint64_t a, uint64_t b) {
-        if (b <= a || F->n >= mm::kMaxFix) return;
-        F->m_a[F->n] = (uint32_t)a;
-        F->m_b[F->n] = (uint32_t)b;
-        F->wg_first[F->n] = F->n_wg;
-        F->n_wg += (int)((b - a + mm::kFixOut - 1) / mm::kFixOut);
-        F->n++;
-        fix_total += b - a;
-    };
+    // outputs whose whole window lies in run r (and that has a table): [lo, hi), on the tile grid
+    bool any = false;
     for (int r = 0; r < nr; r++) {
         const uint64_t a = c->has_shift ? P.segs.first[r] : 0;
         const uint64_t b = (c->has_shift && r + 1 < nr) ? P.segs.first[r + 1] : (uint64_t)n;
         void *dev = nullptr;
         (void)mm_table_for(c, c->has_shift ? P.segs.step[r] : 0.0, 0.0, &dev, false);
         uint64_t lo = (r == 0 && R->cont) ? 0 : (a + nt - 1 + D - 1) / D, hi = std::min((b + D - 1) / D, n_out);
-        lo += lo & 1;  // 16-byte output stores: chunks start on even outputs
-        R->wg_first[r] = R->n_wg;
+        lo = (lo + mm::kT - 1) / mm::kT * mm::kT;
+        if (hi < n_out) hi = hi / mm::kT * mm::kT;
         R->m_lo[r] = R->m_hi[r] = 0;
-        if (!dev || hi < lo + 64) continue;  // a run without a table, or too short to bother
-        add_fix(cur, lo);
-        cur = hi;
         R->tab[r] = dev;
+        if (!dev || hi < lo + 64) continue;  // a run without a table, or too short to bother
         R->m_lo[r] = (uint32_t)lo;
         R->m_hi[r] = (uint32_t)hi;
-        R->n_wg += (int)((hi - lo + mm::kChunkOut - 1) / mm::kChunkOut);
+        any = true;
     }
-    add_fix(cur, n_out);
-    // the fix-up workgroups are the slow way: a call that is mostly boundaries keeps the transforms
-    return R->n_wg > 0 && fix_total <= 16384 && fix_total * 4 <= n_out;
+    if (!any) return false;
+    // The call's outputs in chunks of 2048; a chunk goes to the run that holds most of it (none: the
+    // run of the chunk before), what that run does not hold goes to the fix-up tasks.
+    const uint64_t n_chunks = (n_out + mm::kChunkOut - 1) / mm::kChunkOut;
+    uint64_t fix_total = 0, fix_a = 0, fix_b = 0;  // the open fix interval [fix_a, fix_b)
+    auto flush_fix = [&]() {
+        if (fix_b > fix_a && F->n < mm::kMaxFix) {
+            F->m_a[F->n] = (uint32_t)fix_a;
+            F->m_b[F->n] = (uint32_t)fix_b;
+            F->wg_first[F->n] = F->n_wg;
+            F->n_wg += (int)((fix_b - fix_a + mm::kFixOut - 1) / mm::kFixOut);
+            F->n++;
+        } else if (fix_b > fix_a) {
+            fix_total = ~0ull >> 1;  // too many intervals: the call stays on the transform kernels
+        }
+        fix_a = fix_b = 0;
+    };
+    auto add_fix = [&](uint64_t a, uint64_t b) {
+        if (b <= a) return;
+        fix_total += b - a;
+        if (fix_b == a && fix_b > fix_a) {
+            fix_b = b;
+        } else {
+            flush_fix();
+            fix_a = a;
+            fix_b = b;
+        }
+    };
+    int owner = 0, prev_owner = -1;
+    for (int r = 0; r < nr; r++) R->wg_first[r] = (int)n_chunks;
+    for (uint64_t ch = 0; ch < n_chunks; ch++) {
+        const uint64_t cs = ch * mm::kChunkOut, ce = std::min(cs + mm::kChunkOut, n_out);
+        uint64_t best = 0;
+        for (int r = owner; r < nr; r++) {  // (the valid ranges ascend with r: the owner never goes back)
+            const uint64_t lo = std::max<uint64_t>(R->m_lo[r], cs), hi = std::min<uint64_t>(R->m_hi[r], ce);
+            if (hi > lo && hi - lo > best) {
+                best = hi - lo;
+                owner = r;
+            }
+        }
+        if (owner != prev_owner) {
+            for (int r = prev_owner + 1; r <= owner; r++) R->wg_first[r] = (int)ch;  // (runs skipped over own nothing)
+            prev_owner = owner;
+        }
+        const uint64_t vlo = std::max<uint64_t>(R->m_lo[owner], cs), vhi = std::min<uint64_t>(R->m_hi[owner], ce);
+        if (vlo < vhi) {
+            add_fix(cs, vlo);
+            add_fix(vhi, ce);
+        } else {
+            add_fix(cs, ce);
+        }
+    }
+    flush_fix();
+    R->n_wg = (int)n_chunks;
+    if (getenv("HZ_DEBUG_MM")) {
+        fprintf(stderr, "hzsdr mm: %d runs, cont %d, %llu chunks, %d fix intervals (%d tasks, %llu outputs)\n", nr, R->cont,
+                (unsigned long long)n_chunks, F->n, F->n_wg, (unsigned long long)fix_total);
+        for (int r = 0; r < nr; r++)
+            fprintf(stderr, "   run %d first %llu valid [%u, %u) first chunk %d table %p\n", r,
+                    (unsigned long long)(c->has_shift ? P.segs.first[r] : 0), R->m_lo[r], R->m_hi[r], R->wg_first[r], R->tab[r]);
+        for (int k = 0; k < F->n; k++) fprintf(stderr, "   fix [%u, %u) first task %d\n", F->m_a[k], F->m_b[k], F->wg_first[k]);
+    }
+    // the fix-up tasks are the slow way: a call that is mostly boundaries keeps the transforms
+    return fix_total <= 16384 && fix_total * 8 <= n_out;
 }
 
 template <int FMT>
@@ -540,7 +591,7 @@ static int mm_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const 
     const mm::Geom &g = c->mmg;
     const int D = (int)c->factor;
     const size_t lds = std::max(mm::chunk_bytes(D, g.ks), (size_t)(2 * g.ntaps + D * (mm::kFixOut - 1)) * 8);
-    const unsigned grid = (unsigned)(F.n_wg + (int)((g.off + mm::kThreads - 1) / mm::kThreads) + R.n_wg);
+    const unsigned grid = (unsigned)R.n_wg;  // (the fix-up and history tasks ride on the chunk workgroups)
     if constexpr (FMT == HZSDR_FMT_U8 || FMT == HZSDR_FMT_I8) {
         if (D == 8)
             launch_fv(mm::fir_mm_kernel<FMT, 8>, dim3(grid), dim3(mm::kThreads), lds, ctx->stream, in, (float2 *)out, hist,

@@ -48,7 +48,7 @@ constexpr int kNB = 4;                        // 32-tile column blocks per workg
 constexpr int kChunkTiles = 32 * kNB;         // 128
 constexpr int kChunkOut = kChunkTiles * kT;   // 2048 outputs per chunk workgroup
 constexpr int kThreads = 128;                 // two waves
-constexpr int kFixOut = 8;                    // outputs per fix-up workgroup
+constexpr int kFixOut = 16;                   // outputs per fix-up task
 constexpr int kMaxRuns = kNcoMaxSegs;
 constexpr int kMaxFix = kMaxRuns + 2;
 
@@ -63,7 +63,8 @@ struct Geom {
     unsigned off;  // history length (the chain's `off`)
 };
 
-// per clock run: the table, the outputs that take the matrix path and the first chunk workgroup
+// per clock run: the table, the outputs that take the matrix path (tile-aligned inside the call) and
+// the first chunk (2048 outputs of the call's grid) the host gave to the run
 struct Runs {
     int n;
     int n_wg;                 // chunk workgroups in total
@@ -124,24 +125,29 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     static_assert(D % 8 == 0, "windows start on 16-byte pieces");
     constexpr int TB = tile_bytes(D), PPT = pieces_per_tile(D);
     const int tid = threadIdx.x;
-    int wb = blockIdx.x;
-    // (the short fix-up and history workgroups come LAST in the grid: 1024 chunk workgroups fill the
-    // chip's 1024 slots exactly at 2^21 outputs, and a chunk that waits for a second round costs a
-    // quarter of the kernel)
-    if (wb >= R.n_wg) {
-        wb -= R.n_wg;
-    // ---- fix-up workgroups: reference order, direct form ----------------------------------
-        if (wb < F.n_wg) {
-            const int k = find_le(F.wg_first, F.n, wb);
-            const uint32_t m0 = F.m_a[k] + (uint32_t)(wb - F.wg_first[k]) * kFixOut;
+    const int wb = blockIdx.x;
+    // ---- the small tasks: outputs in reference order (fix-up) and the next call's history --------
+    // They have no workgroups of their own: as workgroups at the END of the grid each was a ~8 us
+    // latency chain (load, Sincos, dot product, store) behind the chunk workgroups, and ahead of them
+    // they push chunk workgroups out of the single round the chip holds (1024 at 2^21 outputs).  A
+    // chunk workgroup takes task b, b + grid, ... after its own stores (at its start, under the
+    // input burst of every workgroup at once, a task's loads took 7 us to come back).
+    const int n_hist_tasks = new_hist ? (int)((G.off + kThreads - 1) / kThreads) : 0;
+    const int n_tasks = F.n_wg + n_hist_tasks;
+    auto small_task = [&](int task) {
+        using RW = typename Raw<FMT>::t;
+        if (task < F.n_wg) {
+            // Up to 16 outputs: their window's samples in reference order (load, convert, elementwise
+            // program: three Sincos chains side by side per lane and trip) and the taps go to LDS (the
+            // chunk image is dead by now), then 8 lanes per output run the direct form in float64.
+            const int k = find_le(F.wg_first, F.n, task);
+            const uint32_t m0 = F.m_a[k] + (uint32_t)(task - F.wg_first[k]) * kFixOut;
             const int cnt = (int)min((uint32_t)kFixOut, F.m_b[k] - m0);
-            float2 *xs = reinterpret_cast<float2 *>(mm_lds);   // the window's samples, in reference order
-            float2 *tl = xs + (G.ntaps + D * (kFixOut - 1));    // the taps
+            float2 *xs = reinterpret_cast<float2 *>(mm_lds);
+            float2 *tl = xs + (G.ntaps + D * (kFixOut - 1));
             const int64_t p_lo = (int64_t)D * m0 - (G.ntaps - 1);
             const int n_s = G.ntaps + D * (cnt - 1);
             for (int idx = tid; idx < G.ntaps; idx += kThreads) tl[idx] = taps[idx];
-            // three samples per lane and trip: their loads, then their Sincos chains side by side
-            using RW = typename Raw<FMT>::t;
             constexpr int W = 3;
 #pragma unroll 1
             for (int i0 = tid; i0 < n_s; i0 += W * kThreads) {
@@ -152,85 +158,69 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                     const bool ok = i0 + u * kThreads < n_s && pu >= 0;
                     v[u] = Raw<FMT>::cvt(ok ? ((const RW *)in)[pu] : RW{});
                 }
-                const int64_t pj = p_lo + i0;
                 // (positions before the buffer wrap around in uint64 and come back: their values are discarded)
-                ew_apply_n<W, true>(P, v, (uint64_t)pj, nco_window_all(P.segs), (uint64_t)kThreads);
+                ew_apply_n<W, true>(P, v, (uint64_t)(p_lo + i0), nco_window_all(P.segs), (uint64_t)kThreads);
 #pragma unroll
                 for (int u = 0; u < W; u++) {
                     const int idx = i0 + u * kThreads;
                     const int64_t pu = p_lo + idx;
-                    if (idx < n_s) xs[idx] = pu >= 0 ? v[u] : (hist ? hist[pu + (int64_t)G.off] : make_float2(0.f, 0.f));
+                    if (idx < n_s)
+                        xs[idx] = pu >= 0 ? v[u] : ((hist && pu + (int64_t)G.off >= 0) ? hist[pu + (int64_t)G.off] : make_float2(0.f, 0.f));
                 }
             }
             __syncthreads();
-            const int o = tid >> 4, sl = tid & 15;  // output, tap slice (k = sl mod 16)
+            const int o = tid >> 3, sl = tid & 7;  // output, tap slice (k = sl mod 8)
             double ar = 0.0, ai = 0.0;
             if (o < cnt) {
                 const float2 *xo = xs + D * o + (G.ntaps - 1);
-#pragma unroll 1
-                for (int k0 = sl; k0 < G.ntaps; k0 += 16 * 8) {
-                    float2 hh[8], xx[8];  // eight taps in flight
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const int kk = k0 + 16 * u, kc = kk < G.ntaps ? kk : 0;
-                        hh[u] = tl[kc];
-                        xx[u] = xo[-kc];
-                        if (kk >= G.ntaps) hh[u] = make_float2(0.f, 0.f);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const double xr = xx[u].x, xi = xx[u].y, hr = hh[u].x, hi = hh[u].y;
-                        ar = __fma_rn(xr, hr, ar);
-                        ar = __fma_rn(-xi, hi, ar);
-                        ai = __fma_rn(xr, hi, ai);
-                        ai = __fma_rn(xi, hr, ai);
-                    }
+#pragma unroll 4
+                for (int kk = sl; kk < G.ntaps; kk += 8) {
+                    const float2 hk = tl[kk], x = xo[-kk];
+                    const double xr = x.x, xi = x.y, hr = hk.x, hi = hk.y;
+                    ar = __fma_rn(xr, hr, ar);
+                    ar = __fma_rn(-xi, hi, ar);
+                    ai = __fma_rn(xr, hi, ai);
+                    ai = __fma_rn(xi, hr, ai);
                 }
             }
 #pragma unroll
-            for (int d = 1; d < 16; d <<= 1) {
+            for (int d = 1; d < 8; d <<= 1) {
                 ar += __shfl_xor(ar, d);
                 ai += __shfl_xor(ai, d);
             }
             if (o < cnt && sl == 0) out[m0 + o] = make_float2((float)ar, (float)ai);
-            return;
-        }
-        wb -= F.n_wg;
-
-        // ---- history workgroups: the last `off` samples after the elementwise program ------------
-        const int n_hist_wg = new_hist ? (int)((G.off + kThreads - 1) / kThreads) : 0;
-        if (wb < n_hist_wg) {
-            const unsigned idx = (unsigned)wb * kThreads + tid;
+        } else {
+            // 128 samples of the history: the last `off` samples after the elementwise program, and the
+            // same samples as raw bytes (the next call's windows reach back into them when the clock
+            // run continues across the call boundary, Runs::cont)
+            const unsigned idx = (unsigned)(task - F.n_wg) * kThreads + tid;
             if (idx < G.off) {
                 const int64_t p = (int64_t)n_in - (int64_t)G.off + idx;
                 new_hist[idx] = ordered_sample<FMT>(in, P, p, hist, G.off);
-                // the same samples as raw bytes: the next call's windows reach back into them when
-                // the clock run continues across the call boundary (Runs::cont)
-                using RW = typename Raw<FMT>::t;
                 reinterpret_cast<RW *>(new_rhist)[idx] = p >= 0 ? ((const RW *)in)[p] : reinterpret_cast<const RW *>(rhist)[p + (int64_t)G.off];
             }
-            return;
         }
-        wb -= n_hist_wg;
-        return;
-    }
+        __syncthreads();  // (LDS: the reduction's slots are the chunk image's first bytes)
+    };
 
-
-    // ---- chunk workgroups: 2048 outputs of one clock run ---------------------------------------
+    // ---- the chunk: outputs [2048 b, 2048 b + 2048) of the call, filtered with the taps of ONE clock
+    // run (the host gave the chunk to the run that holds most of it); the outputs [v_lo, v_hi) of it
+    // lie wholly in that run and are stored, the others belong to fix-up tasks.  (Chunks anchored at
+    // the runs' starts instead made 1025 workgroups out of a 2^21-output call with one clock boundary
+    // -- one more than the chip holds at once, a second round for a single workgroup: +10 us.)
     const int r = __builtin_amdgcn_readfirstlane(find_le(R.wg_first, R.n, wb));
-    const uint32_t m_start = R.m_lo[r] + (uint32_t)(wb - R.wg_first[r]) * kChunkOut;
-    const uint32_t count = min((uint32_t)kChunkOut, R.m_hi[r] - m_start);
+    const uint32_t m_start = (uint32_t)wb * kChunkOut;
+    const uint32_t v_lo = max(R.m_lo[r], m_start), v_hi = min(R.m_hi[r], m_start + (uint32_t)kChunkOut);
+    const bool active = v_lo < v_hi;  // uniform
     const int wave = tid >> 6, l = tid & 63, n = l & 31, h = l >> 5, i = n >> 1, part = n & 1;
     const int64_t n_bytes = 2 * (int64_t)n_in;
-    {
+    if (active) {
         // the chunk's input bytes: from the window start of its first tile
         const int64_t p0 = 2 * ((int64_t)D * m_start - G.w0);
         const int pieces = (int)(chunk_bytes(D, G.ks) / 16);
         const uint8_t *src = (const uint8_t *)in;
         constexpr int U = 9;  // loads in flight per lane and trip
-#pragma unroll 1
-        for (int q0 = tid; q0 < pieces; q0 += U * kThreads) {
-            v4i x[U];
+        auto issue = [&](v4i(&x)[U], int q0) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int q = q0 + u * kThreads;
@@ -251,6 +241,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                     }
                 }
             }
+        };
+        auto land = [&](v4i(&x)[U], int q0) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const int q = q0 + u * kThreads;
@@ -259,193 +251,211 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                     *reinterpret_cast<v4i *>(mm_lds + sw<D>(q / PPT, q % PPT)) = x[u];
                 }
             }
+        };
+        v4i x[U];
+        issue(x, tid);
+        land(x, tid);
+#pragma unroll 1
+        for (int q0 = tid + U * kThreads; q0 < pieces; q0 += U * kThreads) {
+            issue(x, q0);
+            land(x, q0);
         }
     }
-    __syncthreads();
-    // A fragments: entry (D/8) i - h - 2 s + e0 of this wave's two digits, parts interleaved
-    const v4i *ftab = (const v4i *)R.tab[r];
-    const v4i *fa = ftab + (size_t)(2 * wave) * 2 * G.ne + 2 * ((D / 8) * i - h + G.e0) + part;
-    const int dstride = 2 * G.ne;
-    v16i acc[2][kNB];
-#pragma unroll
-    for (int d = 0; d < 2; d++)
-#pragma unroll
-        for (int j = 0; j < kNB; j++)
-#pragma unroll
-            for (int q = 0; q < 16; q++) acc[d][j][q] = 0;
-    // Step s of the window reads piece 2 s + h of tile n (+ 32 j): with GS = PPT / 2 steps per group
-    // the tile is n + g and the piece 2 j + h for step j of group g -- the swizzled address is
-    // 16 ((2 j) ^ xh) past the group's base, xh = ((n + g) & 15) ^ h: two instructions per step.
-    constexpr int GS = PPT / 2;
-    auto load_b = [&](v4i(&b)[kNB], int base, int xh, int j) {
-        const uint8_t *bp = mm_lds + base + 16 * ((2 * j) ^ xh);
-#pragma unroll
-        for (int q = 0; q < kNB; q++) b[q] = *reinterpret_cast<const v4i *>(bp + q * 32 * TB);
-    };
-    auto load_a = [&](v4i(&a)[2], int s) {
-#pragma unroll
-        for (int d = 0; d < 2; d++) a[d] = fa[d * dstride - 4 * s];
-    };
-    auto mma = [&](const v4i(&a)[2], const v4i(&b)[kNB]) {
-#pragma unroll
+    if (active) {
+        __syncthreads();
+        // A fragments: entry (D/8) i - h - 2 s + e0 of this wave's two digits, parts interleaved
+        const v4i *ftab = (const v4i *)R.tab[r];
+        const v4i *fa = ftab + (size_t)(2 * wave) * 2 * G.ne + 2 * ((D / 8) * i - h + G.e0) + part;
+        const int dstride = 2 * G.ne;
+        v16i acc[2][kNB];
+    #pragma unroll
         for (int d = 0; d < 2; d++)
-#pragma unroll
-            for (int q = 0; q < kNB; q++) acc[d][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d], b[q], acc[d][q], 0, 0, 0);
-    };
-    {
-        // Operands ahead of the MFMAs that use them: the bytes one step (LDS), the taps FOUR steps
-        // (the table shares the L1 with the chunk's streaming loads and often comes from L2, 500+
-        // cycles against the 256 of a step's MFMAs: one step ahead left the matrix pipe idle half
-        // of the loop).  Inside a step the loads go between the MFMAs (sched_group_barrier): issued
-        // as a clump after them, the wave's own MFMA stream had a ~100-cycle hole per step.
-        // ks is a multiple of GS and the table is padded by four steps in front.
-        v4i a[4][2], b[2][kNB];
-#pragma unroll
-        for (int q = 0; q < 4; q++) load_a(a[q], q);
-        int t = n, base = TB * t, xh = (t & 15) ^ h;
-        load_b(b[0], base, xh, 0);
-        const int groups = ((EXP & 2) ? 0 : G.ks) / GS;
-#pragma unroll 1
-        for (int g = 0; g < groups; g++) {
-            const int tn = t + 1, base_n = TB * tn, xh_n = (tn & 15) ^ h;
-#pragma unroll
-            for (int j = 0; j < GS; j++) {
-                if (j + 1 < GS) load_b(b[(j + 1) & 1], base, xh, j + 1);
-                else load_b(b[(j + 1) & 1], base_n, xh_n, 0);  // (past the window after the last group: unused)
-                mma(a[j & 3], b[j & 1]);
-                load_a(a[j & 3], g * GS + j + 4);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // the address of the step's reads
-#pragma unroll
-                for (int q = 0; q < kNB; q++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // LDS read
+    #pragma unroll
+            for (int j = 0; j < kNB; j++)
+    #pragma unroll
+                for (int q = 0; q < 16; q++) acc[d][j][q] = 0;
+        // Step s of the window reads piece 2 s + h of tile n (+ 32 j): with GS = PPT / 2 steps per group
+        // the tile is n + g and the piece 2 j + h for step j of group g -- the swizzled address is
+        // 16 ((2 j) ^ xh) past the group's base, xh = ((n + g) & 15) ^ h: two instructions per step.
+        constexpr int GS = PPT / 2;
+        auto load_b = [&](v4i(&b)[kNB], int base, int xh, int j) {
+            const uint8_t *bp = mm_lds + base + 16 * ((2 * j) ^ xh);
+    #pragma unroll
+            for (int q = 0; q < kNB; q++) b[q] = *reinterpret_cast<const v4i *>(bp + q * 32 * TB);
+        };
+        auto load_a = [&](v4i(&a)[2], int s) {
+    #pragma unroll
+            for (int d = 0; d < 2; d++) a[d] = fa[d * dstride - 4 * s];
+        };
+        auto mma = [&](const v4i(&a)[2], const v4i(&b)[kNB]) {
+    #pragma unroll
+            for (int d = 0; d < 2; d++)
+    #pragma unroll
+                for (int q = 0; q < kNB; q++) acc[d][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d], b[q], acc[d][q], 0, 0, 0);
+        };
+        {
+            // Operands ahead of the MFMAs that use them: the bytes two steps (LDS), the taps FOUR steps
+            // (the table shares the L1 with the chunk's streaming loads and often comes from L2, 500+
+            // cycles against the 256 of a step's MFMAs: one step ahead left the matrix pipe idle half
+            // of the loop).  Inside a step the loads go between the MFMAs (sched_group_barrier): issued
+            // as a clump after them, the wave's own MFMA stream had a ~100-cycle hole per step.
+            // ks is a multiple of GS and the table is padded by four steps in front.
+            v4i a[4][2], b[4][kNB];
+    #pragma unroll
+            for (int q = 0; q < 4; q++) load_a(a[q], q);
+            int t = n, base = TB * t, xh = (t & 15) ^ h;
+            load_b(b[0], base, xh, 0);
+            load_b(b[1], base, xh, 1);
+            const int groups = ((EXP & 2) ? 0 : G.ks) / GS;
+    #pragma unroll 1
+            for (int g = 0; g < groups; g++) {
+                const int tn = t + 1, base_n = TB * tn, xh_n = (tn & 15) ^ h;
+    #pragma unroll
+                for (int j = 0; j < GS; j++) {
+                    if (j + 2 < GS) load_b(b[(j + 2) & 3], base, xh, j + 2);
+                    else load_b(b[(j + 2) & 3], base_n, xh_n, j + 2 - GS);  // (past the window after the last group: unused)
+                    mma(a[j & 3], b[j & 3]);
+                    load_a(a[j & 3], g * GS + j + 4);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // the address of the step's reads
+    #pragma unroll
+                    for (int q = 0; q < kNB; q++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // LDS read
+                    }
+    #pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // table load
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * kNB - kNB - 2, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // table load
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 2 * kNB - kNB - 2, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                t = tn;
+                base = base_n;
+                xh = xh_n;
             }
-            t = tn;
-            base = base_n;
-            xh = xh_n;
         }
-    }
-    // The halves meet: wave 0 (digits 0-1) finishes column blocks 0-1, wave 1 (digits 2-3) blocks 2-3.
-    // hi = acc0 * 256 + acc1 is exact in float64; the low pair's weight is 2^-16: float32 is enough.
-    __syncthreads();  // both waves are done with the chunk's bytes
-    double *xhi = reinterpret_cast<double *>(mm_lds);              // [2][16][64]
-    float *xlo = reinterpret_cast<float *>(mm_lds + 2 * 16 * 64 * 8);  // [2][16][64]
-    if (wave == 0) {
-#pragma unroll
+        // The halves meet: wave 0 (digits 0-1) finishes column blocks 0-1, wave 1 (digits 2-3) blocks 2-3.
+        // hi = acc0 * 256 + acc1 is exact in float64; the low pair's weight is 2^-16: float32 is enough.
+        __syncthreads();  // both waves are done with the chunk's bytes
+        double *xhi = reinterpret_cast<double *>(mm_lds);              // [2][16][64]
+        float *xlo = reinterpret_cast<float *>(mm_lds + 2 * 16 * 64 * 8);  // [2][16][64]
+        if (wave == 0) {
+    #pragma unroll
+            for (int j = 0; j < 2; j++)
+    #pragma unroll
+                for (int q = 0; q < 16; q++)
+                    xhi[(j * 16 + q) * 64 + l] = __fma_rn((double)acc[0][2 + j][q], 256.0, (double)acc[1][2 + j][q]);
+        } else {
+    #pragma unroll
+            for (int j = 0; j < 2; j++)
+    #pragma unroll
+                for (int q = 0; q < 16; q++)
+                    xlo[(j * 16 + q) * 64 + l] = __fmaf_rn((float)acc[0][j][q], 256.0f, (float)acc[1][j][q]);
+        }
+        __syncthreads();
+        const double *dc = reinterpret_cast<const double *>((const uint8_t *)R.tab[r] + (size_t)4 * G.ne * 32);
+        const double dcr = dc[0], dci = dc[1];
+        const double scale = __hiloint2double((1023 - G.shift) << 20, 0);  // 2^-S
+        float2 y[2][8];  // [own block][4 q4 + ... ]: outputs 4 q4 + 2 h + e of tile 32 (2 wave + j) + n
+    #pragma unroll
         for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int q = 0; q < 16; q++)
-                xhi[(j * 16 + q) * 64 + l] = __fma_rn((double)acc[0][2 + j][q], 256.0, (double)acc[1][2 + j][q]);
-    } else {
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int q = 0; q < 16; q++)
-                xlo[(j * 16 + q) * 64 + l] = __fmaf_rn((float)acc[0][j][q], 256.0f, (float)acc[1][j][q]);
+    #pragma unroll
+            for (int q4 = 0; q4 < 4; q4++)
+    #pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    float c2[2];
+    #pragma unroll
+                    for (int pt = 0; pt < 2; pt++) {
+                        const int q = 4 * q4 + 2 * e + pt;
+                        double hi, lo;
+                        if (wave == 0) {
+                            hi = __fma_rn((double)acc[0][j][q], 256.0, (double)acc[1][j][q]);
+                            lo = (double)xlo[(j * 16 + q) * 64 + l];
+                        } else {
+                            hi = xhi[(j * 16 + q) * 64 + l];
+                            lo = (double)__fmaf_rn((float)acc[0][2 + j][q], 256.0f, (float)acc[1][2 + j][q]);
+                        }
+                        const double v = __fma_rn(hi, 65536.0, lo) + (pt ? dci : dcr);
+                        c2[pt] = (float)(v * scale);
+                    }
+                    y[j][2 * q4 + e] = make_float2(c2[0], c2[1]);
+                }
+        // The elementwise program over this lane's 16 outputs m = mb + 512 j + 4 q4 + e: equally spaced
+        // in three directions inside one exactly-linear clock run, so a Shift stage is
+        // z0 * wB^j * wA^q4 * wE^e (see ew_apply_seq for the error argument).
+        const uint32_t mb = m_start + (uint32_t)(32 * 2 * wave + n) * kT + 2 * h;
+    #pragma unroll 1
+        for (int oi = 0; oi < ((EXP & 4) ? 0 : P.n); oi++) {  // uniform
+            const EwOp &o = P.op[oi];
+            if (o.kind == EW_SCALE) {
+    #pragma unroll
+                for (int j = 0; j < 2; j++)
+    #pragma unroll
+                    for (int q = 0; q < 8; q++) y[j][q] = make_float2(__fmul_rn(y[j][q].x, o.a), __fmul_rn(y[j][q].y, o.a));
+            } else if (o.kind == EW_ROTATE) {
+    #pragma unroll
+                for (int j = 0; j < 2; j++)
+    #pragma unroll
+                    for (int q = 0; q < 8; q++) y[j][q] = go_cmul(y[j][q], make_float2(o.a, o.b));
+            } else {
+                // the clock at the lane's first output, by the run's line -- also for a lane whose first
+                // outputs lie BEFORE the run (a chunk may start in the previous run; those outputs are
+                // not stored, but the recurrence to the lane's valid ones starts there)
+                const double step = P.segs.step[r];
+                const int64_t dj = (int64_t)((uint64_t)D * mb) - (int64_t)P.segs.first[r];
+                const double ts0 = __fma_rn((double)dj, step, P.segs.t0[r]);
+                double z0s, z0c, es, ec, as, ac, bs, bc;
+                sincos_late(__dmul_rn(o.tau_shift, ts0), z0s, z0c);
+                sincos_late(__dmul_rn(o.tau_shift, __dmul_rn((double)D, step)), es, ec);
+                sincos_late(__dmul_rn(o.tau_shift, __dmul_rn((double)(4 * D), step)), as, ac);
+                sincos_late(__dmul_rn(o.tau_shift, __dmul_rn((double)(32 * kT * D), step)), bs, bc);
+    #pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    double zc = z0c, zs = z0s;
+    #pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) {
+                        y[j][2 * q4] = go_cmul(y[j][2 * q4], make_float2((float)zc, (float)zs));
+                        const double ze_c = __fma_rn(zc, ec, -(zs * es)), ze_s = __fma_rn(zc, es, zs * ec);
+                        y[j][2 * q4 + 1] = go_cmul(y[j][2 * q4 + 1], make_float2((float)ze_c, (float)ze_s));
+                        const double nc = __fma_rn(zc, ac, -(zs * as)), ns = __fma_rn(zc, as, zs * ac);
+                        zc = nc;
+                        zs = ns;
+                    }
+                    const double nc = __fma_rn(z0c, bc, -(z0s * bs)), ns = __fma_rn(z0c, bs, z0s * bc);
+                    z0c = nc;
+                    z0s = ns;
+                }
+            }
+        }
+        // Stores: a lane holds eight outputs of each of its tiles, 128 bytes apart from the next lane's --
+        // through LDS (16-byte pieces swizzled by the tile index) a wave writes whole 1 KiB rows instead
+        // (direct 8-byte stores cost 10 us of the kernel's 46).
+        __syncthreads();  // the exchange buffers have been read
+        {
+            float4 *yl = reinterpret_cast<float4 *>(mm_lds) + wave * (2 * 32 * 8);  // [2 blocks][32 tiles][8 pieces]
+    #pragma unroll
+            for (int j = 0; j < 2; j++)
+    #pragma unroll
+                for (int q4 = 0; q4 < 4; q4++)
+                    yl[(j * 32 + n) * 8 + ((2 * q4 + h) ^ (n & 7))] =
+                        make_float4(y[j][2 * q4].x, y[j][2 * q4].y, y[j][2 * q4 + 1].x, y[j][2 * q4 + 1].y);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+    #pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int idx = it * 64 + l, tile = idx >> 3, piece = idx & 7;  // tile = 32 j + n
+                const float4 v = yl[tile * 8 + (piece ^ (tile & 7))];
+                const uint32_t rel = (uint32_t)(64 * wave + tile) * kT + 2 * piece;
+                const uint32_t mo = m_start + rel;  // (even: v_lo and v_hi are even except the call's last output)
+            const bool st = (EXP & 8) == 0 && mo >= v_lo;
+            if (st && mo + 1 < v_hi) *reinterpret_cast<float4 *>(out + mo) = v;
+                else if (st && mo < v_hi) out[mo] = make_float2(v.x, v.y);
+            }
+        }
     }
     __syncthreads();
-    const double *dc = reinterpret_cast<const double *>((const uint8_t *)R.tab[r] + (size_t)4 * G.ne * 32);
-    const double dcr = dc[0], dci = dc[1];
-    const double scale = __hiloint2double((1023 - G.shift) << 20, 0);  // 2^-S
-    float2 y[2][8];  // [own block][4 q4 + ... ]: outputs 4 q4 + 2 h + e of tile 32 (2 wave + j) + n
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; q4++)
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                float c2[2];
-#pragma unroll
-                for (int pt = 0; pt < 2; pt++) {
-                    const int q = 4 * q4 + 2 * e + pt;
-                    double hi, lo;
-                    if (wave == 0) {
-                        hi = __fma_rn((double)acc[0][j][q], 256.0, (double)acc[1][j][q]);
-                        lo = (double)xlo[(j * 16 + q) * 64 + l];
-                    } else {
-                        hi = xhi[(j * 16 + q) * 64 + l];
-                        lo = (double)__fmaf_rn((float)acc[0][2 + j][q], 256.0f, (float)acc[1][2 + j][q]);
-                    }
-                    const double v = __fma_rn(hi, 65536.0, lo) + (pt ? dci : dcr);
-                    c2[pt] = (float)(v * scale);
-                }
-                y[j][2 * q4 + e] = make_float2(c2[0], c2[1]);
-            }
-    // The elementwise program over this lane's 16 outputs m = mb + 512 j + 4 q4 + e: equally spaced
-    // in three directions inside one exactly-linear clock run, so a Shift stage is
-    // z0 * wB^j * wA^q4 * wE^e (see ew_apply_seq for the error argument).
-    const uint32_t mb = m_start + (uint32_t)(32 * 2 * wave + n) * kT + 2 * h;
-    const NcoWin w{r, r};
-#pragma unroll 1
-    for (int oi = 0; oi < ((EXP & 4) ? 0 : P.n); oi++) {  // uniform
-        const EwOp &o = P.op[oi];
-        if (o.kind == EW_SCALE) {
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int q = 0; q < 8; q++) y[j][q] = make_float2(__fmul_rn(y[j][q].x, o.a), __fmul_rn(y[j][q].y, o.a));
-        } else if (o.kind == EW_ROTATE) {
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int q = 0; q < 8; q++) y[j][q] = go_cmul(y[j][q], make_float2(o.a, o.b));
-        } else {
-            const double ts0 = nco_ts(P.segs, w, (uint64_t)D * mb);
-            const double step = P.segs.step[r];
-            double z0s, z0c, es, ec, as, ac, bs, bc;
-            sincos_late(__dmul_rn(o.tau_shift, ts0), z0s, z0c);
-            sincos_late(__dmul_rn(o.tau_shift, __dmul_rn((double)D, step)), es, ec);
-            sincos_late(__dmul_rn(o.tau_shift, __dmul_rn((double)(4 * D), step)), as, ac);
-            sincos_late(__dmul_rn(o.tau_shift, __dmul_rn((double)(32 * kT * D), step)), bs, bc);
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                double zc = z0c, zs = z0s;
-#pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                    y[j][2 * q4] = go_cmul(y[j][2 * q4], make_float2((float)zc, (float)zs));
-                    const double ze_c = __fma_rn(zc, ec, -(zs * es)), ze_s = __fma_rn(zc, es, zs * ec);
-                    y[j][2 * q4 + 1] = go_cmul(y[j][2 * q4 + 1], make_float2((float)ze_c, (float)ze_s));
-                    const double nc = __fma_rn(zc, ac, -(zs * as)), ns = __fma_rn(zc, as, zs * ac);
-                    zc = nc;
-                    zs = ns;
-                }
-                const double nc = __fma_rn(z0c, bc, -(z0s * bs)), ns = __fma_rn(z0c, bs, z0s * bc);
-                z0c = nc;
-                z0s = ns;
-            }
-        }
-    }
-    // Stores: a lane holds eight outputs of each of its tiles, 128 bytes apart from the next lane's --
-    // through LDS (16-byte pieces swizzled by the tile index) a wave writes whole 1 KiB rows instead
-    // (direct 8-byte stores cost 10 us of the kernel's 46).
-    __syncthreads();  // the exchange buffers have been read
-    {
-        float4 *yl = reinterpret_cast<float4 *>(mm_lds) + wave * (2 * 32 * 8);  // [2 blocks][32 tiles][8 pieces]
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; q4++)
-                yl[(j * 32 + n) * 8 + ((2 * q4 + h) ^ (n & 7))] =
-                    make_float4(y[j][2 * q4].x, y[j][2 * q4].y, y[j][2 * q4 + 1].x, y[j][2 * q4 + 1].y);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int idx = it * 64 + l, tile = idx >> 3, piece = idx & 7;  // tile = 32 j + n
-            const float4 v = yl[tile * 8 + (piece ^ (tile & 7))];
-            const uint32_t rel = (uint32_t)(64 * wave + tile) * kT + 2 * piece;
-            if (rel + 1 < ((EXP & 8) ? 0u : count)) *reinterpret_cast<float4 *>(out + m_start + rel) = v;
-            else if (rel < ((EXP & 8) ? 0u : count)) out[m_start + rel] = make_float2(v.x, v.y);
-        }
-    }
+    for (int task = wb; task < n_tasks; task += (int)gridDim.x) small_task(task);  // (uniform)
 }
 
 }  // namespace mm

@@ -44,17 +44,17 @@ template <int EXP> static void run(void *const *in, float2 *out, const float2 *t
     // steady state: run 0 continues the previous call's run (no fix-up workgroups); FIX=1: a first call
     const bool fix = getenv("FIX") != nullptr;
     R.cont = fix ? 0 : 1;
-    R.m_lo[0] = fix ? lo : 0;
+    R.m_lo[0] = fix ? (lo + mm::kT - 1) / mm::kT * mm::kT : 0;
     R.m_hi[0] = n_out;
-    R.n_wg = (int)((n_out - R.m_lo[0] + mm::kChunkOut - 1) / mm::kChunkOut);
+    R.n_wg = (int)((n_out + mm::kChunkOut - 1) / mm::kChunkOut);
     if (fix) {
         F.n = 1;
         F.m_a[0] = 0;
-        F.m_b[0] = lo;
-        F.n_wg = (int)((lo + mm::kFixOut - 1) / mm::kFixOut);
+        F.m_b[0] = R.m_lo[0];
+        F.n_wg = (int)((R.m_lo[0] + mm::kFixOut - 1) / mm::kFixOut);
     }
     const size_t lds = mm::chunk_bytes(D, g.ks);
-    const unsigned grid = (unsigned)(R.n_wg + F.n_wg + (g.off + mm::kThreads - 1) / mm::kThreads);
+    const unsigned grid = (unsigned)R.n_wg;
     auto k = mm::fir_mm_kernel<HZSDR_FMT_U8, D, EXP>;
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
