@@ -21,8 +21,9 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (CONV_CONVOLVE, CONV_CROSS_CORRELATE, FFT_BACKWARD, FFT_FORWARD, FMT_C64,
-                    FMT_I8, FMT_I16, FMT_U8, MEM_DEVICE, MEM_HOST, lib)
+from ._capi import (CONV_CONVOLVE, CONV_CROSS_CORRELATE, FFT_BACKWARD, FFT_FORWARD, FIR_PATH_MATRIX,
+                    FIR_PATH_NONE, FIR_PATH_TRANSFORM, FMT_C64, FMT_I8, FMT_I16, FMT_U8, MEM_DEVICE,
+                    MEM_HOST, lib)
 
 SampleFormatC64, SampleFormatU8, SampleFormatI16, SampleFormatI8 = FMT_C64, FMT_U8, FMT_I16, FMT_I8
 
@@ -583,6 +584,12 @@ class Chain:
         t = C.c_double(0.0)
         self.ctx._ck(lib.hzsdr_chain_time(self._h, C.byref(t)))
         return t.value
+
+    def last_fir_path(self):
+        """FIR_PATH_NONE / _TRANSFORM / _MATRIX: the kernels the last run of a FIR-decimate chain used."""
+        p = C.c_int32(0)
+        self.ctx._ck(lib.hzsdr_chain_last_fir_path(self._h, C.byref(p)))
+        return p.value
 
     def ring(self, slot_length, slots=4):
         return Ring(self, slot_length, slots)

@@ -50,6 +50,7 @@ lib = C.CDLL(LIB_PATH)
 FMT_C64, FMT_U8, FMT_I16, FMT_I8 = 1, 2, 3, 4
 MEM_HOST, MEM_DEVICE = 0, 1
 FFT_BACKWARD, FFT_FORWARD = 0, 1
+FIR_PATH_NONE, FIR_PATH_TRANSFORM, FIR_PATH_MATRIX = 0, 1, 2
 CONV_CONVOLVE, CONV_CROSS_CORRELATE = 0, 1
 
 (OK, ERR_FORMAT_MISMATCH, ERR_FORMAT_UNKNOWN, ERR_DST_TOO_SMALL, ERR_CONVERSION_NOT_IMPLEMENTED,
@@ -152,6 +153,7 @@ SIGNATURES = {
     "hzsdr_chain_reset": (i32, [vp]),
     "hzsdr_chain_set_time": (i32, [vp, f64]),
     "hzsdr_chain_time": (i32, [vp, C.POINTER(f64)]),
+    "hzsdr_chain_last_fir_path": (i32, [vp, C.POINTER(i32)]),
     "hzsdr_chain_free": (i32, [vp]),
     "hzsdr_ring_create": (i32, [vp, sz, i32, pvp]),
     "hzsdr_ring_iq_buffer": (i32, [vp, pvp, psz, psz]),

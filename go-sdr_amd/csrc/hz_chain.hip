@@ -67,6 +67,7 @@ struct hzsdr_chain {
     bool rh_valid = false;
     double rh_step = 0.0;
     uint64_t rh_len = 0;
+    int last_path = HZSDR_FIR_PATH_NONE;
 };
 
 struct hzsdr_conv {
@@ -717,6 +718,7 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
             if (mm_plan(c, P, n_cons, in, out, &R, &F)) {
                 HZ_TRY(mm_launch<FMT>(c, in, out, n_cons, P, R, F));
                 c->hist_cur ^= 1;
+                c->last_path = HZSDR_FIR_PATH_MATRIX;
                 // the raw history now ends in this call's last clock run
                 const bool was = c->rh_valid;
                 c->rh_valid = n_cons >= c->off || was;
@@ -804,6 +806,7 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
 #undef HZ_SYNTH16
         c->hist_cur ^= 1;  // the kernel wrote the next run's history into nhist
         c->rh_valid = false;  // (the transform kernels keep no raw history)
+        c->last_path = HZSDR_FIR_PATH_TRANSFORM;
         break;
     }
     }
@@ -1111,6 +1114,12 @@ int hzsdr_chain_free(hzsdr_chain *c) {
     if (c->rhist[0]) (void)hipFree(c->rhist[0]);
     if (c->rhist[1]) (void)hipFree(c->rhist[1]);
     delete c;
+    return HZSDR_OK;
+}
+
+int hzsdr_chain_last_fir_path(const hzsdr_chain *c, int *path) {
+    if (!c || !path) return HZSDR_ERR_INVALID_ARGUMENT;
+    *path = c->last_path;
     return HZSDR_OK;
 }
 

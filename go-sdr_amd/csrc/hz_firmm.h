@@ -116,6 +116,8 @@ __device__ __forceinline__ float2 ordered_sample(const void *in, const EwProgram
 
 // EXP: ablation switches for tools/mfma_fir.hip (0 in the library): 1 = no input loads, 2 = no
 // matrix loop, 4 = no elementwise program, 8 = no stores.  Results are wrong with any of them set.
+// (Switching the loop's operand loads off does not time the MFMAs alone: with undefined operands the
+// compiler deletes the loop.  tools/mfma_rate.hip has the loop's MFMA pattern with and without loads.)
 template <int FMT, int D, int EXP = 0>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_mm_kernel(
     const void *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ hist,
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         };
         v4i x[U];
         issue(x, tid);
+        for (int task = wb; task < n_tasks; task += (int)gridDim.x) small_task(task);  // (uniform)
         land(x, tid);
 #pragma unroll 1
         for (int q0 = tid + U * kThreads; q0 < pieces; q0 += U * kThreads) {
@@ -268,11 +271,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         const v4i *fa = ftab + (size_t)(2 * wave) * 2 * G.ne + 2 * ((D / 8) * i - h + G.e0) + part;
         const int dstride = 2 * G.ne;
         v16i acc[2][kNB];
-    #pragma unroll
+#pragma unroll
         for (int d = 0; d < 2; d++)
-    #pragma unroll
+#pragma unroll
             for (int j = 0; j < kNB; j++)
-    #pragma unroll
+#pragma unroll
                 for (int q = 0; q < 16; q++) acc[d][j][q] = 0;
         // Step s of the window reads piece 2 s + h of tile n (+ 32 j): with GS = PPT / 2 steps per group
         // the tile is n + g and the piece 2 j + h for step j of group g -- the swizzled address is
@@ -280,17 +283,20 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         constexpr int GS = PPT / 2;
         auto load_b = [&](v4i(&b)[kNB], int base, int xh, int j) {
             const uint8_t *bp = mm_lds + base + 16 * ((2 * j) ^ xh);
-    #pragma unroll
+#pragma unroll
             for (int q = 0; q < kNB; q++) b[q] = *reinterpret_cast<const v4i *>(bp + q * 32 * TB);
         };
-        auto load_a = [&](v4i(&a)[2], int s) {
-    #pragma unroll
-            for (int d = 0; d < 2; d++) a[d] = fa[d * dstride - 4 * s];
+        // (a running pointer per digit, stepped once per group: the loads inside a group take immediate
+        // offsets instead of 64-bit address arithmetic per load)
+        const v4i *pa0 = fa, *pa1 = fa + dstride;
+        auto load_a = [&](v4i(&a)[2], int js) {  // step js of the current group (may run into the next)
+            a[0] = pa0[-4 * js];
+            a[1] = pa1[-4 * js];
         };
         auto mma = [&](const v4i(&a)[2], const v4i(&b)[kNB]) {
-    #pragma unroll
+#pragma unroll
             for (int d = 0; d < 2; d++)
-    #pragma unroll
+#pragma unroll
                 for (int q = 0; q < kNB; q++) acc[d][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d], b[q], acc[d][q], 0, 0, 0);
         };
         {
@@ -301,28 +307,27 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             // as a clump after them, the wave's own MFMA stream had a ~100-cycle hole per step.
             // ks is a multiple of GS and the table is padded by four steps in front.
             v4i a[4][2], b[4][kNB];
-    #pragma unroll
+#pragma unroll
             for (int q = 0; q < 4; q++) load_a(a[q], q);
             int t = n, base = TB * t, xh = (t & 15) ^ h;
             load_b(b[0], base, xh, 0);
             load_b(b[1], base, xh, 1);
             const int groups = ((EXP & 2) ? 0 : G.ks) / GS;
-    #pragma unroll 1
-            for (int g = 0; g < groups; g++) {
+            auto group = [&](int) {
                 const int tn = t + 1, base_n = TB * tn, xh_n = (tn & 15) ^ h;
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < GS; j++) {
                     if (j + 2 < GS) load_b(b[(j + 2) & 3], base, xh, j + 2);
                     else load_b(b[(j + 2) & 3], base_n, xh_n, j + 2 - GS);  // (past the window after the last group: unused)
                     mma(a[j & 3], b[j & 3]);
-                    load_a(a[j & 3], g * GS + j + 4);
+                    load_a(a[j & 3], j + 4);
                     __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // the address of the step's reads
-    #pragma unroll
+#pragma unroll
                     for (int q = 0; q < kNB; q++) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // LDS read
                     }
-    #pragma unroll
+#pragma unroll
                     for (int q = 0; q < 2; q++) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // table load
@@ -333,6 +338,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                 t = tn;
                 base = base_n;
                 xh = xh_n;
+                pa0 -= 4 * GS;
+                pa1 -= 4 * GS;
+            };
+            // The compiler drains every outstanding load at a loop header (s_waitcnt vmcnt(0) lgkmcnt(0):
+            // it cannot count across the back edge), which empties the operand pipeline once per trip:
+            // the common window (1024 taps at D = 8: nine groups) runs unrolled, without a header.
+            if (groups == 9) {
+#pragma unroll
+                for (int g = 0; g < 9; g++) group(g);
+            } else {
+#pragma unroll 1
+                for (int g = 0; g < groups; g++) group(g);
             }
         }
         // The halves meet: wave 0 (digits 0-1) finishes column blocks 0-1, wave 1 (digits 2-3) blocks 2-3.
@@ -341,15 +358,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         double *xhi = reinterpret_cast<double *>(mm_lds);              // [2][16][64]
         float *xlo = reinterpret_cast<float *>(mm_lds + 2 * 16 * 64 * 8);  // [2][16][64]
         if (wave == 0) {
-    #pragma unroll
+#pragma unroll
             for (int j = 0; j < 2; j++)
-    #pragma unroll
+#pragma unroll
                 for (int q = 0; q < 16; q++)
                     xhi[(j * 16 + q) * 64 + l] = __fma_rn((double)acc[0][2 + j][q], 256.0, (double)acc[1][2 + j][q]);
         } else {
-    #pragma unroll
+#pragma unroll
             for (int j = 0; j < 2; j++)
-    #pragma unroll
+#pragma unroll
                 for (int q = 0; q < 16; q++)
                     xlo[(j * 16 + q) * 64 + l] = __fmaf_rn((float)acc[0][j][q], 256.0f, (float)acc[1][j][q]);
         }
@@ -358,14 +375,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         const double dcr = dc[0], dci = dc[1];
         const double scale = __hiloint2double((1023 - G.shift) << 20, 0);  // 2^-S
         float2 y[2][8];  // [own block][4 q4 + ... ]: outputs 4 q4 + 2 h + e of tile 32 (2 wave + j) + n
-    #pragma unroll
+#pragma unroll
         for (int j = 0; j < 2; j++)
-    #pragma unroll
+#pragma unroll
             for (int q4 = 0; q4 < 4; q4++)
-    #pragma unroll
+#pragma unroll
                 for (int e = 0; e < 2; e++) {
                     float c2[2];
-    #pragma unroll
+#pragma unroll
                     for (int pt = 0; pt < 2; pt++) {
                         const int q = 4 * q4 + 2 * e + pt;
                         double hi, lo;
@@ -385,18 +402,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         // in three directions inside one exactly-linear clock run, so a Shift stage is
         // z0 * wB^j * wA^q4 * wE^e (see ew_apply_seq for the error argument).
         const uint32_t mb = m_start + (uint32_t)(32 * 2 * wave + n) * kT + 2 * h;
-    #pragma unroll 1
+#pragma unroll 1
         for (int oi = 0; oi < ((EXP & 4) ? 0 : P.n); oi++) {  // uniform
             const EwOp &o = P.op[oi];
             if (o.kind == EW_SCALE) {
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < 2; j++)
-    #pragma unroll
+#pragma unroll
                     for (int q = 0; q < 8; q++) y[j][q] = make_float2(__fmul_rn(y[j][q].x, o.a), __fmul_rn(y[j][q].y, o.a));
             } else if (o.kind == EW_ROTATE) {
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < 2; j++)
-    #pragma unroll
+#pragma unroll
                     for (int q = 0; q < 8; q++) y[j][q] = go_cmul(y[j][q], make_float2(o.a, o.b));
             } else {
                 // the clock at the lane's first output, by the run's line -- also for a lane whose first
@@ -410,10 +427,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                 sincos_late(__dmul_rn(o.tau_shift, __dmul_rn((double)D, step)), es, ec);
                 sincos_late(__dmul_rn(o.tau_shift, __dmul_rn((double)(4 * D), step)), as, ac);
                 sincos_late(__dmul_rn(o.tau_shift, __dmul_rn((double)(32 * kT * D), step)), bs, bc);
-    #pragma unroll
+#pragma unroll
                 for (int j = 0; j < 2; j++) {
                     double zc = z0c, zs = z0s;
-    #pragma unroll
+#pragma unroll
                     for (int q4 = 0; q4 < 4; q4++) {
                         y[j][2 * q4] = go_cmul(y[j][2 * q4], make_float2((float)zc, (float)zs));
                         const double ze_c = __fma_rn(zc, ec, -(zs * es)), ze_s = __fma_rn(zc, es, zs * ec);
@@ -434,15 +451,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         __syncthreads();  // the exchange buffers have been read
         {
             float4 *yl = reinterpret_cast<float4 *>(mm_lds) + wave * (2 * 32 * 8);  // [2 blocks][32 tiles][8 pieces]
-    #pragma unroll
+#pragma unroll
             for (int j = 0; j < 2; j++)
-    #pragma unroll
+#pragma unroll
                 for (int q4 = 0; q4 < 4; q4++)
                     yl[(j * 32 + n) * 8 + ((2 * q4 + h) ^ (n & 7))] =
                         make_float4(y[j][2 * q4].x, y[j][2 * q4].y, y[j][2 * q4 + 1].x, y[j][2 * q4 + 1].y);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-    #pragma unroll
+#pragma unroll
             for (int it = 0; it < 8; it++) {
                 const int idx = it * 64 + l, tile = idx >> 3, piece = idx & 7;  // tile = 32 j + n
                 const float4 v = yl[tile * 8 + (piece ^ (tile & 7))];
@@ -454,8 +471,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
     }
-    __syncthreads();
-    for (int task = wb; task < n_tasks; task += (int)gridDim.x) small_task(task);  // (uniform)
+    if (!active) {
+        for (int task = wb; task < n_tasks; task += (int)gridDim.x) small_task(task);  // (uniform)
+    }
 }
 
 }  // namespace mm

@@ -219,6 +219,14 @@ func (ch *Chain) Time() (float64, error) {
 	rc := C.hzsdr_chain_time(ch.c, &ts)
 	return float64(ts), toErr(ch.x.c, rc)
 }
+
+// LastFIRPath reports which kernels the last Run of a FIR-decimate chain used
+// (C.HZSDR_FIR_PATH_TRANSFORM or C.HZSDR_FIR_PATH_MATRIX; C.HZSDR_FIR_PATH_NONE before the first run).
+func (ch *Chain) LastFIRPath() (int, error) {
+	var p C.int
+	rc := C.hzsdr_chain_last_fir_path(ch.c, &p)
+	return int(p), toErr(ch.x.c, rc)
+}
 func (ch *Chain) Close() error { return toErr(ch.x.c, C.hzsdr_chain_free(ch.c)) }
 
 // Reader wraps the chain as ONE sdr.Reader behind stream.ReadTransformer: `block` input

@@ -355,6 +355,18 @@ int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps_c64, size_t n_tap
  * bound, not to bits).  in_order = 1: every block mixes each input sample before the
  * filter, exactly as nested stream.ShiftReader -> filter Readers would. */
 int hzsdr_chain_mix_in_order(hzsdr_chain *c, int in_order);
+/* Which kernels the LAST hzsdr_chain_run of a FIR-decimate chain used (for tests, benchmarks and
+ * logs; the results are held to the same bound either way):
+ *   HZSDR_FIR_PATH_NONE       no run yet / no FIR-decimate terminal
+ *   HZSDR_FIR_PATH_TRANSFORM  overlap-save transforms (any source format, any factor)
+ *   HZSDR_FIR_PATH_MATRIX     int8 matrix form (csrc/hz_firmm.h): u8 / i8 sources, factor 8 or 16,
+ *                             64..4096 taps, default mixer order, 16-byte aligned device buffers,
+ *                             at least 4096 outputs per call.  Environment HZ_FIR_FFT=1 (read when
+ *                             the terminal is created) keeps a chain on the transforms. */
+#define HZSDR_FIR_PATH_NONE 0
+#define HZSDR_FIR_PATH_TRANSFORM 1
+#define HZSDR_FIR_PATH_MATRIX 2
+int hzsdr_chain_last_fir_path(const hzsdr_chain *c, int *path);
 /* Samples the chain would produce for n_in input samples, and how many input
  * samples it consumes (whole blocks only for block-structured terminals). */
 int hzsdr_chain_plan(const hzsdr_chain *c, size_t n_in, size_t *n_consumed, size_t *n_out);

@@ -247,6 +247,9 @@ static void chain_and_ring(void) { /* go/hip/stream.go Chain, go/hip/ring.go */
     double ts = 0;
     OK(hzsdr_chain_time(c, &ts));
     CHECK(ts > 0.003 && ts < 0.0033); /* 65536 samples at 20 Msps */
+    int path = -1;
+    OK(hzsdr_chain_last_fir_path(c, &path));
+    CHECK(path == HZSDR_FIR_PATH_TRANSFORM || path == HZSDR_FIR_PATH_MATRIX);
     OK(hzsdr_chain_set_time(c, 1.0));
     OK(hzsdr_chain_reset(c));
     /* the ring: ONE pinned region for all slots (IQBufferAllocator), acquire / fill / submit / pop */

@@ -1,0 +1,216 @@
+"""The int8 matrix form of the FIR-decimate terminal (csrc/hz_firmm.h): u8 / i8 sources,
+decimation 8 or 16.  Every case is held to the oracle (reference-order Shift, float64 direct
+form) with the bounds of tests/util.py, and the cases assert WHICH kernels ran
+(hzsdr_chain_last_fir_path): the matrix form where it applies, the transform kernels where
+it must not (other factors, misaligned buffers, short calls, HZ_FIR_FFT=1, in-order mixer).
+
+What the matrix form adds to the late mixer's tests (test_gpu_latemix.py):
+  * the filter sums are exact integer arithmetic on the quantised taps: a relative L2 error an
+    order of magnitude under the transform path's is asserted;
+  * chunks of 2048 outputs on the call's grid, owned by one clock run each; outputs whose window
+    crosses a run boundary, the stream start or a run without a table come from the fix-up
+    tasks -- calls that start on a boundary, cross several, wrap at 2*pi;
+  * the raw history: a window that reaches back into the previous call when the clock run
+    continues, the float history otherwise and after a call on the transform kernels."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from util import assert_fir_close, fir_errors, rand_i8, rand_u8, zeros
+
+pytestmark = pytest.mark.gpu
+
+TAU = 6.283185307179586476925286766559
+
+
+@pytest.fixture(scope="module")
+def hz():
+    return importlib.import_module("go-sdr_amd")
+
+
+@pytest.fixture(scope="module")
+def ctx(hz):
+    c = hz.Context(0, hz.MEM_HOST)
+    yield c
+    c.close()
+
+
+def taps_for(ntaps, cutoff=1 / 32, rot=0.3):
+    k = np.arange(ntaps) - (ntaps - 1) / 2
+    return (2 * cutoff * np.sinc(2 * cutoff * k) * np.hamming(ntaps) * np.exp(1j * rot * k)).astype(np.complex64)
+
+
+def oracle(orc, x, rate, ops, taps, D, ts0=0.0, cuts=None, ts_at=None):
+    """Reference order over the whole stream; `ts_at[i]` resets the clock before call i."""
+    n = len(x)
+    xc = zeros("c64", n)
+    orc.convert(xc, x)
+    cuts = cuts or [0, n]
+    for kind, arg in ops:
+        if kind == "shift":
+            sh = orc.Shifter(rate)
+            sh.ts.value = ts0
+            for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+                if ts_at and ts_at.get(i) is not None:
+                    sh.ts.value = ts_at[i]
+                sh(arg, xc[a:b])
+        elif kind == "gain":
+            orc.scale(xc, arg)
+        else:
+            orc.rotate(xc, arg)
+    want = zeros("c64", n // D)
+    orc.par_fir_decimate_f64(want, xc, taps, D)
+    return want, float(np.abs(xc).max())
+
+
+def build(hz, ctx, fmt, rate, ops, taps, D):
+    ch = ctx.chain(fmt, rate)
+    for kind, arg in ops:
+        ch = ch.shift(arg) if kind == "shift" else ch.gain(arg) if kind == "gain" else ch.rotate(arg)
+    return ch.fir_decimate(taps, D)
+
+
+CASES = {
+    "u8_d8_1024": dict(fmt="u8", rate=20_000_000, ops=[("shift", -2.5e6)], ntaps=1024, D=8, n=1 << 20),
+    "u8_d16_2047": dict(fmt="u8", rate=20_000_000, ops=[("shift", 1.1e6)], ntaps=2047, D=16, n=1 << 20),
+    "u8_d8_64": dict(fmt="u8", rate=2_400_000, ops=[("shift", 3e5)], ntaps=64, D=8, n=1 << 19),
+    "u8_d8_129_program": dict(fmt="u8", rate=2_400_000, ops=[("gain", 0.5), ("shift", 1e5), ("rotate", 0.6 - 0.8j),
+                                                              ("shift", -3.5e5)], ntaps=129, D=8, n=1 << 19),
+    "u8_d16_1000_noshift": dict(fmt="u8", rate=1_000_000, ops=[("gain", 1.5), ("rotate", -0.28 + 0.96j)], ntaps=1000,
+                                D=16, n=1 << 20),
+    "i8_d8_1024": dict(fmt="i8", rate=20_000_000, ops=[("shift", 4e6)], ntaps=1024, D=8, n=1 << 20),
+    "i8_d16_300": dict(fmt="i8", rate=8_000_000, ops=[("shift", -1e6), ("gain", 0.25)], ntaps=300, D=16, n=1 << 19),
+    "u8_d8_4096": dict(fmt="u8", rate=20_000_000, ops=[("shift", 2e6)], ntaps=4096, D=8, n=1 << 19),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_matrix_form_against_the_oracle(hz, ctx, orc, name):
+    c = CASES[name]
+    n, D, taps = c["n"], c["D"], taps_for(c["ntaps"])
+    x = rand_u8(31, n) if c["fmt"] == "u8" else rand_i8(31, n)
+    fmt = hz.FMT_U8 if c["fmt"] == "u8" else hz.FMT_I8
+    # three ragged calls: the second starts inside the clock run the first ended in (raw history),
+    # all cuts on the decimation grid
+    cuts = [0, n // 4 + 16 * 77, n - 16 * 8192, n]
+    # (the clock starts at 1 s: from 0 it runs through twenty short binades first, and a call that is
+    # mostly clock boundaries stays on the transform kernels -- test_clock_boundaries_and_wrap)
+    want, xmax = oracle(orc, x, c["rate"], c["ops"], taps, D, ts0=1.0)
+    ch = build(hz, ctx, fmt, c["rate"], c["ops"], taps, D)
+    ch.set_time(1.0)
+    out = zeros("c64", n // D)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        assert ch.run(x[a:b], out[a // D:b // D]) == (b - a, (b - a) // D)
+        assert ch.last_fir_path() == hz.FIR_PATH_MATRIX, (name, a)
+    assert_fir_close(out, want, taps, xmax, name)
+    # exact integer filter sums: what is left is one float32 rounding of the filter output and one per
+    # elementwise stage (the transform path: 1.7e-7 with a single stage)
+    err, bound, rel = fir_errors(out, want, taps, xmax)
+    assert rel <= 4e-8 * (1 + len(c["ops"])), (name, rel)
+    ch.close()
+
+
+def test_matrix_and_transform_paths_share_the_history(hz, ctx, orc):
+    """Calls alternate between the matrix form and the transform kernels (short calls, a misaligned
+    buffer): the float history and the clock carry over in both directions."""
+    rate, D, taps = 20_000_000, 8, taps_for(1024)
+    n = 1 << 20
+    x = rand_u8(5, n + 8)
+    cuts = [0, 1 << 18, (1 << 18) + 8 * 1000, 1 << 19, (1 << 19) + (1 << 18) + 8, n]
+    ops = [("shift", -2.5e6)]
+    want, xmax = oracle(orc, x[:n], rate, ops, taps, D, ts0=1.0)
+    ch = build(hz, ctx, hz.FMT_U8, rate, ops, taps, D)
+    ch.set_time(1.0)
+    out = zeros("c64", n // D)
+    paths = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        assert ch.run(x[a:b], out[a // D:b // D]) == (b - a, (b - a) // D)
+        paths.append(ch.last_fir_path())
+    # 8000 samples = 1000 outputs: too short for the matrix form
+    assert paths == [hz.FIR_PATH_MATRIX, hz.FIR_PATH_TRANSFORM, hz.FIR_PATH_MATRIX, hz.FIR_PATH_MATRIX, hz.FIR_PATH_MATRIX]
+    assert_fir_close(out, want, taps, xmax, "alternating paths")
+    ch.close()
+
+
+def test_clock_boundaries_and_wrap(hz, ctx, orc):
+    """250 ksps: the clock wraps at 2*pi s = 1 570 796 samples.  Call 1 starts on ts = 0 (a dozen short
+    clock runs first: fix-up tasks), call 2 resumes just before the wrap, call 3 continues after it."""
+    rate, D, taps = 250_000, 8, taps_for(1024)
+    n = 3 * (1 << 19)
+    x = rand_u8(6, n)
+    cuts = [0, 1 << 19, 1 << 20, n]
+    ts2 = TAU - 1.0  # one second before the wrap: inside call 2 (2.1 s per call)
+    ops = [("shift", 31_250.0)]
+    want, xmax = oracle(orc, x, rate, ops, taps, D, cuts=cuts, ts_at={1: ts2})
+    ch = build(hz, ctx, hz.FMT_U8, rate, ops, taps, D)
+    out = zeros("c64", n // D)
+    paths = []
+    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        if i == 1:
+            ch.set_time(ts2)
+        assert ch.run(x[a:b], out[a // D:b // D]) == (b - a, (b - a) // D)
+        paths.append(ch.last_fir_path())
+    assert paths == [hz.FIR_PATH_MATRIX] * 3, paths
+    # set_time breaks the stream for the oracle too: compare per call, skipping the outputs whose
+    # window crosses the cut into call 2 (the oracle filtered ONE concatenated stream)
+    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        lo = a // D + (128 if i == 1 else 0)
+        assert_fir_close(out[lo:b // D], want[lo:b // D], taps, xmax, ("call", i))
+    ch.close()
+
+
+def test_where_the_matrix_form_must_not_run(hz, ctx, orc, monkeypatch):
+    rate, taps = 20_000_000, taps_for(1024)
+    n = 1 << 19
+    x = rand_u8(8, n)
+    ops = [("shift", -2.5e6)]
+
+    def run(D, in_order=False, fmt=None, data=None):
+        ch = build(hz, ctx, fmt or hz.FMT_U8, rate, ops, taps, D)
+        ch.mix_in_order(in_order)
+        ch.set_time(1.0)
+        out = zeros("c64", n // D)
+        assert ch.last_fir_path() == hz.FIR_PATH_NONE
+        ch.run(data if data is not None else x, out)
+        p = ch.last_fir_path()
+        ch.close()
+        return p, out
+
+    want8, xmax = oracle(orc, x, rate, ops, taps, 8, ts0=1.0)
+    p, out = run(8)
+    assert p == hz.FIR_PATH_MATRIX
+    assert_fir_close(out, want8, taps, xmax, "matrix")
+    p, out_io = run(8, in_order=True)  # reference order: the transform kernels
+    assert p == hz.FIR_PATH_TRANSFORM
+    assert_fir_close(out_io, want8, taps, xmax, "in order")
+    p, _ = run(4)  # another factor
+    assert p == hz.FIR_PATH_TRANSFORM
+    monkeypatch.setenv("HZ_FIR_FFT", "1")  # read when the terminal is created
+    p, out_fft = run(8)
+    assert p == hz.FIR_PATH_TRANSFORM
+    assert_fir_close(out_fft, want8, taps, xmax, "HZ_FIR_FFT")
+    monkeypatch.delenv("HZ_FIR_FFT")
+    # the two implementations agree far inside their common bound
+    d = out.astype(np.complex128) - out_fft
+    assert np.linalg.norm(d) <= 3e-7 * np.linalg.norm(want8.astype(np.complex128))
+
+
+def test_misaligned_device_buffers_take_the_transforms(hz, orc):
+    import torch
+    ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+    rate, D, taps = 20_000_000, 8, taps_for(1024)
+    n = 1 << 19
+    x = rand_u8(9, n + 8)
+    dx = torch.from_numpy(x).cuda()
+    want, xmax = oracle(orc, x[1:n + 1], rate, [("shift", 1e6)], taps, D, ts0=1.0)
+    ch = build(hz, ctx, hz.FMT_U8, rate, [("shift", 1e6)], taps, D)
+    ch.set_time(1.0)
+    out = torch.zeros(n // D, dtype=torch.complex64, device="cuda")
+    ch.run(dx[1:n + 1], out)  # one sample into the allocation: 2-byte aligned only
+    ctx.synchronize()
+    assert ch.last_fir_path() == hz.FIR_PATH_TRANSFORM
+    assert_fir_close(out.cpu().numpy(), want, taps, xmax, "misaligned")
+    ch.close()
+    ctx.close()

@@ -47,6 +47,138 @@ __global__ __launch_bounds__(256) void rate(int iters, int *sink, unsigned long 
     if (r == 0x7fffffff) sink[0] = r;
 }
 
+// the accumulator pattern of fir_mm_kernel: 8 accumulators of 16 registers, 2 A x 4 B operands
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void rate8(int iters, int *sink, int seed) {
+    v4i a[2], b[4];
+    for (int q = 0; q < 2; q++) a[q] = v4i{seed + q + (int)threadIdx.x * 0x01020304, seed * 3 + q, (int)threadIdx.x * 77, seed ^ 0x5a5a5a5a};
+    for (int q = 0; q < 4; q++) b[q] = v4i{seed * 7 + q + (int)threadIdx.x * 0x11213141, seed * 5, (int)threadIdx.x * 91 + q, seed ^ 0x3c3c3c3c};
+    v16i acc[2][4];
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[d][j][q] = 0;
+#pragma unroll 1
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int d = 0; d < 2; d++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[d][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d], b[j], acc[d][j], 0, 0, 0);
+    }
+    int r = 0;
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) r += acc[d][j][0] + acc[d][j][15];
+    if (r == 0x7fffffff) sink[0] = r;
+}
+
+// the same with the B operands read from LDS two steps ahead (MODE 1), the A operands from global
+// memory four steps ahead (MODE 2), or both (MODE 3)
+template <int MODE>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void rate8m(int iters, int *sink, const v4i *gtab, int seed) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int l = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int q = threadIdx.x; q < 34816 / 16; q += 128) reinterpret_cast<v4i *>(lds)[q] = v4i{q * seed, q, seed, 7};
+    __syncthreads();
+    v4i a[4][2], b[4][4];
+    for (int r = 0; r < 4; r++)
+        for (int q = 0; q < 2; q++) a[r][q] = v4i{seed + q + l * 0x01020304, seed * 3 + q + r, l * 77, seed ^ 0x5a5a5a5a};
+    for (int r = 0; r < 4; r++)
+        for (int q = 0; q < 4; q++) b[r][q] = v4i{seed * 7 + q + l * 0x11213141, seed * 5 + r, l * 91 + q, seed ^ 0x3c3c3c3c};
+    v16i acc[2][4];
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[d][j][q] = 0;
+    const unsigned char *bp = lds + 16 * l;
+    const v4i *ap = gtab + wave * 4096 + l;
+#pragma unroll 1
+    for (int i = 0; i < iters; i += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (MODE & 1) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) b[(j + 2) & 3][q] = *reinterpret_cast<const v4i *>(bp + q * 8192 + ((i + j) & 7) * 1024);
+            }
+#pragma unroll
+            for (int d = 0; d < 2; d++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[d][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[j][d], b[j][q], acc[d][q], 0, 0, 0);
+            if (MODE & 2) {
+                a[j][0] = ap[((i + j) & 31) * 64];
+                a[j][1] = ap[2048 + ((i + j) & 31) * 64];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    int r = 0;
+#pragma unroll
+    for (int d = 0; d < 2; d++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) r += acc[d][j][0] + acc[d][j][15];
+    if (r == 0x7fffffff) sink[0] = r;
+}
+
+template <int MODE> static void run8m(int iters) {
+    int *sink;
+    v4i *gtab;
+    CK(hipMalloc(&sink, 4));
+    CK(hipMalloc(&gtab, 1 << 20));
+    CK(hipMemset(gtab, 1, 1 << 20));
+    CK(hipFuncSetAttribute((const void *)rate8m<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 34816));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e9f;
+    for (int r = 0; r < 5; r++) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(rate8m<MODE>, dim3(1024), dim3(128), 34816, 0, iters, sink, gtab, 12345 + r);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    printf("fir_mm pattern, mode %d (1 = B from LDS, 2 = A from global), %d steps: wall %.1f us, %.1f ns per MFMA per SIMD\n", MODE, iters,
+           best * 1e3, best * 1e6 / (2.0 * iters * 8));
+}
+
+static void run8(int iters) {
+    int *sink;
+    CK(hipMalloc(&sink, 4));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float best = 1e9f;
+    for (int r = 0; r < 5; r++) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(rate8, dim3(1024), dim3(128), 34816, 0, iters, sink, 12345 + r);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    // per SIMD: 2 waves x iters x 8 MFMAs
+    printf("fir_mm pattern (8 accumulators x 16 regs, 2 waves/SIMD, %d steps): wall %.1f us, %.1f ns per MFMA per SIMD\n", iters,
+           best * 1e3, best * 1e6 / (2.0 * iters * 8));
+}
+
 template <int SHAPE> static void run(int wg_per_cu, int iters) {
     int *sink;
     unsigned long long *cyc;
@@ -77,9 +209,12 @@ template <int SHAPE> static void run(int wg_per_cu, int iters) {
 }
 
 int main() {
-    run<16>(1, 4096);
-    run<16>(2, 4096);
-    run<32>(1, 4096);
-    run<32>(2, 4096);
+    run8(72);
+    run8(720);
+    run8m<0>(720);
+    run8m<1>(720);
+    run8m<2>(720);
+    run8m<3>(720);
+    run8m<3>(72);
     return 0;
 }
