@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3    # vector f32
+I8_PEAK_TOPS = 5000.0       # MI355X_MICROARCH.md: dense int8 MFMA, 2x the ~2.5 PF of bf16
 
 
 def splitmix64(seed, n):
@@ -200,6 +201,42 @@ def main():
     # lanes), one 512-point inverse
     m = nfft // D
     flops = (D * 5 * m * (np.log2(m) - 1) + 256 * (24 * 6 + 30 * 2) + 5 * m * np.log2(m)) / valid * n
+    matrix = chain.last_fir_path() == hz.FIR_PATH_MATRIX
+    # int8 matrix form: every output is 1024 complex taps x a complex sample = 4 real MACs per tap,
+    # in FOUR int8 digit planes (32-bit fixed-point taps x 8-bit samples): 2 ops per MAC
+    mm_ops = 4 * 4 * 2 * ntaps * (n // D)
+    hbm = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4)}
+    if matrix:
+        tops = mm_ops / (kernel_ms * 1e-3) / 1e12
+        roof = {
+            "bound": "mfma", "achieved": round(tops, 1), "peak": I8_PEAK_TOPS, "unit": "TFLOP/s",
+            "frac": round(tops / I8_PEAK_TOPS, 4), "traffic": None,
+            "kernel": "hz::mm::fir_mm_kernel<u8, D = 8>",
+            "kernel_ms": round(kernel_ms, 4),
+            "kernel_ms_is": "device time per chain_run (one kernel), one HIP-event pair around the timed "
+                            "loop / steps",
+            "algorithmic_ops_per_launch": int(mm_ops),
+            "ops_are": "int8 multiply-adds x 2: taps x outputs x 4 real products per complex tap x 4 digit "
+                       "planes of the 32-bit fixed-point taps (the zero padding of the tile windows, "
+                       "+12 %, is not counted)",
+            "algorithmic_bytes_per_launch": int(alg_bytes),
+            "hbm": hbm,
+            "note": "the chain is above the HBM ridge (3 B/sample): the int8 matrix cores bind; the "
+                    "matrix pipe is busy ~42 % of the kernel (SQ_VALU_MFMA_BUSY_CYCLES, "
+                    "profiles/r02_sq_counters.txt), the rest is the input burst before and the "
+                    "epilogue after the matrix loop of workgroups that all run in phase",
+        }
+    else:
+        roof = dict(hbm, traffic=None,
+                    kernel="hz::fir_decimate_kernel16<4096, u8, fold 8, late> + hz::fir_synth_kernel16<4096, 8, late>",
+                    kernel_ms=round(kernel_ms, 4),
+                    kernel_ms_is="device time per chain_run (both kernels and the gap between them), one "
+                                 "HIP-event pair around the timed loop / steps",
+                    algorithmic_bytes_per_launch=int(alg_bytes),
+                    note="3 B/sample puts this chain above the ridge: FFT vector work and its LDS/barrier "
+                         "latency bind, not HBM",
+                    fp32_vector_frac=round(flops / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4))
     result = {
         "metric": "Msamples/s: u8->c64->Shift->FIR-decimate chain @1 GPU; 4-ch Beamform @1/2/4 GPU",
         "value": round(value, 1),
@@ -211,29 +248,24 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u8->c64(f32), NCO phase f64",
+        "dtype": "u8 x int32 fixed-point taps (int8 MFMA digit planes, exact) -> c64(f32), NCO phase f64"
+                 if matrix else "u8->c64(f32), NCO phase f64",
         "data": f"synthetic (splitmix64 u8 IQ, seeds 9+rank+101i; {nbuf} distinct buffers in rotation, "
                 f"{nbuf * 2 * n >> 20} MiB resident in HBM); windowed-sinc taps",
         "config": {
-            "workload": "north-star chain: u8->c64->Shift(-fs/8)->1024-tap FIR->decimate-by-8, one "
-                        "chain_run per buffer = analysis kernel (convert, 4096-point overlap-save "
-                        "FFT, filter, fold by 8) + synthesis kernel (512-point inverse, mixer at the "
-                        "decimated rate), input resident in HBM",
+            "workload": ("north-star chain: u8->c64->Shift(-fs/8)->1024-tap FIR->decimate-by-8, one "
+                         "chain_run per buffer = ONE kernel: the filter over the raw bytes as an int8 "
+                         "matrix product with the clock run's modulated taps, the mixer at the decimated "
+                         "rate, outputs across clock boundaries in reference order; input resident in HBM")
+                        if matrix else
+                        ("north-star chain: u8->c64->Shift(-fs/8)->1024-tap FIR->decimate-by-8, one "
+                         "chain_run per buffer = analysis kernel (convert, 4096-point overlap-save "
+                         "FFT, filter, fold by 8) + synthesis kernel (512-point inverse, mixer at the "
+                         "decimated rate), input resident in HBM"),
             "samples_per_buffer": n, "sample_rate": fs, "taps": ntaps, "decimation": D,
             "parallelism": "1 stream per GPU (replicas)" if world > 1 else "1 GPU",
         },
-        "roofline": {
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "kernel": "hz::fir_decimate_kernel16<4096, u8, fold 8, late> + hz::fir_synth_kernel16<4096, 8, late>",
-            "kernel_ms": round(kernel_ms, 4),
-            "kernel_ms_is": "device time per chain_run (both kernels and the gap between them), one "
-                            "HIP-event pair around the timed loop / steps",
-            "algorithmic_bytes_per_launch": int(alg_bytes),
-            "note": "3 B/sample puts this chain above the ridge: FFT vector work and its LDS/barrier "
-                    "latency bind, not HBM",
-            "fp32_vector_frac": round(flops / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
-        },
+        "roofline": roof,
     }
     chain.close()
     # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc
@@ -242,12 +274,17 @@ def main():
     if n == (1 << 24) and os.path.exists(tpath):
         try:
             tk = json.load(open(tpath))["kernels"]
-            keys = [k for k in tk if "fir_decimate_kernel16<4096, 2, 8, true" in k
-                    or "fir_synth_kernel16<4096, 8, true>" in k]
-            if len(keys) == 2:
+            if matrix:
+                keys = [k for k in tk if "fir_mm_kernel<2, 8" in k]
+                want = 1
+            else:
+                keys = [k for k in tk if "fir_decimate_kernel16<4096, 2, 8, true" in k
+                        or "fir_synth_kernel16<4096, 8, true>" in k]
+                want = 2
+            if len(keys) == want:
                 result["roofline"]["traffic"] = sum(tk[k]["hbm_bytes"] for k in keys)
                 result["roofline"]["traffic_source"] = ("profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + "
-                                                        "WRITE_SIZE, both kernels of a chain_run)")
+                                                        "WRITE_SIZE, the kernel(s) of a chain_run)")
         except (StopIteration, KeyError, ValueError):
             pass
 
@@ -272,6 +309,13 @@ def main():
         extra["chain_adc_like_u8"] = rate(n, float(np.median(ms)), 2 + 8 / D)
         ch.close()
         del xa
+        # the same chain on the overlap-save transform kernels (round 2's first implementation)
+        os.environ["HZ_FIR_FFT"] = "1"
+        ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D)
+        del os.environ["HZ_FIR_FFT"]
+        _, ms = timed(torch, lambda: ch.run(x, y), k, w)
+        extra["chain_transform_kernels"] = rate(n, float(np.median(ms)), 2 + 8 / D)
+        ch.close()
         # the same chain with the mixer forced in front of the filter on every block
         ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D).mix_in_order(True)
         _, ms = timed(torch, lambda: ch.run(x, y), k, w)

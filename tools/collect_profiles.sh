@@ -10,17 +10,23 @@ export TMPDIR=/tmp
 mkdir -p $out
 python3 bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_trace -- python3 bench.py --steps 20 --warmup 5 --no-oracle > $out/bench_profiled.json 2> /dev/null
-K="chain convert shift_gain conv chain_c64 beamform downsample"
+K="chain chain_fft convert shift_gain conv chain_c64 beamform downsample"
 REPS=6 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 tools/prof_kernels.py $K > /dev/null 2>&1
 REPS=6 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 tools/prof_kernels.py $K > /dev/null 2>&1
 python3 tools/pmc_summary.py $out/pmc_fetch $out/pmc_write $out/traffic.json > /dev/null
-REPS=6 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $out/sq1 -- python3 tools/prof_kernels.py chain conv chain_c64 > /dev/null 2>&1
-REPS=6 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_LDS_UNALIGNED_STALL --output-format csv -d $out/sq2 -- python3 tools/prof_kernels.py chain conv chain_c64 > /dev/null 2>&1
+REPS=6 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $out/sq1 -- python3 tools/prof_kernels.py chain chain_fft conv chain_c64 > /dev/null 2>&1
+REPS=6 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_LDS_UNALIGNED_STALL --output-format csv -d $out/sq2 -- python3 tools/prof_kernels.py chain chain_fft conv chain_c64 > /dev/null 2>&1
 python3 tools/pmc_sq.py $out/sq1 $out/sq2 > $out/sq_counters.txt
 REPS=6 rocprofv3 --kernel-trace --stats --output-format csv -d $out/fft_trace -- python3 tools/prof_kernels.py fft1024 fft4096 fftbig13 fftbig14 fftbig15 fftbig16 fftbig18 > /dev/null 2>&1
 REPS=10 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kern_trace -- python3 tools/prof_kernels.py $K shift scale rotate > /dev/null 2>&1
 python3 tools/host_path_bench.py > $out/host_path.txt 2>&1
 ./build/tools/fir_ablate > $out/fir_ablate.txt 2>&1
+REPS=6 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $out/sq3 -- python3 tools/prof_kernels.py chain > /dev/null 2>&1
+python3 tools/pmc_sq.py $out/sq3 >> $out/sq_counters.txt
+tools/bin/mfma_fir > $out/mfma_fir.txt 2>&1
+tools/bin/mfma_rate > $out/mfma_rate.txt 2>&1
+python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" > $out/firmm_probe.txt
+HZ_FIR_FFT=1 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" >> $out/firmm_probe.txt
 for f in $out/bench_trace/*/*kernel_stats.csv $out/fft_trace/*/*kernel_stats.csv $out/kern_trace/*/*kernel_stats.csv; do echo "== $f"; cut -d, -f1-4 $f | cut -c1-160 | head -14; done
 cat $out/sq_counters.txt | head -60
 tail -3 $out/bench.err
