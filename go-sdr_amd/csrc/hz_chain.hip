@@ -596,10 +596,10 @@ static int mm_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const 
     if constexpr (FMT == HZSDR_FMT_U8 || FMT == HZSDR_FMT_I8) {
         if (D == 8)
             launch_fv(mm::fir_mm_kernel<FMT, 8>, dim3(grid), dim3(mm::kThreads), lds, ctx->stream, in, (float2 *)out, hist,
-                      nhist, rh, nrh, (const float2 *)c->taps_dev, n, g, P, R, F);
+                      nhist, rh, nrh, (const float2 *)c->taps_dev, n, g, P, R, F, (unsigned long long *)nullptr);
         else
             launch_fv(mm::fir_mm_kernel<FMT, 16>, dim3(grid), dim3(mm::kThreads), lds, ctx->stream, in, (float2 *)out, hist,
-                      nhist, rh, nrh, (const float2 *)c->taps_dev, n, g, P, R, F);
+                      nhist, rh, nrh, (const float2 *)c->taps_dev, n, g, P, R, F, (unsigned long long *)nullptr);
         return HZSDR_OK;
     }
     return HZSDR_ERR_INVALID_ARGUMENT;

@@ -106,12 +106,22 @@ __device__ __forceinline__ int find_le(const int *tab, int n, int key) {
 // One post-elementwise sample in reference order: position p of the buffer (p < 0: history).
 template <int FMT>
 __device__ __forceinline__ float2 ordered_sample(const void *in, const EwProgram &P, int64_t p, const float2 *hist,
-                                                 unsigned off) {
+                                                 unsigned off, NcoWin w) {
     using R = typename Raw<FMT>::t;
     if (p < 0) return hist ? hist[p + (int64_t)off] : make_float2(0.f, 0.f);
     float2 v[1] = {Raw<FMT>::cvt(((const R *)in)[p])};
-    ew_apply_n<1, true>(P, v, (uint64_t)p, nco_window_all(P.segs));
+    ew_apply_n<1, true>(P, v, (uint64_t)p, w);
     return v[0];
+}
+
+// the clock runs that hold samples [p_lo, p_hi] (clamped to the buffer), found by the wave together
+// (nco_window_ballot; the inline table only -- the matrix form does not run with the device table).
+// A task that scanned the whole table per sample (nco_window_all) waited for ~25 dependent scalar
+// loads per sample on a call in which the clock wraps: +30 us on that call.
+__device__ __forceinline__ NcoWin task_window(const EwProgram &P, int64_t p_lo, int64_t p_hi) {
+    if (P.segs.n <= 1) return NcoWin{0, 0};
+    const NcoWin w = nco_window_ballot(P.segs, (uint64_t)(p_lo < 0 ? 0 : p_lo), (uint64_t)(p_hi < 0 ? 0 : p_hi), 64);
+    return NcoWin{__builtin_amdgcn_readfirstlane(w.lo), __builtin_amdgcn_readfirstlane(w.hi)};
 }
 
 // EXP: ablation switches for tools/mfma_fir.hip (0 in the library): 1 = no input loads, 2 = no
@@ -122,12 +132,20 @@ template <int FMT, int D, int EXP = 0>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void fir_mm_kernel(
     const void *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ hist,
     float2 *__restrict__ new_hist, const uint8_t *__restrict__ rhist, uint8_t *__restrict__ new_rhist,
-    const float2 *__restrict__ taps, size_t n_in, Geom G, EwProgram P, Runs R, Fix F) {
+    const float2 *__restrict__ taps, size_t n_in, Geom G, EwProgram P, Runs R, Fix F,
+    unsigned long long *stamps = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t mm_lds[];
     static_assert(D % 8 == 0, "windows start on 16-byte pieces");
     constexpr int TB = tile_bytes(D), PPT = pieces_per_tile(D);
     const int tid = threadIdx.x;
     const int wb = blockIdx.x;
+    // (EXP & 64, tools/mfma_fir.hip: s_memtime at the phase boundaries of every workgroup)
+    auto stamp = [&](int k) {
+        if constexpr ((EXP & 64) != 0) {
+            if (tid == 0) stamps[(size_t)wb * 8 + k] = __builtin_amdgcn_s_memtime();
+        }
+    };
+    stamp(0);
     // ---- the small tasks: outputs in reference order (fix-up) and the next call's history --------
     // They have no workgroups of their own: as workgroups at the END of the grid each was a ~8 us
     // latency chain (load, Sincos, dot product, store) behind the chunk workgroups, and ahead of them
@@ -150,6 +168,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             const int64_t p_lo = (int64_t)D * m0 - (G.ntaps - 1);
             const int n_s = G.ntaps + D * (cnt - 1);
             for (int idx = tid; idx < G.ntaps; idx += kThreads) tl[idx] = taps[idx];
+            const NcoWin tw = task_window(P, p_lo, p_lo + n_s - 1);
             constexpr int W = 3;
 #pragma unroll 1
             for (int i0 = tid; i0 < n_s; i0 += W * kThreads) {
@@ -161,7 +180,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                     v[u] = Raw<FMT>::cvt(ok ? ((const RW *)in)[pu] : RW{});
                 }
                 // (positions before the buffer wrap around in uint64 and come back: their values are discarded)
-                ew_apply_n<W, true>(P, v, (uint64_t)(p_lo + i0), nco_window_all(P.segs), (uint64_t)kThreads);
+                ew_apply_n<W, true>(P, v, (uint64_t)(p_lo + i0), tw, (uint64_t)kThreads);
 #pragma unroll
                 for (int u = 0; u < W; u++) {
                     const int idx = i0 + u * kThreads;
@@ -196,9 +215,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             // same samples as raw bytes (the next call's windows reach back into them when the clock
             // run continues across the call boundary, Runs::cont)
             const unsigned idx = (unsigned)(task - F.n_wg) * kThreads + tid;
+            const int64_t h_lo = (int64_t)n_in - (int64_t)G.off + (int64_t)(task - F.n_wg) * kThreads;
+            const NcoWin tw = task_window(P, h_lo, h_lo + kThreads - 1);
             if (idx < G.off) {
                 const int64_t p = (int64_t)n_in - (int64_t)G.off + idx;
-                new_hist[idx] = ordered_sample<FMT>(in, P, p, hist, G.off);
+                new_hist[idx] = ordered_sample<FMT>(in, P, p, hist, G.off, tw);
                 reinterpret_cast<RW *>(new_rhist)[idx] = p >= 0 ? ((const RW *)in)[p] : reinterpret_cast<const RW *>(rhist)[p + (int64_t)G.off];
             }
         }
@@ -221,7 +242,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int64_t p0 = 2 * ((int64_t)D * m_start - G.w0);
         const int pieces = (int)(chunk_bytes(D, G.ks) / 16);
         const uint8_t *src = (const uint8_t *)in;
-        constexpr int U = 9;  // loads in flight per lane and trip
+        constexpr int U = 17;  // loads in flight per lane and trip: the whole chunk at D = 8, 1024 taps (one HBM round trip)
         auto issue = [&](v4i(&x)[U], int q0) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -264,8 +285,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             land(x, q0);
         }
     }
+    stamp(1);
     if (active) {
         __syncthreads();
+        stamp(2);
         // A fragments: entry (D/8) i - h - 2 s + e0 of this wave's two digits, parts interleaved
         const v4i *ftab = (const v4i *)R.tab[r];
         const v4i *fa = ftab + (size_t)(2 * wave) * 2 * G.ne + 2 * ((D / 8) * i - h + G.e0) + part;
@@ -352,6 +375,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                 for (int g = 0; g < groups; g++) group(g);
             }
         }
+        stamp(3);
         // The halves meet: wave 0 (digits 0-1) finishes column blocks 0-1, wave 1 (digits 2-3) blocks 2-3.
         // hi = acc0 * 256 + acc1 is exact in float64; the low pair's weight is 2^-16: float32 is enough.
         __syncthreads();  // both waves are done with the chunk's bytes
@@ -422,19 +446,28 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const double step = P.segs.step[r];
                 const int64_t dj = (int64_t)((uint64_t)D * mb) - (int64_t)P.segs.first[r];
                 const double ts0 = __fma_rn((double)dj, step, P.segs.t0[r]);
-                double z0s, z0c, es, ec, as, ac, bs, bc;
+                // The three step factors are the same for every lane: lanes 0 / 1 / 2 evaluate one each
+                // and the wave reads them back (two Sincos per lane instead of four).  The products with
+                // the filter outputs are float32 (the factors rounded once, as the reference does; the
+                // late path is held to an error bound and float64 products cost a third of the epilogue).
+                double z0s, z0c, fs, fc;
                 sincos_late(__dmul_rn(o.tau_shift, ts0), z0s, z0c);
-                sincos_late(__dmul_rn(o.tau_shift, __dmul_rn((double)D, step)), es, ec);
-                sincos_late(__dmul_rn(o.tau_shift, __dmul_rn((double)(4 * D), step)), as, ac);
-                sincos_late(__dmul_rn(o.tau_shift, __dmul_rn((double)(32 * kT * D), step)), bs, bc);
+                const double mult = l == 0 ? (double)D : l == 1 ? (double)(4 * D) : (double)(32 * kT * D);
+                sincos_late(__dmul_rn(o.tau_shift, __dmul_rn(mult, step)), fs, fc);
+                const double es = __shfl(fs, 0), ec = __shfl(fc, 0), as = __shfl(fs, 1), ac = __shfl(fc, 1);
+                const double bs = __shfl(fs, 2), bc = __shfl(fc, 2);
+                auto mul32 = [](float2 a, double c, double sn) {
+                    const float cr = (float)c, ci = (float)sn;
+                    return make_float2(__fmaf_rn(a.x, cr, -(a.y * ci)), __fmaf_rn(a.x, ci, a.y * cr));
+                };
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     double zc = z0c, zs = z0s;
 #pragma unroll
                     for (int q4 = 0; q4 < 4; q4++) {
-                        y[j][2 * q4] = go_cmul(y[j][2 * q4], make_float2((float)zc, (float)zs));
+                        y[j][2 * q4] = mul32(y[j][2 * q4], zc, zs);
                         const double ze_c = __fma_rn(zc, ec, -(zs * es)), ze_s = __fma_rn(zc, es, zs * ec);
-                        y[j][2 * q4 + 1] = go_cmul(y[j][2 * q4 + 1], make_float2((float)ze_c, (float)ze_s));
+                        y[j][2 * q4 + 1] = mul32(y[j][2 * q4 + 1], ze_c, ze_s);
                         const double nc = __fma_rn(zc, ac, -(zs * as)), ns = __fma_rn(zc, as, zs * ac);
                         zc = nc;
                         zs = ns;
@@ -445,6 +478,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
             }
         }
+        stamp(4);
         // Stores: a lane holds eight outputs of each of its tiles, 128 bytes apart from the next lane's --
         // through LDS (16-byte pieces swizzled by the tile index) a wave writes whole 1 KiB rows instead
         // (direct 8-byte stores cost 10 us of the kernel's 46).
@@ -471,6 +505,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
     }
+    stamp(5);
     if (!active) {
         for (int task = wb; task < n_tasks; task += (int)gridDim.x) small_task(task);  // (uniform)
     }

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "hz_firmm.h"
@@ -14,6 +15,8 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 using namespace hz;
+
+static unsigned long long *g_stamps = nullptr;
 
 template <int EXP> static void run(void *const *in, float2 *out, const float2 *taps, const void *tab, size_t n, int ntaps,
                                    bool shift) {
@@ -65,7 +68,7 @@ template <int EXP> static void run(void *const *in, float2 *out, const float2 *t
     for (int r = 0; r < reps + 4; r++) {
         CK(hipEventRecord(e0, 0));
         hipLaunchKernelGGL(k, dim3(grid), dim3(mm::kThreads), lds, 0, (const void *)in[r % 12], out, (const float2 *)nullptr,
-                           out + n_out, (const uint8_t *)taps, (uint8_t *)(out + n_out + 4096), taps, n, g, P, R, F);
+                           out + n_out, (const uint8_t *)taps, (uint8_t *)(out + n_out + 4096), taps, n, g, P, R, F, g_stamps);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -75,6 +78,21 @@ template <int EXP> static void run(void *const *in, float2 *out, const float2 *t
     CK(hipGetLastError());
     printf("EXP %2d%s: grid %u, LDS %zu, min %.1f us  avg %.1f us\n", EXP, shift ? " +Shift" : "       ", grid, lds, best * 1e3f,
            sum / reps * 1e3f);
+    if (EXP & 64) {
+        // phase durations per workgroup of the last launch, in s_memtime ticks (the counters of
+        // different XCDs are not aligned: only differences inside a workgroup mean anything)
+        std::vector<unsigned long long> st((size_t)grid * 8);
+        CK(hipMemcpy(st.data(), g_stamps, st.size() * 8, hipMemcpyDeviceToHost));
+        const char *names[6] = {"input loads + landing", "barrier", "matrix loop", "exchange + mixer", "stores", "whole workgroup"};
+        for (int k = 0; k < 6; k++) {
+            std::vector<double> v;
+            for (unsigned b = 0; b < grid; b++)
+                v.push_back(k < 5 ? (double)(st[b * 8 + k + 1] - st[b * 8 + k]) : (double)(st[b * 8 + 5] - st[b * 8]));
+            std::sort(v.begin(), v.end());
+            printf("    %-22s min %7.0f  p10 %7.0f  median %7.0f  p90 %7.0f  max %7.0f ticks\n", names[k], v[0], v[v.size() / 10],
+                   v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+        }
+    }
 }
 
 int main(int argc, char **argv) {
@@ -102,5 +120,7 @@ int main(int argc, char **argv) {
     run<2>(in, out, taps, tab, n, ntaps, true);
     run<8>(in, out, taps, tab, n, ntaps, true);
     run<4>(in, out, taps, tab, n, ntaps, true);
+    CK(hipMalloc(&g_stamps, 8 * 8 * 4096));
+    run<64>(in, out, taps, tab, n, ntaps, true);
     return 0;
 }
