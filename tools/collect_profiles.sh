@@ -20,7 +20,7 @@ python3 tools/pmc_sq.py $out/sq1 $out/sq2 > $out/sq_counters.txt
 REPS=6 rocprofv3 --kernel-trace --stats --output-format csv -d $out/fft_trace -- python3 tools/prof_kernels.py fft1024 fft4096 fftbig13 fftbig14 fftbig15 fftbig16 fftbig18 > /dev/null 2>&1
 REPS=10 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kern_trace -- python3 tools/prof_kernels.py $K shift scale rotate > /dev/null 2>&1
 python3 tools/host_path_bench.py > $out/host_path.txt 2>&1
-./build/tools/fir_ablate > $out/fir_ablate.txt 2>&1
+tools/bin/fir_ablate > $out/fir_ablate.txt 2>&1
 REPS=6 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $out/sq3 -- python3 tools/prof_kernels.py chain > /dev/null 2>&1
 python3 tools/pmc_sq.py $out/sq3 >> $out/sq_counters.txt
 tools/bin/mfma_fir > $out/mfma_fir.txt 2>&1
