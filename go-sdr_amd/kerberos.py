@@ -123,3 +123,46 @@ def phase_offsets(ctx, readers, n=SYNC_LENGTH):
         p /= float(n)
         ret[i] = np.complex64(complex(math.cos(p), math.sin(p)))  # cmplx.Rect(1, p)
     return ret
+
+
+def guess_alignment(readings):
+    """align.go:155-165: the lags are trusted only if every measurement of the batch agrees."""
+    ret = list(readings[0])
+    for r in readings:
+        if list(r) != ret:
+            return None, False
+    return ret, True
+
+
+def align_step(alignments, readers):
+    """align.go:167-238 (alignReaders).  A positive lag: reader 0 is that many samples behind reader n;
+    consume the largest one from reader 0, slide the others, then consume each remaining (negative)
+    lag from its own reader.  Returns True when every lag is 0 (sample lock)."""
+    alignments = list(alignments)
+    lo, hi = min([0] + alignments), max([0] + alignments)
+    if lo == 0 and hi == 0:
+        return True
+    if hi > 0:
+        read_full(readers[0], make_samples(FMT_C64, hi))
+        for i in range(1, len(alignments)):
+            alignments[i] -= hi
+    for i, a in enumerate(alignments):
+        if a != 0:
+            read_full(readers[i], make_samples(FMT_C64, -a))
+    return False
+
+
+def align_readers(ctx, readers, n=SYNC_LENGTH, measurements=10, max_rounds=64):
+    """align.go:273-305 (AlignReaders): measure the lags `measurements` times on fresh buffers
+    (cross-correlation on the GPU, hzsdr_peak_lag), act only on a unanimous batch, repeat until the
+    readers are in sample lock.  The reference loops forever on a stream that never agrees;
+    `max_rounds` bounds that here (HzsdrError)."""
+    bufs = [make_samples(FMT_C64, n) for _ in readers]
+    for _ in range(max_rounds):
+        batch = [check_alignment(ctx, readers, bufs) for _ in range(measurements)]
+        alignment, ok = guess_alignment(batch)
+        if not ok:
+            continue
+        if align_step(alignment, readers):
+            return
+    raise HzsdrError("kerberos: readers did not reach sample lock")

@@ -83,3 +83,28 @@ def test_mean_phase_and_phase_offsets(hz, ctx, orc):
         want = orc.mean_phase(chans[0], chans[j])
         assert abs(offs[j] - np.complex64(complex(math.cos(want), math.sin(want)))) < 1e-6
     assert abs(offs[0] - np.complex64(complex(math.cos(1 / n), math.sin(1 / n)))) < 1e-7  # the reference's phases[0] = 1
+
+
+def test_align_readers_reaches_sample_lock(hz, ctx):
+    """AlignReaders (align.go:273-305): three receivers that started 0, 37 and 211 samples apart;
+    batches of unanimous lag measurements, the consume steps of alignReaders, until every lag is 0.
+    Afterwards the three readers hand out the same samples."""
+    K = importlib.import_module("go-sdr_amd.kerberos")
+    S = importlib.import_module("go-sdr_amd.stream")
+    n = 1 << 14
+    base = rand_c64(21, 40 * n)
+    starts = [211, 174, 0]  # reader 0 is 37 behind reader 1 and 211 ahead of reader 2
+    readers = [S.BufferReader(base[s:].copy(), 2_400_000) for s in starts]
+    # the pieces: unanimity, and one consume step
+    assert K.guess_alignment([[0, 3, -2], [0, 3, -2]]) == ([0, 3, -2], True)
+    assert K.guess_alignment([[0, 3, -2], [0, 3, -1]]) == (None, False)
+    assert K.align_step([0, 0, 0], readers) is True
+    K.align_readers(ctx, readers, n=n, measurements=3)
+    a, b, c = (zeros("c64", 1000) for _ in range(3))
+    for r, buf in zip(readers, (a, b, c)):
+        S.read_full(r, buf)
+    assert a.tobytes() == b.tobytes() == c.tobytes()
+    # a stream that never agrees ends in an error here (the reference retries forever)
+    noise = [S.BufferReader(rand_c64(30 + i, 8 * n), 2_400_000) for i in range(2)]
+    with pytest.raises(hz.HzsdrError):
+        K.align_readers(ctx, noise, n=n, measurements=2, max_rounds=1)
