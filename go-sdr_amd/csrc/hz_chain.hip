@@ -363,13 +363,16 @@ static int prepare_late_filters(hzsdr_chain *c, double ts0) {
 
 static double mm_scale(const hzsdr_chain *c) { return c->src_fmt == HZSDR_FMT_U8 ? 1.0 / 127.5 : 1.0 / 128.0; }
 
-// Byte sources with a decimation of 8 or 16 and a filter the tile geometry holds.  Environment
-// HZ_FIR_FFT=1 keeps every chain on the transform kernels (A/B measurements, tests of that path).
+// Byte sources with a decimation of 8 or 16, up to the tap count at which the direct form's work
+// (proportional to the taps) passes the transforms' (tools/firmm_probe.py, 2^24 samples, us per
+// call, matrix / transform: D = 8: 64 taps 33 / 152, 256: 35 / 73, 512: 41 / 50, 1024: 48 / 53,
+// 1536: 70 / 70, 2048: 87 / 73; D = 16: 256: 32 / 70, 512: 37 / 78, 1024: 49 / 48, 2047: 72 / 67).
+// Environment HZ_FIR_FFT=1 keeps every chain on the transform kernels (A/B measurements, tests).
 static bool mm_eligible(const hzsdr_chain *c) {
     if (getenv("HZ_FIR_FFT")) return false;
     if (c->src_fmt != HZSDR_FMT_U8 && c->src_fmt != HZSDR_FMT_I8) return false;
     if (c->factor != 8 && c->factor != 16) return false;
-    return c->ntaps >= 64 && c->ntaps <= 4096;
+    return c->ntaps >= 16 && c->ntaps <= (c->factor == 8 ? 1536u : 1024u);
 }
 
 static void mm_geometry(hzsdr_chain *c) {

@@ -74,7 +74,7 @@ def build(hz, ctx, fmt, rate, ops, taps, D):
 
 CASES = {
     "u8_d8_1024": dict(fmt="u8", rate=20_000_000, ops=[("shift", -2.5e6)], ntaps=1024, D=8, n=1 << 20),
-    "u8_d16_2047": dict(fmt="u8", rate=20_000_000, ops=[("shift", 1.1e6)], ntaps=2047, D=16, n=1 << 20),
+    "u8_d16_1023": dict(fmt="u8", rate=20_000_000, ops=[("shift", 1.1e6)], ntaps=1023, D=16, n=1 << 20),
     "u8_d8_64": dict(fmt="u8", rate=2_400_000, ops=[("shift", 3e5)], ntaps=64, D=8, n=1 << 19),
     "u8_d8_129_program": dict(fmt="u8", rate=2_400_000, ops=[("gain", 0.5), ("shift", 1e5), ("rotate", 0.6 - 0.8j),
                                                               ("shift", -3.5e5)], ntaps=129, D=8, n=1 << 19),
@@ -82,7 +82,8 @@ CASES = {
                                 D=16, n=1 << 20),
     "i8_d8_1024": dict(fmt="i8", rate=20_000_000, ops=[("shift", 4e6)], ntaps=1024, D=8, n=1 << 20),
     "i8_d16_300": dict(fmt="i8", rate=8_000_000, ops=[("shift", -1e6), ("gain", 0.25)], ntaps=300, D=16, n=1 << 19),
-    "u8_d8_4096": dict(fmt="u8", rate=20_000_000, ops=[("shift", 2e6)], ntaps=4096, D=8, n=1 << 19),
+    "u8_d8_1536": dict(fmt="u8", rate=20_000_000, ops=[("shift", 2e6)], ntaps=1536, D=8, n=1 << 19),
+    "u8_d8_17": dict(fmt="u8", rate=20_000_000, ops=[("shift", 2e6)], ntaps=17, D=8, n=1 << 18),
 }
 
 
@@ -187,6 +188,11 @@ def test_where_the_matrix_form_must_not_run(hz, ctx, orc, monkeypatch):
     assert_fir_close(out_io, want8, taps, xmax, "in order")
     p, _ = run(4)  # another factor
     assert p == hz.FIR_PATH_TRANSFORM
+    ch = build(hz, ctx, hz.FMT_U8, rate, ops, taps_for(2048), 8)  # past the tap count where the direct form pays
+    ch.set_time(1.0)
+    ch.run(x, zeros("c64", n // 8))
+    assert ch.last_fir_path() == hz.FIR_PATH_TRANSFORM
+    ch.close()
     monkeypatch.setenv("HZ_FIR_FFT", "1")  # read when the terminal is created
     p, out_fft = run(8)
     assert p == hz.FIR_PATH_TRANSFORM
