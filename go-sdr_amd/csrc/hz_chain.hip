@@ -951,8 +951,16 @@ int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps, size_t n_taps, u
     HZ_TRY(chain_terminal_set(c));
     hzsdr_ctx *ctx = c->ctx;
     if (!taps || n_taps == 0 || factor == 0) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: fir taps / factor");
-    // N_fft = next power of two >= 4 * taps, in [256, 8192]
-    unsigned nfft = 256;
+    // N_fft = next power of two >= 4 * taps, in [N_min, 8192].  N_min is the smallest size at which the
+    // fast forms of the kernels apply: the late mixer needs one block per workgroup (N >= 1024) and
+    // the polyphase analysis N / D >= 256 for D = 2, 4, 8, 16.  Measured on 2^24 u8 samples (us per
+    // chain_run, N_min = 256 as in round 1 -> now): D = 8, 64 taps 152 -> 43, 256 taps 71 -> 45;
+    // D = 16, 256 taps 69 -> 41; D = 4, 128 taps 167 -> 54; D = 2, 64 taps 157 -> 78.
+    // (HZ_FIR_NFFT_MIN overrides N_min: the measurement aid those numbers come from.)
+    unsigned nfft = 1024;
+    if (factor == 2 || factor == 4 || factor == 8 || factor == 16) nfft = std::max(1024u, 256u * factor);
+    if (getenv("HZ_FIR_NFFT_MIN")) nfft = (unsigned)atoi(getenv("HZ_FIR_NFFT_MIN"));
+    if (nfft < 256 || nfft > 8192 || (nfft & (nfft - 1))) nfft = 1024;
     while (nfft < 4 * n_taps && nfft < 8192) nfft <<= 1;
     unsigned off = (unsigned)(n_taps - 1);
     off = (off + factor - 1) / factor * factor;  // first valid output on the decimation grid

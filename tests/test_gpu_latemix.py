@@ -147,3 +147,27 @@ def test_chains_without_a_shift(hz, ctx, orc):
         # differently): not the same bits, but equal to float32 rounding
         d = outs[0].astype(np.complex128) - outs[1]
         assert np.linalg.norm(d) <= CROSS_REL_L2 * np.linalg.norm(want.astype(np.complex128))
+
+
+@pytest.mark.parametrize("nmin,ntaps,D,fmt", [(256, 50, 3, "c64"), (256, 64, 8, "u8"), (512, 100, 2, "i16"), (512, 120, 5, "c64")])
+def test_small_overlap_save_blocks(hz, ctx, orc, monkeypatch, nmin, ntaps, D, fmt):
+    """The library picks N_fft >= 1024 (>= 256 D for the polyphase factors) because the fast forms of
+    the kernels need it; the 256- and 512-point instantiations stay correct (HZ_FIR_NFFT_MIN, read
+    when the terminal is created, and HZ_FIR_FFT for the byte source that would otherwise take the
+    matrix form)."""
+    from util import rand_i16
+    monkeypatch.setenv("HZ_FIR_NFFT_MIN", str(nmin))
+    monkeypatch.setenv("HZ_FIR_FFT", "1")
+    n, rate, taps = 1 << 18, 2_400_000, taps_for(ntaps)
+    ops = [("shift", 2.5e5), ("gain", 0.5)]
+    x = {"u8": rand_u8, "i16": rand_i16, "c64": rand_c64}[fmt](3, n)
+    f = {"u8": hz.FMT_U8, "i16": hz.FMT_I16, "c64": hz.FMT_C64}[fmt]
+    want, xc = oracle_chain(orc, x, rate, ops, taps, D)
+    for in_order in (False, True):
+        ch = build(hz, ctx, f, rate, ops, taps, D, in_order)
+        out = zeros("c64", n // D)
+        cons, outn = ch.run(x, out)
+        assert (cons, outn) == (n // D * D, n // D)
+        assert ch.last_fir_path() == hz.FIR_PATH_TRANSFORM
+        assert_fir_close(out, want[:outn], taps, float(np.abs(xc).max()), (nmin, ntaps, D, fmt, in_order))
+        ch.close()
