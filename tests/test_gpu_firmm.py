@@ -220,3 +220,52 @@ def test_misaligned_device_buffers_take_the_transforms(hz, orc):
     assert_fir_close(out.cpu().numpy(), want, taps, xmax, "misaligned")
     ch.close()
     ctx.close()
+
+
+def fuzz_case(seed):
+    r = np.random.default_rng(7000 + seed)
+    fmt = ["u8", "i8"][seed % 2]
+    D = [8, 16][(seed // 2) % 2]
+    ntaps = int(r.choice([16, 17, 63, 64, 65, 128, 255, 500, 777, 1024] + ([1025, 1400, 1536] if D == 8 else [1000])))
+    rate = int(r.choice([250_000, 2_400_000, 20_000_000]))
+    ops = []
+    for _ in range(int(r.integers(0, 4))):
+        kind = ["shift", "gain", "rotate"][int(r.integers(0, 3))]
+        if kind == "shift":
+            ops.append(("shift", float(r.uniform(-0.45, 0.45)) * rate))
+        elif kind == "gain":
+            ops.append(("gain", float(np.float32(r.uniform(0.1, 1.5)))))
+        else:
+            ops.append(("rotate", complex(np.complex64(np.exp(1j * r.uniform(0, TAU))))))
+    # ragged calls on the decimation grid, some too short for the matrix form
+    lens = [int(r.integers(3000, 60000)) * D for _ in range(int(r.integers(2, 5)))]
+    if seed % 3 == 0:
+        lens.insert(1, int(r.integers(10, 3000)) * D)
+    # clock starts: inside a long binade, just under a binade edge, just under the 2*pi wrap
+    ts0 = [1.3, 2.0 - 40000 / rate, TAU - 30000 / rate, 0.5 - 9000 / rate][seed % 4]
+    return dict(fmt=fmt, D=D, taps=taps_for(ntaps, 0.4 / D, float(r.uniform(-0.5, 0.5))), rate=rate, ops=ops,
+                lens=lens, ts0=float(ts0))
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("HZ_FUZZ_SEEDS", "32"))))
+def test_random_matrix_form_streams(hz, ctx, orc, seed):
+    """Seeded random chains over byte sources at factor 8 / 16: tap counts around the tile and table
+    edges, zero to three elementwise stages, ragged calls (some on the transform kernels, so the two
+    histories alternate), clocks that cross a binade edge or the 2*pi wrap inside the stream."""
+    c = fuzz_case(seed)
+    D, taps, rate = c["D"], c["taps"], c["rate"]
+    n = sum(c["lens"])
+    x = (rand_u8 if c["fmt"] == "u8" else rand_i8)(8000 + seed, n)
+    cuts = np.concatenate([[0], np.cumsum(c["lens"])]).tolist()
+    want, xmax = oracle(orc, x, rate, c["ops"], taps, D, ts0=c["ts0"])
+    ch = build(hz, ctx, hz.FMT_U8 if c["fmt"] == "u8" else hz.FMT_I8, rate, c["ops"], taps, D)
+    ch.set_time(c["ts0"])
+    out = zeros("c64", n // D)
+    paths = set()
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        assert ch.run(x[a:b], out[a // D:b // D]) == (b - a, (b - a) // D)
+        paths.add(ch.last_fir_path())
+    if max(c["lens"]) // D >= 16384:  # (a short call that is mostly clock boundaries may stay on the transforms)
+        assert hz.FIR_PATH_MATRIX in paths, (seed, c["lens"])
+    assert_fir_close(out, want, taps, xmax, (seed, c["fmt"], D, len(taps), rate, c["ops"], c["lens"], c["ts0"]))
+    ch.close()
