@@ -223,9 +223,9 @@ def main():
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "hbm": hbm,
             "note": "the chain is above the HBM ridge (3 B/sample): the int8 matrix cores bind; the "
-                    "matrix pipe is busy ~42 % of the kernel (SQ_VALU_MFMA_BUSY_CYCLES, "
-                    "profiles/r02_sq_counters.txt), the rest is the input burst before and the "
-                    "epilogue after the matrix loop of workgroups that all run in phase",
+                    "matrix pipe is busy 94 % of the matrix loop and ~44 % of the kernel "
+                    "(profiles/r02_mfma_fir.txt, r02_sq_counters.txt); the rest is the input burst before and "
+                    "the epilogue after the loop of workgroups that all run in phase",
         }
     else:
         roof = dict(hbm, traffic=None,

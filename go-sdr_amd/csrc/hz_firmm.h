@@ -26,14 +26,21 @@
 //     registers each, two waves per SIMD); they exchange halves through LDS and each finishes
 //     1024 outputs: float64 combination, the elementwise program as a phase recurrence (the
 //     clock is exactly linear inside the run), store.
-//   * outputs whose window crosses a boundary of the clock's runs, the start of the stream or a
-//     run without a table are computed in reference order by the same launch's FIX-UP workgroups
-//     (direct form, float64 accumulation), and the history for the next call (the last `off`
-//     samples after the elementwise program, the format the transform kernels share) by its
-//     HISTORY workgroups.  The int8 form needs no FFT, no spectrum round trip and one launch.
+//   * the call's outputs are cut into chunks of 2048 on ONE grid; a chunk belongs to the clock run
+//     that holds most of it.  Outputs whose window crosses a boundary of the clock's runs, the start
+//     of the stream or a run without a table -- and what a boundary chunk's run does not hold -- are
+//     FIX-UP TASKS (16 outputs in reference order: direct form, float64 accumulation); the history
+//     for the next call (the last `off` samples after the elementwise program, the format the
+//     transform kernels share, and the same samples as raw bytes) are HISTORY TASKS.  Chunk
+//     workgroup b takes task b, b + grid, ... while its first input loads are in flight: no second
+//     launch, no extra workgroups (1024 chunk workgroups fill the chip exactly at 2^21 outputs).
+//     When the clock run continues across a call boundary the first windows reach back into the raw
+//     history: a steady-state call has no fix-up at all.
 //
-// Measured (tools/mfma_fir.hip, MI355X): the matrix loop of 2^24 samples, 1024 taps, D = 8 runs
-// at ~3.1 Pop/s (the chip holds ~1.6 GHz under this load) -- see DESIGN.md section 4.
+// Measured (MI355X, 2^24 u8 samples, 1024 taps, D = 8; tools/mfma_fir.hip, tools/firmm_probe.py,
+// profiles/r02_*): 43-46 us per call inside one clock run, 1.5 Pop/s = 0.30 of the dense int8 peak,
+// the matrix pipe busy 94 % of the matrix loop and 42 % of the kernel (the chip holds ~1.55 GHz
+// under this load); HBM traffic 1.07x the algorithmic bytes.  DESIGN.md section 4 has the history.
 #pragma once
 #include "hz_chain_dev.h"
 
