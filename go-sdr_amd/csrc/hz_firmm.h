@@ -132,7 +132,9 @@ __device__ __forceinline__ NcoWin task_window(const EwProgram &P, int64_t p_lo, 
 }
 
 // EXP: ablation switches for tools/mfma_fir.hip (0 in the library): 1 = no input loads, 2 = no
-// matrix loop, 4 = no elementwise program, 8 = no stores.  Results are wrong with any of them set.
+// matrix loop, 4 = no elementwise program, 8 = no stores (results are wrong with any of these set);
+// 64 = s_memtime stamps at the phase boundaries of every workgroup, 128 = plain instead of
+// non-temporal input loads (input phase 16.8 k -> 18.0 k cycles).
 // (Switching the loop's operand loads off does not time the MFMAs alone: with undefined operands the
 // compiler deletes the loop.  tools/mfma_rate.hip has the loop's MFMA pattern with and without loads.)
 template <int FMT, int D, int EXP = 0>
@@ -258,7 +260,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                 x[u] = v4i{0, 0, 0, 0};
                 if (q < pieces) {
                     if ((EXP & 1) == 0 && p >= 0 && p + 16 <= n_bytes) {
-                        x[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(src + p));
+                        if constexpr ((EXP & 128) != 0) x[u] = *reinterpret_cast<const v4i *>(src + p);
+                        else x[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(src + p));
                     } else if (p < 0 && R.cont && p + 2 * (int64_t)G.off >= 0) {
                         // before the buffer: the previous call's last samples (2 off is a multiple of 16)
                         x[u] = *reinterpret_cast<const v4i *>(rhist + (p + 2 * (int64_t)G.off));

@@ -122,5 +122,6 @@ int main(int argc, char **argv) {
     run<4>(in, out, taps, tab, n, ntaps, true);
     CK(hipMalloc(&g_stamps, 8 * 8 * 4096));
     run<64>(in, out, taps, tab, n, ntaps, true);
+    run<64 + 128>(in, out, taps, tab, n, ntaps, true);
     return 0;
 }
