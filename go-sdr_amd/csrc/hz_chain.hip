@@ -550,8 +550,12 @@ static bool mm_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in
     for (int r = 0; r < nr; r++) R->wg_first[r] = (int)n_chunks;
     for (uint64_t ch = 0; ch < n_chunks; ch++) {
         const uint64_t cs = ch * mm::kChunkOut, ce = std::min(cs + mm::kChunkOut, n_out);
+        // the valid ranges ascend with r, so the owner never goes back and the scan stops at the first
+        // run that starts behind the chunk (runs without a range are [0, 0)): linear in chunks + runs
         uint64_t best = 0;
-        for (int r = owner; r < nr; r++) {  // (the valid ranges ascend with r: the owner never goes back)
+        for (int r = owner; r < nr; r++) {
+            if (R->m_hi[r] == 0) continue;
+            if (R->m_lo[r] >= ce) break;
             const uint64_t lo = std::max<uint64_t>(R->m_lo[r], cs), hi = std::min<uint64_t>(R->m_hi[r], ce);
             if (hi > lo && hi - lo > best) {
                 best = hi - lo;
