@@ -93,7 +93,7 @@ __device__ __forceinline__ NcoWin nco_window_all(const NcoSegs &sg) {
 __device__ __forceinline__ double nco_ts(const NcoSegs &sg, NcoWin w, uint64_t j) {
     uint64_t first;
     double t0, step;
-    if (sg.big_n == 0) {
+    if (sg.big_n == 0 && w.hi - w.lo <= 3) {
         first = sg.first[w.lo];
         t0 = sg.t0[w.lo];
         step = sg.step[w.lo];
@@ -105,6 +105,18 @@ __device__ __forceinline__ double nco_ts(const NcoSegs &sg, NcoWin w, uint64_t j
                 step = sg.step[s];
             }
         }
+    } else if (sg.big_n == 0) {
+        // a wide window (a span over the short runs right behind the clock's 2*pi wrap): the scan above
+        // waits for a dependent scalar load per run and sample -- 15 runs cost a fix-up task of the
+        // matrix FIR 17 us; a per-lane binary search is five vector loads
+        int lo = w.lo, hi = w.hi;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (sg.first[mid] <= j) lo = mid; else hi = mid - 1;
+        }
+        first = sg.first[lo];
+        t0 = sg.t0[lo];
+        step = sg.step[lo];
     } else {
         int lo = w.lo, hi = w.hi;  // last run with first <= j, per lane
         while (lo < hi) {
