@@ -163,6 +163,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     // input burst of every workgroup at once, a task's loads took 7 us to come back).
     const int n_hist_tasks = new_hist ? (int)((G.off + kThreads - 1) / kThreads) : 0;
     const int n_tasks = F.n_wg + n_hist_tasks;
+    // A few tasks (a clock boundary in the call: ~40) hide best under the input burst of the workgroups
+    // that take them; hundreds (the call in which the clock wraps) are cheaper behind the stores, where
+    // their own loads do not queue behind the burst (measured: 48 / 53 us and 61 / 57 us per call).
+    const bool tasks_late = n_tasks > 200;
     auto small_task = [&](int task) {
         using RW = typename Raw<FMT>::t;
         if (task < F.n_wg) {
@@ -287,7 +291,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         };
         v4i x[U];
         issue(x, tid);
-        for (int task = wb; task < n_tasks; task += (int)gridDim.x) small_task(task);  // (uniform)
+        if (!tasks_late)
+            for (int task = wb; task < n_tasks; task += (int)gridDim.x) small_task(task);  // (uniform)
         land(x, tid);
 #pragma unroll 1
         for (int q0 = tid + U * kThreads; q0 < pieces; q0 += U * kThreads) {
@@ -516,7 +521,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
     }
     stamp(5);
-    if (!active) {
+    if (!active || tasks_late) {
+        if (active) __syncthreads();
         for (int task = wb; task < n_tasks; task += (int)gridDim.x) small_task(task);  // (uniform)
     }
 }
