@@ -603,7 +603,7 @@ static int mm_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const 
     uint8_t *nrh = (uint8_t *)c->rhist[c->hist_cur ^ 1];
     const mm::Geom &g = c->mmg;
     const int D = (int)c->factor;
-    const size_t lds = std::max(mm::chunk_bytes(D, g.ks), (size_t)(2 * g.ntaps + D * (mm::kFixOut - 1)) * 8);
+    const size_t lds = std::max(mm::chunk_bytes(D, g.ks) + mm::kLookAhead, (size_t)(2 * g.ntaps + D * (mm::kFixOut - 1)) * 8);
     const unsigned grid = (unsigned)R.n_wg;  // (the fix-up and history tasks ride on the chunk workgroups)
     if constexpr (FMT == HZSDR_FMT_U8 || FMT == HZSDR_FMT_I8) {
         if (D == 8)

@@ -91,6 +91,9 @@ struct Fix {
 constexpr int tile_bytes(int D) { return 2 * D * kT; }
 constexpr int pieces_per_tile(int D) { return tile_bytes(D) / 16; }
 constexpr size_t chunk_bytes(int D, int ks) { return (size_t)(kChunkTiles - 1) * tile_bytes(D) + 32 * (size_t)ks; }
+// the matrix loop's look-ahead reads two steps past the last window: LDS allocated behind the image
+// (a conditional in the unrolled loop instead cost 1.8 us of the kernel)
+constexpr size_t kLookAhead = 1024;
 // table bytes: 4 digits x ne x 2 parts x 16, then (dc_re, dc_im) as two doubles
 constexpr size_t table_bytes(int ne) { return (size_t)4 * ne * 32 + 16; }
 
@@ -158,9 +161,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     // ---- the small tasks: outputs in reference order (fix-up) and the next call's history --------
     // They have no workgroups of their own: as workgroups at the END of the grid each was a ~8 us
     // latency chain (load, Sincos, dot product, store) behind the chunk workgroups, and ahead of them
-    // they push chunk workgroups out of the single round the chip holds (1024 at 2^21 outputs).  A
-    // chunk workgroup takes task b, b + grid, ... after its own stores (at its start, under the
-    // input burst of every workgroup at once, a task's loads took 7 us to come back).
+    // they push chunk workgroups out of the single round the chip holds (1024 at 2^21 outputs).
+    // Chunk workgroup b takes task b, b + grid, ...
     const int n_hist_tasks = new_hist ? (int)((G.off + kThreads - 1) / kThreads) : 0;
     const int n_tasks = F.n_wg + n_hist_tasks;
     // A few tasks (a clock boundary in the call: ~40) hide best under the input burst of the workgroups
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                 for (int j = 0; j < GS; j++) {
                     if (j + 2 < GS) load_b(b[(j + 2) & 3], base, xh, j + 2);
-                    else load_b(b[(j + 2) & 3], base_n, xh_n, j + 2 - GS);  // (past the window after the last group: unused)
+                    else load_b(b[(j + 2) & 3], base_n, xh_n, j + 2 - GS);  // (after the last group: one tile past the image, unused -- kLookAhead)
                     mma(a[j & 3], b[j & 3]);
                     load_a(a[j & 3], j + 4);
                     __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // the address of the step's reads

@@ -56,7 +56,7 @@ template <int EXP> static void run(void *const *in, float2 *out, const float2 *t
         F.m_b[0] = R.m_lo[0];
         F.n_wg = (int)((R.m_lo[0] + mm::kFixOut - 1) / mm::kFixOut);
     }
-    const size_t lds = mm::chunk_bytes(D, g.ks);
+    const size_t lds = mm::chunk_bytes(D, g.ks) + mm::kLookAhead;
     const unsigned grid = (unsigned)R.n_wg;
     auto k = mm::fir_mm_kernel<HZSDR_FMT_U8, D, EXP>;
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
