@@ -269,3 +269,33 @@ def test_random_matrix_form_streams(hz, ctx, orc, seed):
         assert hz.FIR_PATH_MATRIX in paths, (seed, c["lens"])
     assert_fir_close(out, want, taps, xmax, (seed, c["fmt"], D, len(taps), rate, c["ops"], c["lens"], c["ts0"]))
     ch.close()
+
+
+def test_reset_and_interleaved_chains(hz, ctx, orc):
+    """hzsdr_chain_reset drops both histories and the clock; two chains on one context keep their own
+    state when their calls interleave."""
+    rate, D = 2_400_000, 8
+    n = 1 << 18
+    xa, xb = rand_u8(41, 2 * n), rand_u8(42, 2 * n)
+    ta, tb = taps_for(300), taps_for(777, 1 / 40, -0.2)
+    opa, opb = [("shift", 2e5)], [("shift", -7e5), ("gain", 0.5)]
+    wa, xma = oracle(orc, xa, rate, opa, ta, D, ts0=1.0)
+    wb, xmb = oracle(orc, xb, rate, opb, tb, D, ts0=2.5)
+    ca = build(hz, ctx, hz.FMT_U8, rate, opa, ta, D).set_time(1.0)
+    cb = build(hz, ctx, hz.FMT_U8, rate, opb, tb, D).set_time(2.5)
+    oa, ob = zeros("c64", 2 * n // D), zeros("c64", 2 * n // D)
+    for k in range(2):  # a, b, a, b
+        sl, so = slice(k * n, (k + 1) * n), slice(k * n // D, (k + 1) * n // D)
+        assert ca.run(xa[sl], oa[so]) == (n, n // D)
+        assert cb.run(xb[sl], ob[so]) == (n, n // D)
+        assert ca.last_fir_path() == cb.last_fir_path() == hz.FIR_PATH_MATRIX
+    assert_fir_close(oa, wa, ta, xma, "chain a")
+    assert_fir_close(ob, wb, tb, xmb, "chain b")
+    # reset: the same first half again, from a clean history and clock 0 -> set back to 1 s
+    ca.reset()
+    ca.set_time(1.0)
+    again = zeros("c64", n // D)
+    assert ca.run(xa[:n], again) == (n, n // D)
+    assert again.tobytes() == oa[:n // D].tobytes()
+    ca.close()
+    cb.close()
