@@ -58,6 +58,16 @@ constexpr int kThreads = 128;                 // two waves
 constexpr int kFixOut = 16;                   // outputs per fix-up task
 constexpr int kMaxRuns = kNcoMaxSegs;
 constexpr int kMaxFix = kMaxRuns + 2;
+// How the two waves of a workgroup share the chunk's 4 digit planes x 4 column blocks:
+// HZ_MM_SPLIT_BLOCKS = 0: by digits (wave 0: planes 0-1, wave 1: planes 2-3, all four blocks; the halves
+// meet through LDS); 1: by blocks (each wave all four planes of two blocks: no exchange, twice the
+// table loads, half the LDS reads).
+#ifndef HZ_MM_SPLIT_BLOCKS
+#define HZ_MM_SPLIT_BLOCKS 0
+#endif
+constexpr bool kSplitBlocks = HZ_MM_SPLIT_BLOCKS != 0;
+constexpr int kND = kSplitBlocks ? 4 : 2;       // digit planes per wave
+constexpr int kNBW = kSplitBlocks ? 2 : kNB;    // column blocks per wave
 
 // geometry of one chain (host: mm_geometry)
 struct Geom {
@@ -308,36 +318,38 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         stamp(2);
         // A fragments: entry (D/8) i - h - 2 s + e0 of this wave's two digits, parts interleaved
         const v4i *ftab = (const v4i *)R.tab[r];
-        const v4i *fa = ftab + (size_t)(2 * wave) * 2 * G.ne + 2 * ((D / 8) * i - h + G.e0) + part;
+        const v4i *fa = ftab + (size_t)(kSplitBlocks ? 0 : 2 * wave) * 2 * G.ne + 2 * ((D / 8) * i - h + G.e0) + part;
         const int dstride = 2 * G.ne;
-        v16i acc[2][kNB];
+        v16i acc[kND][kNBW];
 #pragma unroll
-        for (int d = 0; d < 2; d++)
+        for (int d = 0; d < kND; d++)
 #pragma unroll
-            for (int j = 0; j < kNB; j++)
+            for (int j = 0; j < kNBW; j++)
 #pragma unroll
                 for (int q = 0; q < 16; q++) acc[d][j][q] = 0;
         // Step s of the window reads piece 2 s + h of tile n (+ 32 j): with GS = PPT / 2 steps per group
         // the tile is n + g and the piece 2 j + h for step j of group g -- the swizzled address is
         // 16 ((2 j) ^ xh) past the group's base, xh = ((n + g) & 15) ^ h: two instructions per step.
         constexpr int GS = PPT / 2;
-        auto load_b = [&](v4i(&b)[kNB], int base, int xh, int j) {
-            const uint8_t *bp = mm_lds + base + 16 * ((2 * j) ^ xh);
+        auto load_b = [&](v4i(&b)[kNBW], int base, int xh, int j) {
+            const uint8_t *bp = mm_lds + base + 16 * ((2 * j) ^ xh) + (kSplitBlocks ? wave * 2 * 32 * TB : 0);
 #pragma unroll
-            for (int q = 0; q < kNB; q++) b[q] = *reinterpret_cast<const v4i *>(bp + q * 32 * TB);
+            for (int q = 0; q < kNBW; q++) b[q] = *reinterpret_cast<const v4i *>(bp + q * 32 * TB);
         };
         // (a running pointer per digit, stepped once per group: the loads inside a group take immediate
         // offsets instead of 64-bit address arithmetic per load)
-        const v4i *pa0 = fa, *pa1 = fa + dstride;
-        auto load_a = [&](v4i(&a)[2], int js) {  // step js of the current group (may run into the next)
-            a[0] = pa0[-4 * js];
-            a[1] = pa1[-4 * js];
+        const v4i *pa[kND];
+#pragma unroll
+        for (int d = 0; d < kND; d++) pa[d] = fa + d * dstride;
+        auto load_a = [&](v4i(&a)[kND], int js) {  // step js of the current group (may run into the next)
+#pragma unroll
+            for (int d = 0; d < kND; d++) a[d] = pa[d][-4 * js];
         };
-        auto mma = [&](const v4i(&a)[2], const v4i(&b)[kNB]) {
+        auto mma = [&](const v4i(&a)[kND], const v4i(&b)[kNBW]) {
 #pragma unroll
-            for (int d = 0; d < 2; d++)
+            for (int d = 0; d < kND; d++)
 #pragma unroll
-                for (int q = 0; q < kNB; q++) acc[d][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d], b[q], acc[d][q], 0, 0, 0);
+                for (int q = 0; q < kNBW; q++) acc[d][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d], b[q], acc[d][q], 0, 0, 0);
         };
         {
             // Operands ahead of the MFMAs that use them: the bytes two steps (LDS), the taps FOUR steps
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             // of the loop).  Inside a step the loads go between the MFMAs (sched_group_barrier): issued
             // as a clump after them, the wave's own MFMA stream had a ~100-cycle hole per step.
             // ks is a multiple of GS and the table is padded by four steps in front.
-            v4i a[4][2], b[4][kNB];
+            v4i a[4][kND], b[4][kNBW];
 #pragma unroll
             for (int q = 0; q < 4; q++) load_a(a[q], q);
             int t = n, base = TB * t, xh = (t & 15) ^ h;
@@ -363,23 +375,23 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                     load_a(a[j & 3], j + 4);
                     __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // the address of the step's reads
 #pragma unroll
-                    for (int q = 0; q < kNB; q++) {
+                    for (int q = 0; q < kNBW; q++) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // LDS read
                     }
 #pragma unroll
-                    for (int q = 0; q < 2; q++) {
+                    for (int q = 0; q < kND; q++) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // table load
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * kNB - kNB - 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, kND * kNBW - kNBW - kND, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 t = tn;
                 base = base_n;
                 xh = xh_n;
-                pa0 -= 4 * GS;
-                pa1 -= 4 * GS;
+#pragma unroll
+                for (int d = 0; d < kND; d++) pa[d] -= 4 * GS;
             };
             // The compiler drains every outstanding load at a loop header (s_waitcnt vmcnt(0) lgkmcnt(0):
             // it cannot count across the back edge), which empties the operand pipeline once per trip:
@@ -393,52 +405,73 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
         stamp(3);
-        // The halves meet: wave 0 (digits 0-1) finishes column blocks 0-1, wave 1 (digits 2-3) blocks 2-3.
-        // hi = acc0 * 256 + acc1 is exact in float64; the low pair's weight is 2^-16: float32 is enough.
+        // The planes meet.  Split by digits: wave 0 (planes 0-1) finishes column blocks 0-1, wave 1 (planes
+        // 2-3) blocks 2-3; hi = acc0 * 256 + acc1 is exact in float64, the low pair's weight is 2^-16:
+        // float32 is enough.  Split by blocks: a wave has all four planes of its two blocks.
         __syncthreads();  // both waves are done with the chunk's bytes
-        double *xhi = reinterpret_cast<double *>(mm_lds);              // [2][16][64]
-        float *xlo = reinterpret_cast<float *>(mm_lds + 2 * 16 * 64 * 8);  // [2][16][64]
-        if (wave == 0) {
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int q = 0; q < 16; q++)
-                    xhi[(j * 16 + q) * 64 + l] = __fma_rn((double)acc[0][2 + j][q], 256.0, (double)acc[1][2 + j][q]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int q = 0; q < 16; q++)
-                    xlo[(j * 16 + q) * 64 + l] = __fmaf_rn((float)acc[0][j][q], 256.0f, (float)acc[1][j][q]);
-        }
-        __syncthreads();
         const double *dc = reinterpret_cast<const double *>((const uint8_t *)R.tab[r] + (size_t)4 * G.ne * 32);
         const double dcr = dc[0], dci = dc[1];
         const double scale = __hiloint2double((1023 - G.shift) << 20, 0);  // 2^-S
         float2 y[2][8];  // [own block][4 q4 + ... ]: outputs 4 q4 + 2 h + e of tile 32 (2 wave + j) + n
+        if constexpr (kSplitBlocks) {
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+            for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int q4 = 0; q4 < 4; q4++)
+                for (int q4 = 0; q4 < 4; q4++)
 #pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    float c2[2];
+                    for (int e = 0; e < 2; e++) {
+                        float c2[2];
 #pragma unroll
-                    for (int pt = 0; pt < 2; pt++) {
-                        const int q = 4 * q4 + 2 * e + pt;
-                        double hi, lo;
-                        if (wave == 0) {
-                            hi = __fma_rn((double)acc[0][j][q], 256.0, (double)acc[1][j][q]);
-                            lo = (double)xlo[(j * 16 + q) * 64 + l];
-                        } else {
-                            hi = xhi[(j * 16 + q) * 64 + l];
-                            lo = (double)__fmaf_rn((float)acc[0][2 + j][q], 256.0f, (float)acc[1][2 + j][q]);
+                        for (int pt = 0; pt < 2; pt++) {
+                            const int q = 4 * q4 + 2 * e + pt;
+                            const double hi = __fma_rn((double)acc[0][j][q], 256.0, (double)acc[1][j][q]);
+                            const double lo = __fma_rn((double)acc[kND - 2][j][q], 256.0, (double)acc[kND - 1][j][q]);
+                            const double v = __fma_rn(hi, 65536.0, lo) + (pt ? dci : dcr);
+                            c2[pt] = (float)(v * scale);
                         }
-                        const double v = __fma_rn(hi, 65536.0, lo) + (pt ? dci : dcr);
-                        c2[pt] = (float)(v * scale);
+                        y[j][2 * q4 + e] = make_float2(c2[0], c2[1]);
                     }
-                    y[j][2 * q4 + e] = make_float2(c2[0], c2[1]);
-                }
+        } else {
+            double *xhi = reinterpret_cast<double *>(mm_lds);              // [2][16][64]
+            float *xlo = reinterpret_cast<float *>(mm_lds + 2 * 16 * 64 * 8);  // [2][16][64]
+            if (wave == 0) {
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int q = 0; q < 16; q++)
+                        xhi[(j * 16 + q) * 64 + l] = __fma_rn((double)acc[0][(2 + j) % kNBW][q], 256.0, (double)acc[1][(2 + j) % kNBW][q]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int q = 0; q < 16; q++)
+                        xlo[(j * 16 + q) * 64 + l] = __fmaf_rn((float)acc[0][j][q], 256.0f, (float)acc[1][j][q]);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++)
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        float c2[2];
+#pragma unroll
+                        for (int pt = 0; pt < 2; pt++) {
+                            const int q = 4 * q4 + 2 * e + pt;
+                            double hi, lo;
+                            if (wave == 0) {
+                                hi = __fma_rn((double)acc[0][j][q], 256.0, (double)acc[1][j][q]);
+                                lo = (double)xlo[(j * 16 + q) * 64 + l];
+                            } else {
+                                hi = xhi[(j * 16 + q) * 64 + l];
+                                lo = (double)__fmaf_rn((float)acc[0][(2 + j) % kNBW][q], 256.0f, (float)acc[1][(2 + j) % kNBW][q]);
+                            }
+                            const double v = __fma_rn(hi, 65536.0, lo) + (pt ? dci : dcr);
+                            c2[pt] = (float)(v * scale);
+                        }
+                        y[j][2 * q4 + e] = make_float2(c2[0], c2[1]);
+                    }
+        }
         // The elementwise program over this lane's 16 outputs m = mb + 512 j + 4 q4 + e: equally spaced
         // in three directions inside one exactly-linear clock run, so a Shift stage is
         // z0 * wB^j * wA^q4 * wE^e (see ew_apply_seq for the error argument).
