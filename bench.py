@@ -103,7 +103,7 @@ def self_launch(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=150)  # 20 periods of the clock (a 2*pi wrap every 7.5 steps)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log2n", type=int, default=24, help="samples per buffer = 2^log2n")
     ap.add_argument("--no-extra", action="store_true", help="skip the per-config side measurements")
