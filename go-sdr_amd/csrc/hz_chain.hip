@@ -371,13 +371,14 @@ static double mm_scale(const hzsdr_chain *c) { return c->src_fmt == HZSDR_FMT_U8
 // Byte sources with a decimation of 8 or 16, up to the tap count at which the direct form's work
 // (proportional to the taps) passes the transforms' (tools/firmm_probe.py, 2^24 samples, us per
 // call, matrix / transform: D = 8: 64 taps 33 / 152, 256: 35 / 73, 512: 41 / 50, 1024: 48 / 53,
-// 1536: 70 / 70, 2048: 87 / 73; D = 16: 256: 32 / 70, 512: 37 / 78, 1024: 49 / 48, 2047: 72 / 67).
+// 1536: 70 / 70, 2048: 87 / 73; D = 16 (chunks of 1024 outputs): 256: 24 / 70, 512: 28 / 78, 1024: 36 / 48,
+// 1536: 46 / 67, 2047: 54 / 69, 3000: 85 / 82; the transform figures before N_fft started at 256 D).
 // Environment HZ_FIR_FFT=1 keeps every chain on the transform kernels (A/B measurements, tests).
 static bool mm_eligible(const hzsdr_chain *c) {
     if (getenv("HZ_FIR_FFT")) return false;
     if (c->src_fmt != HZSDR_FMT_U8 && c->src_fmt != HZSDR_FMT_I8) return false;
     if (c->factor != 8 && c->factor != 16) return false;
-    return c->ntaps >= 16 && c->ntaps <= (c->factor == 8 ? 1536u : 1024u);
+    return c->ntaps >= 16 && c->ntaps <= (c->factor == 8 ? 1536u : 2560u);
 }
 
 static void mm_geometry(hzsdr_chain *c) {
@@ -496,7 +497,8 @@ static bool mm_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in
     memset(F, 0, sizeof *F);
     if (!c->mm_ok || c->mix_in_order || P.segs.big_n != 0 || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) return false;
     const uint64_t D = c->factor, n_out = n / D, nt = c->ntaps;
-    if (n_out < 2 * (uint64_t)mm::kChunkOut || n_out >= (1ull << 31)) return false;
+    const uint64_t chunk_out = mm::chunk_out(mm::blocks_for((int)D));  // 2048 outputs at D = 8, 1024 at D = 16
+    if (n_out < 4096 || n_out >= (1ull << 31)) return false;
     for (int i = 0; i < P.n; i++)
         if (P.op[i].kind == EW_SHIFT && !(fabs(P.op[i].tau_shift) * 6.2832 < 1073741824.0)) return false;
     const int nr = c->has_shift ? P.segs.n : 1;
@@ -524,9 +526,9 @@ static bool mm_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in
         any = true;
     }
     if (!any) return false;
-    // The call's outputs in chunks of 2048; a chunk goes to the run that holds most of it (none: the
+    // The call's outputs in chunks of 2048 (D = 16: 1024); a chunk goes to the run that holds most of it (none: the
     // run of the chunk before), what that run does not hold goes to the fix-up tasks.
-    const uint64_t n_chunks = (n_out + mm::kChunkOut - 1) / mm::kChunkOut;
+    const uint64_t n_chunks = (n_out + chunk_out - 1) / chunk_out;
     uint64_t fix_total = 0, fix_a = 0, fix_b = 0;  // the open fix interval [fix_a, fix_b)
     auto flush_fix = [&]() {
         if (fix_b > fix_a && F->n < mm::kMaxFix) {
@@ -554,7 +556,7 @@ static bool mm_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in
     int owner = 0, prev_owner = -1;
     for (int r = 0; r < nr; r++) R->wg_first[r] = (int)n_chunks;
     for (uint64_t ch = 0; ch < n_chunks; ch++) {
-        const uint64_t cs = ch * mm::kChunkOut, ce = std::min(cs + mm::kChunkOut, n_out);
+        const uint64_t cs = ch * chunk_out, ce = std::min(cs + chunk_out, n_out);
         // the valid ranges ascend with r, so the owner never goes back and the scan stops at the first
         // run that starts behind the chunk (runs without a range are [0, 0)): linear in chunks + runs
         uint64_t best = 0;

@@ -20,13 +20,13 @@
 //     instruction.  Every A fragment is an entry of ONE small table F[digit][E][part] (16 bytes:
 //     eight taps x (coefficient of re, of im)), E = (D/8) i - h - 2 s: 21 KB per clock run,
 //     read coalesced (a wave's 64 lanes read ~544 consecutive bytes) and L1-resident.
-//   * a workgroup = two waves over the same 2048 outputs (128 tiles, 34 KB of input in LDS,
+//   * a workgroup = two waves over the same 2048 outputs at D = 8, 1024 at D = 16 (34 KB of input in LDS,
 //     16-byte pieces XOR-swizzled by the tile index so that a fragment read is conflict-free
 //     without padding): wave 0 multiplies by digits 0-1, wave 1 by digits 2-3 (128 accumulator
 //     registers each, two waves per SIMD); they exchange halves through LDS and each finishes
 //     1024 outputs: float64 combination, the elementwise program as a phase recurrence (the
 //     clock is exactly linear inside the run), store.
-//   * the call's outputs are cut into chunks of 2048 on ONE grid; a chunk belongs to the clock run
+//   * the call's outputs are cut into chunks of 2048 (1024) on ONE grid; a chunk belongs to the clock run
 //     that holds most of it.  Outputs whose window crosses a boundary of the clock's runs, the start
 //     of the stream or a run without a table -- and what a boundary chunk's run does not hold -- are
 //     FIX-UP TASKS (16 outputs in reference order: direct form, float64 accumulation); the history
@@ -51,9 +51,12 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int kT = 16;                        // outputs per tile
-constexpr int kNB = 4;                        // 32-tile column blocks per workgroup
-constexpr int kChunkTiles = 32 * kNB;         // 128
-constexpr int kChunkOut = kChunkTiles * kT;   // 2048 outputs per chunk workgroup
+// NB 32-tile column blocks per workgroup: 4 at D = 8 (2048 outputs, 34 KB of input: four workgroups per
+// CU), 2 at D = 16 (1024 outputs, the same 34 KB: with 4 a chunk was 67 KB, two workgroups per CU --
+// one wave per SIMD -- and the matrix form no faster than the transforms at 1024 taps)
+constexpr int blocks_for(int D) { return D >= 16 ? 2 : 4; }
+constexpr int chunk_tiles(int nb) { return 32 * nb; }
+constexpr int chunk_out(int nb) { return chunk_tiles(nb) * kT; }
 constexpr int kThreads = 128;                 // two waves
 constexpr int kFixOut = 16;                   // outputs per fix-up task
 constexpr int kMaxRuns = kNcoMaxSegs;
@@ -67,7 +70,6 @@ constexpr int kMaxFix = kMaxRuns + 2;
 #endif
 constexpr bool kSplitBlocks = HZ_MM_SPLIT_BLOCKS != 0;
 constexpr int kND = kSplitBlocks ? 4 : 2;       // digit planes per wave
-constexpr int kNBW = kSplitBlocks ? 2 : kNB;    // column blocks per wave
 
 // geometry of one chain (host: mm_geometry)
 struct Geom {
@@ -100,7 +102,9 @@ struct Fix {
 
 constexpr int tile_bytes(int D) { return 2 * D * kT; }
 constexpr int pieces_per_tile(int D) { return tile_bytes(D) / 16; }
-constexpr size_t chunk_bytes(int D, int ks) { return (size_t)(kChunkTiles - 1) * tile_bytes(D) + 32 * (size_t)ks; }
+constexpr size_t chunk_bytes(int D, int ks) {
+    return (size_t)(chunk_tiles(blocks_for(D)) - 1) * tile_bytes(D) + 32 * (size_t)ks;
+}
 // the matrix loop's look-ahead reads two steps past the last window: LDS allocated behind the image
 // (a conditional in the unrolled loop instead cost 1.8 us of the kernel)
 constexpr size_t kLookAhead = 1024;
@@ -159,6 +163,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     extern __shared__ __attribute__((aligned(16))) uint8_t mm_lds[];
     static_assert(D % 8 == 0, "windows start on 16-byte pieces");
     constexpr int TB = tile_bytes(D), PPT = pieces_per_tile(D);
+    constexpr int NB = blocks_for(D), kNBW = kSplitBlocks ? NB / 2 : NB, BW = NB / 2;  // blocks: per workgroup, per wave in the loop, per wave in the epilogue
+    constexpr int kChunkOut = chunk_out(NB);
+    static_assert(!kSplitBlocks || NB == 4, "the block-split variant is the D = 8 experiment");
     const int tid = threadIdx.x;
     const int wb = blockIdx.x;
     // (EXP & 64, tools/mfma_fir.hip: s_memtime at the phase boundaries of every workgroup)
@@ -332,7 +339,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         // 16 ((2 j) ^ xh) past the group's base, xh = ((n + g) & 15) ^ h: two instructions per step.
         constexpr int GS = PPT / 2;
         auto load_b = [&](v4i(&b)[kNBW], int base, int xh, int j) {
-            const uint8_t *bp = mm_lds + base + 16 * ((2 * j) ^ xh) + (kSplitBlocks ? wave * 2 * 32 * TB : 0);
+            const uint8_t *bp = mm_lds + base + 16 * ((2 * j) ^ xh) + (kSplitBlocks ? wave * BW * 32 * TB : 0);
 #pragma unroll
             for (int q = 0; q < kNBW; q++) b[q] = *reinterpret_cast<const v4i *>(bp + q * 32 * TB);
         };
@@ -412,10 +419,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         const double *dc = reinterpret_cast<const double *>((const uint8_t *)R.tab[r] + (size_t)4 * G.ne * 32);
         const double dcr = dc[0], dci = dc[1];
         const double scale = __hiloint2double((1023 - G.shift) << 20, 0);  // 2^-S
-        float2 y[2][8];  // [own block][4 q4 + ... ]: outputs 4 q4 + 2 h + e of tile 32 (2 wave + j) + n
+        float2 y[BW][8];  // [own block][4 q4 + ... ]: outputs 4 q4 + 2 h + e of tile 32 (2 wave + j) + n
         if constexpr (kSplitBlocks) {
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+            for (int j = 0; j < BW; j++)
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++)
 #pragma unroll
@@ -432,24 +439,24 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                         y[j][2 * q4 + e] = make_float2(c2[0], c2[1]);
                     }
         } else {
-            double *xhi = reinterpret_cast<double *>(mm_lds);              // [2][16][64]
-            float *xlo = reinterpret_cast<float *>(mm_lds + 2 * 16 * 64 * 8);  // [2][16][64]
+            double *xhi = reinterpret_cast<double *>(mm_lds);              // [BW][16][64]
+            float *xlo = reinterpret_cast<float *>(mm_lds + BW * 16 * 64 * 8);  // [BW][16][64]
             if (wave == 0) {
 #pragma unroll
-                for (int j = 0; j < 2; j++)
+                for (int j = 0; j < BW; j++)
 #pragma unroll
                     for (int q = 0; q < 16; q++)
-                        xhi[(j * 16 + q) * 64 + l] = __fma_rn((double)acc[0][(2 + j) % kNBW][q], 256.0, (double)acc[1][(2 + j) % kNBW][q]);
+                        xhi[(j * 16 + q) * 64 + l] = __fma_rn((double)acc[0][(BW + j) % kNBW][q], 256.0, (double)acc[1][(BW + j) % kNBW][q]);
             } else {
 #pragma unroll
-                for (int j = 0; j < 2; j++)
+                for (int j = 0; j < BW; j++)
 #pragma unroll
                     for (int q = 0; q < 16; q++)
                         xlo[(j * 16 + q) * 64 + l] = __fmaf_rn((float)acc[0][j][q], 256.0f, (float)acc[1][j][q]);
             }
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+            for (int j = 0; j < BW; j++)
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++)
 #pragma unroll
@@ -464,7 +471,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                                 lo = (double)xlo[(j * 16 + q) * 64 + l];
                             } else {
                                 hi = xhi[(j * 16 + q) * 64 + l];
-                                lo = (double)__fmaf_rn((float)acc[0][(2 + j) % kNBW][q], 256.0f, (float)acc[1][(2 + j) % kNBW][q]);
+                                lo = (double)__fmaf_rn((float)acc[0][(BW + j) % kNBW][q], 256.0f, (float)acc[1][(BW + j) % kNBW][q]);
                             }
                             const double v = __fma_rn(hi, 65536.0, lo) + (pt ? dci : dcr);
                             c2[pt] = (float)(v * scale);
@@ -475,18 +482,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         // The elementwise program over this lane's 16 outputs m = mb + 512 j + 4 q4 + e: equally spaced
         // in three directions inside one exactly-linear clock run, so a Shift stage is
         // z0 * wB^j * wA^q4 * wE^e (see ew_apply_seq for the error argument).
-        const uint32_t mb = m_start + (uint32_t)(32 * 2 * wave + n) * kT + 2 * h;
+        const uint32_t mb = m_start + (uint32_t)(32 * BW * wave + n) * kT + 2 * h;
 #pragma unroll 1
         for (int oi = 0; oi < ((EXP & 4) ? 0 : P.n); oi++) {  // uniform
             const EwOp &o = P.op[oi];
             if (o.kind == EW_SCALE) {
 #pragma unroll
-                for (int j = 0; j < 2; j++)
+                for (int j = 0; j < BW; j++)
 #pragma unroll
                     for (int q = 0; q < 8; q++) y[j][q] = make_float2(__fmul_rn(y[j][q].x, o.a), __fmul_rn(y[j][q].y, o.a));
             } else if (o.kind == EW_ROTATE) {
 #pragma unroll
-                for (int j = 0; j < 2; j++)
+                for (int j = 0; j < BW; j++)
 #pragma unroll
                     for (int q = 0; q < 8; q++) y[j][q] = go_cmul(y[j][q], make_float2(o.a, o.b));
             } else {
@@ -511,7 +518,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                     return make_float2(__fmaf_rn(a.x, cr, -(a.y * ci)), __fmaf_rn(a.x, ci, a.y * cr));
                 };
 #pragma unroll
-                for (int j = 0; j < 2; j++) {
+                for (int j = 0; j < BW; j++) {
                     double zc = z0c, zs = z0s;
 #pragma unroll
                     for (int q4 = 0; q4 < 4; q4++) {
@@ -534,9 +541,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         // (direct 8-byte stores cost 10 us of the kernel's 46).
         __syncthreads();  // the exchange buffers have been read
         {
-            float4 *yl = reinterpret_cast<float4 *>(mm_lds) + wave * (2 * 32 * 8);  // [2 blocks][32 tiles][8 pieces]
+            float4 *yl = reinterpret_cast<float4 *>(mm_lds) + wave * (BW * 32 * 8);  // [BW blocks][32 tiles][8 pieces]
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+            for (int j = 0; j < BW; j++)
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++)
                     yl[(j * 32 + n) * 8 + ((2 * q4 + h) ^ (n & 7))] =
@@ -544,10 +551,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int it = 0; it < 8; it++) {
+            for (int it = 0; it < 4 * BW; it++) {
                 const int idx = it * 64 + l, tile = idx >> 3, piece = idx & 7;  // tile = 32 j + n
                 const float4 v = yl[tile * 8 + (piece ^ (tile & 7))];
-                const uint32_t rel = (uint32_t)(64 * wave + tile) * kT + 2 * piece;
+                const uint32_t rel = (uint32_t)(32 * BW * wave + tile) * kT + 2 * piece;
                 const uint32_t mo = m_start + rel;  // (even: v_lo and v_hi are even except the call's last output)
             const bool st = (EXP & 8) == 0 && mo >= v_lo;
             if (st && mo + 1 < v_hi) *reinterpret_cast<float4 *>(out + mo) = v;

@@ -360,7 +360,7 @@ int hzsdr_chain_mix_in_order(hzsdr_chain *c, int in_order);
  *   HZSDR_FIR_PATH_NONE       no run yet / no FIR-decimate terminal
  *   HZSDR_FIR_PATH_TRANSFORM  overlap-save transforms (any source format, any factor)
  *   HZSDR_FIR_PATH_MATRIX     int8 matrix form (csrc/hz_firmm.h): u8 / i8 sources, factor 8 or 16,
- *                             16..1536 taps (factor 16: ..1024), default mixer order, 16-byte aligned device buffers,
+ *                             16..1536 taps (factor 16: ..2560), default mixer order, 16-byte aligned device buffers,
  *                             at least 4096 outputs per call.  Environment HZ_FIR_FFT=1 (read when
  *                             the terminal is created) keeps a chain on the transforms. */
 #define HZSDR_FIR_PATH_NONE 0

@@ -83,6 +83,7 @@ CASES = {
     "i8_d8_1024": dict(fmt="i8", rate=20_000_000, ops=[("shift", 4e6)], ntaps=1024, D=8, n=1 << 20),
     "i8_d16_300": dict(fmt="i8", rate=8_000_000, ops=[("shift", -1e6), ("gain", 0.25)], ntaps=300, D=16, n=1 << 19),
     "u8_d8_1536": dict(fmt="u8", rate=20_000_000, ops=[("shift", 2e6)], ntaps=1536, D=8, n=1 << 19),
+    "u8_d16_2047": dict(fmt="u8", rate=20_000_000, ops=[("shift", -3e6)], ntaps=2047, D=16, n=1 << 20),
     "u8_d8_17": dict(fmt="u8", rate=20_000_000, ops=[("shift", 2e6)], ntaps=17, D=8, n=1 << 18),
 }
 
@@ -226,7 +227,7 @@ def fuzz_case(seed):
     r = np.random.default_rng(7000 + seed)
     fmt = ["u8", "i8"][seed % 2]
     D = [8, 16][(seed // 2) % 2]
-    ntaps = int(r.choice([16, 17, 63, 64, 65, 128, 255, 500, 777, 1024] + ([1025, 1400, 1536] if D == 8 else [1000])))
+    ntaps = int(r.choice([16, 17, 63, 64, 65, 128, 255, 500, 777, 1024] + ([1025, 1400, 1536] if D == 8 else [1000, 1800, 2560])))
     rate = int(r.choice([250_000, 2_400_000, 20_000_000]))
     ops = []
     for _ in range(int(r.integers(0, 4))):

@@ -49,7 +49,7 @@ template <int EXP> static void run(void *const *in, float2 *out, const float2 *t
     R.cont = fix ? 0 : 1;
     R.m_lo[0] = fix ? (lo + mm::kT - 1) / mm::kT * mm::kT : 0;
     R.m_hi[0] = n_out;
-    R.n_wg = (int)((n_out + mm::kChunkOut - 1) / mm::kChunkOut);
+    R.n_wg = (int)((n_out + mm::chunk_out(mm::blocks_for(D)) - 1) / mm::chunk_out(mm::blocks_for(D)));
     if (fix) {
         F.n = 1;
         F.m_a[0] = 0;
