@@ -320,7 +320,8 @@ int hzsdr_convert_foreign(hzsdr_ctx *ctx, int dst_format, void *dst, size_t dst_
  * (stream/read_transformer.go:92-116 Proc is the per-buffer hook it plugs in
  * at).  Stages are pushed in data-flow order; elementwise stages (convert to
  * c64, shift, gain, rotate) and at most one terminal stage fuse into a single
- * kernel launch per hzsdr_chain_run (two for the FIR-decimate terminal: the
+ * kernel launch per hzsdr_chain_run (the FIR-decimate terminal: one for u8 / i8 sources at
+ * factor 8 / 16 -- the int8 matrix form, hzsdr_chain_last_fir_path -- otherwise two, the
  * overlap-save analysis and the small inverse transforms; no full-rate complex64
  * intermediate is ever written). */
 int hzsdr_chain_create(hzsdr_ctx *ctx, int src_format, uint64_t sample_rate, hzsdr_chain **out);
@@ -340,8 +341,9 @@ int hzsdr_chain_downsample(hzsdr_chain *c, unsigned factor);
 int hzsdr_chain_convolution(hzsdr_chain *c, const void *filter_freq, size_t filter_len,
                             unsigned decimate_factor);
 /* Terminal: the north-star FIR-decimate (BASELINE.json north_star; not a
- * reference function): y[m] = sum_k taps[k] * x[factor*m - k] by overlap-save,
- * history carried across runs.  taps: n_taps complex64 in HOST memory. */
+ * reference function): y[m] = sum_k taps[k] * x[factor*m - k], history carried across
+ * runs; at most 8191 taps (minus the rounding of taps - 1 up to the factor).  taps: n_taps
+ * complex64 in HOST memory. */
 int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps_c64, size_t n_taps,
                              unsigned factor);
 /* Where the elementwise stages run relative to the FIR-decimate terminal.
