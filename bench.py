@@ -316,6 +316,24 @@ def main():
         _, ms = timed(torch, lambda: ch.run(x, y), k, w)
         extra["chain_transform_kernels"] = rate(n, float(np.median(ms)), 2 + 8 / D)
         ch.close()
+        # the two implementations of the terminal over tap counts and factors (ms per 2^24 samples)
+        paths = {}
+        for dd, nt in ((8, 64), (8, 256), (8, 1024), (16, 256), (16, 1024), (16, 2047)):
+            tt = lowpass_taps(nt, 0.5 / dd)
+            yy = y[:n // dd]
+            row = {}
+            for name, env in (("matrix", None), ("transform", "1")):
+                if env:
+                    os.environ["HZ_FIR_FFT"] = env
+                ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(tt, dd)
+                os.environ.pop("HZ_FIR_FFT", None)
+                ch.set_time(1.0)
+                _, ms = timed(torch, lambda: ch.run(x, yy), 12, 2)
+                row[name + "_ms"] = round(float(np.median(ms)), 4)
+                row[name + "_path"] = ch.last_fir_path()
+                ch.close()
+            paths[f"D{dd}_taps{nt}"] = row
+        extra["fir_decimate_paths_u8"] = paths
         # the same chain with the mixer forced in front of the filter on every block
         ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D).mix_in_order(True)
         _, ms = timed(torch, lambda: ch.run(x, y), k, w)
@@ -358,7 +376,7 @@ def main():
         extra["beamform4_c64_1gpu"] = rate(n, float(np.median(ms)), 40)
         del chans, c, out
         for name, row in extra.items():
-            if name != "device_copy_c64":
+            if name != "device_copy_c64" and "GBps" in row:
                 row["frac_of_device_copy"] = round(row["GBps"] / copy_gbps, 4)
         extra["small_buffers"] = small_buffers_gpu(hz, ctx, torch, local_rank)
         result["extra"] = extra
