@@ -150,7 +150,8 @@ __device__ __forceinline__ NcoWin task_window(const EwProgram &P, int64_t p_lo, 
 
 // EXP: ablation switches for tools/mfma_fir.hip (0 in the library): 1 = no input loads, 2 = no
 // matrix loop, 4 = no elementwise program, 8 = no stores (results are wrong with any of these set);
-// 64 = s_memtime stamps at the phase boundaries of every workgroup, 128 = plain instead of
+// 64 = s_memtime stamps at the phase boundaries of every workgroup (+ 256: s_memrealtime, 10 ns
+// ticks: wall time instead of cycles), 128 = plain instead of
 // non-temporal input loads (input phase 16.8 k -> 18.0 k cycles).
 // (Switching the loop's operand loads off does not time the MFMAs alone: with undefined operands the
 // compiler deletes the loop.  tools/mfma_rate.hip has the loop's MFMA pattern with and without loads.)
@@ -171,7 +172,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     // (EXP & 64, tools/mfma_fir.hip: s_memtime at the phase boundaries of every workgroup)
     auto stamp = [&](int k) {
         if constexpr ((EXP & 64) != 0) {
-            if (tid == 0) stamps[(size_t)wb * 8 + k] = __builtin_amdgcn_s_memtime();
+            if (tid == 0)
+                stamps[(size_t)wb * 8 + k] = (EXP & 256) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime();
         }
     };
     stamp(0);

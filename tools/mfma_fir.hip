@@ -123,5 +123,6 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&g_stamps, 8 * 8 * 4096));
     run<64>(in, out, taps, tab, n, ntaps, true);
     run<64 + 128>(in, out, taps, tab, n, ntaps, true);
+    run<64 + 256>(in, out, taps, tab, n, ntaps, true);  // the same phases in 10 ns ticks
     return 0;
 }
