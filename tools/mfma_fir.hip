@@ -92,6 +92,17 @@ template <int EXP> static void run(void *const *in, float2 *out, const float2 *t
             printf("    %-22s min %7.0f  p10 %7.0f  median %7.0f  p90 %7.0f  max %7.0f ticks\n", names[k], v[0], v[v.size() / 10],
                    v[v.size() / 2], v[v.size() * 9 / 10], v.back());
         }
+        if (EXP & 256) {  // s_memrealtime is one clock for the chip: when the workgroups start and end
+            unsigned long long t0 = ~0ull;
+            for (unsigned b = 0; b < grid; b++) t0 = st[b * 8] < t0 ? st[b * 8] : t0;
+            for (int k = 0; k < 6; k += 5) {
+                std::vector<double> v;
+                for (unsigned b = 0; b < grid; b++) v.push_back((double)(st[b * 8 + k] - t0));
+                std::sort(v.begin(), v.end());
+                printf("    %-22s min %7.0f  p10 %7.0f  median %7.0f  p90 %7.0f  max %7.0f ticks after the first start\n",
+                       k ? "workgroup end" : "workgroup start", v[0], v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+            }
+        }
     }
 }
 
