@@ -318,7 +318,7 @@ def main():
         ch.close()
         # the two implementations of the terminal over tap counts and factors (ms per 2^24 samples)
         paths = {}
-        for dd, nt in ((8, 64), (8, 256), (8, 1024), (16, 256), (16, 1024), (16, 2047)):
+        for dd, nt in ((8, 64), (8, 256), (8, 1024), (16, 256), (16, 1024), (16, 2047), (32, 1024), (64, 1024)):
             tt = lowpass_taps(nt, 0.5 / dd)
             yy = y[:n // dd]
             row = {}

@@ -372,13 +372,14 @@ static double mm_scale(const hzsdr_chain *c) { return c->src_fmt == HZSDR_FMT_U8
 // (proportional to the taps) passes the transforms' (tools/firmm_probe.py, 2^24 samples, us per
 // call, matrix / transform: D = 8: 64 taps 33 / 152, 256: 35 / 73, 512: 41 / 50, 1024: 48 / 53,
 // 1536: 70 / 70, 2048: 87 / 73; D = 16 (chunks of 1024 outputs): 256: 24 / 70, 512: 28 / 78, 1024: 36 / 48,
-// 1536: 46 / 67, 2047: 54 / 69, 3000: 85 / 82; the transform figures before N_fft started at 256 D).
+// 1536: 46 / 67, 2047: 54 / 69, 3000: 85 / 82; D = 32: 256: 31 / 71, 1024: 41 / 80, 4096: 99 / 151; D = 64: 1024:
+// 39 / 79, 4096: 77 / 152; the D = 8 / 16 transform figures from before N_fft started at 256 D).
 // Environment HZ_FIR_FFT=1 keeps every chain on the transform kernels (A/B measurements, tests).
 static bool mm_eligible(const hzsdr_chain *c) {
     if (getenv("HZ_FIR_FFT")) return false;
     if (c->src_fmt != HZSDR_FMT_U8 && c->src_fmt != HZSDR_FMT_I8) return false;
-    if (c->factor != 8 && c->factor != 16) return false;
-    return c->ntaps >= 16 && c->ntaps <= (c->factor == 8 ? 1536u : 2560u);
+    if (c->factor != 8 && c->factor != 16 && c->factor != 32 && c->factor != 64) return false;
+    return c->ntaps >= 16 && c->ntaps <= (c->factor == 8 ? 1536u : c->factor == 16 ? 2560u : 4096u);
 }
 
 static void mm_geometry(hzsdr_chain *c) {
@@ -498,7 +499,7 @@ static bool mm_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in
     if (!c->mm_ok || c->mix_in_order || P.segs.big_n != 0 || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) return false;
     const uint64_t D = c->factor, n_out = n / D, nt = c->ntaps;
     const uint64_t chunk_out = mm::chunk_out(mm::blocks_for((int)D));  // 2048 outputs at D = 8, 1024 at D = 16
-    if (n_out < 4096 || n_out >= (1ull << 31)) return false;
+    if (n_out < 4096 || n_out >= (1ull << 31)) return false;  // (a call this short is launch-bound either way)
     for (int i = 0; i < P.n; i++)
         if (P.op[i].kind == EW_SHIFT && !(fabs(P.op[i].tau_shift) * 6.2832 < 1073741824.0)) return false;
     const int nr = c->has_shift ? P.segs.n : 1;
@@ -611,8 +612,14 @@ static int mm_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const 
         if (D == 8)
             launch_fv(mm::fir_mm_kernel<FMT, 8>, dim3(grid), dim3(mm::kThreads), lds, ctx->stream, in, (float2 *)out, hist,
                       nhist, rh, nrh, (const float2 *)c->taps_dev, n, g, P, R, F, (unsigned long long *)nullptr);
-        else
+        else if (D == 16)
             launch_fv(mm::fir_mm_kernel<FMT, 16>, dim3(grid), dim3(mm::kThreads), lds, ctx->stream, in, (float2 *)out, hist,
+                      nhist, rh, nrh, (const float2 *)c->taps_dev, n, g, P, R, F, (unsigned long long *)nullptr);
+        else if (D == 32)
+            launch_fv(mm::fir_mm_kernel<FMT, 32>, dim3(grid), dim3(mm::kThreads), lds, ctx->stream, in, (float2 *)out, hist,
+                      nhist, rh, nrh, (const float2 *)c->taps_dev, n, g, P, R, F, (unsigned long long *)nullptr);
+        else
+            launch_fv(mm::fir_mm_kernel<FMT, 64>, dim3(grid), dim3(mm::kThreads), lds, ctx->stream, in, (float2 *)out, hist,
                       nhist, rh, nrh, (const float2 *)c->taps_dev, n, g, P, R, F, (unsigned long long *)nullptr);
         return HZSDR_OK;
     }

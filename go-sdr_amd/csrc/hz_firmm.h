@@ -1,6 +1,6 @@
 // hz_firmm.h -- the FIR-decimate terminal of a chain over RAW 8-bit IQ as an int8 MFMA product.
 //
-// For a u8 / i8 source and a decimation D that is a multiple of 8 the filter runs in the time
+// For a u8 / i8 source and a decimation D of 8, 16, 32 or 64 the filter runs in the time
 // domain on the matrix cores instead of through overlap-save transforms (hz_chain_dev.h):
 //
 //   * the late mixer (see fir_decimate_kernel16) already filters the CONVERTED samples with the
@@ -53,8 +53,9 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr int kT = 16;                        // outputs per tile
 // NB 32-tile column blocks per workgroup: 4 at D = 8 (2048 outputs, 34 KB of input: four workgroups per
 // CU), 2 at D = 16 (1024 outputs, the same 34 KB: with 4 a chunk was 67 KB, two workgroups per CU --
-// one wave per SIMD -- and the matrix form no faster than the transforms at 1024 taps)
-constexpr int blocks_for(int D) { return D >= 16 ? 2 : 4; }
+// one wave per SIMD -- and the matrix form no faster than the transforms at 1024 taps), 1 at D = 32 (512
+// outputs, 34 KB: the table loads are no longer shared between blocks, but the matrix work is a quarter)
+constexpr int blocks_for(int D) { return D >= 32 ? 1 : D >= 16 ? 2 : 4; }
 constexpr int chunk_tiles(int nb) { return 32 * nb; }
 constexpr int chunk_out(int nb) { return chunk_tiles(nb) * kT; }
 constexpr int kThreads = 128;                 // two waves
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     extern __shared__ __attribute__((aligned(16))) uint8_t mm_lds[];
     static_assert(D % 8 == 0, "windows start on 16-byte pieces");
     constexpr int TB = tile_bytes(D), PPT = pieces_per_tile(D);
-    constexpr int NB = blocks_for(D), kNBW = kSplitBlocks ? NB / 2 : NB, BW = NB / 2;  // blocks: per workgroup, per wave in the loop, per wave in the epilogue
+    constexpr int NB = blocks_for(D), kNBW = kSplitBlocks ? NB / 2 : NB, BW = NB >= 2 ? NB / 2 : 1;  // blocks: per workgroup, per wave in the loop, per wave in the epilogue
     constexpr int kChunkOut = chunk_out(NB);
     static_assert(!kSplitBlocks || NB == 4, "the block-split variant is the D = 8 experiment");
     const int tid = threadIdx.x;
@@ -383,17 +384,24 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                     mma(a[j & 3], b[j & 3]);
                     load_a(a[j & 3], j + 4);
                     __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // the address of the step's reads
+                    if constexpr (kND * kNBW >= kNBW + kND) {
 #pragma unroll
-                    for (int q = 0; q < kNBW; q++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // LDS read
-                    }
+                        for (int q = 0; q < kNBW; q++) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // LDS read
+                        }
 #pragma unroll
-                    for (int q = 0; q < kND; q++) {
+                        for (int q = 0; q < kND; q++) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // table load
+                        }
+                        __builtin_amdgcn_sched_group_barrier(0x008, kND * kNBW - kNBW - kND, 0);
+                    } else {  // one column block: two MFMAs, one LDS read, two table loads per step
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // table load
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, kND * kNBW - kNBW - kND, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 t = tn;
@@ -484,9 +492,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         // The elementwise program over this lane's 16 outputs m = mb + 512 j + 4 q4 + e: equally spaced
         // in three directions inside one exactly-linear clock run, so a Shift stage is
         // z0 * wB^j * wA^q4 * wE^e (see ew_apply_seq for the error argument).
+        // (one column block per workgroup: wave 0 finishes it, wave 1 only hands its planes over)
+        const bool fin = NB >= 2 || wave == 0;
         const uint32_t mb = m_start + (uint32_t)(32 * BW * wave + n) * kT + 2 * h;
 #pragma unroll 1
-        for (int oi = 0; oi < ((EXP & 4) ? 0 : P.n); oi++) {  // uniform
+        for (int oi = 0; oi < ((EXP & 4) || !fin ? 0 : P.n); oi++) {  // uniform per wave
             const EwOp &o = P.op[oi];
             if (o.kind == EW_SCALE) {
 #pragma unroll
@@ -542,7 +552,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         // through LDS (16-byte pieces swizzled by the tile index) a wave writes whole 1 KiB rows instead
         // (direct 8-byte stores cost 10 us of the kernel's 46).
         __syncthreads();  // the exchange buffers have been read
-        {
+        if (fin) {
             float4 *yl = reinterpret_cast<float4 *>(mm_lds) + wave * (BW * 32 * 8);  // [BW blocks][32 tiles][8 pieces]
 #pragma unroll
             for (int j = 0; j < BW; j++)
@@ -558,8 +568,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                 const float4 v = yl[tile * 8 + (piece ^ (tile & 7))];
                 const uint32_t rel = (uint32_t)(32 * BW * wave + tile) * kT + 2 * piece;
                 const uint32_t mo = m_start + rel;  // (even: v_lo and v_hi are even except the call's last output)
-            const bool st = (EXP & 8) == 0 && mo >= v_lo;
-            if (st && mo + 1 < v_hi) *reinterpret_cast<float4 *>(out + mo) = v;
+                const bool st = (EXP & 8) == 0 && mo >= v_lo;
+                if (st && mo + 1 < v_hi) *reinterpret_cast<float4 *>(out + mo) = v;
                 else if (st && mo < v_hi) out[mo] = make_float2(v.x, v.y);
             }
         }

@@ -84,6 +84,10 @@ CASES = {
     "i8_d16_300": dict(fmt="i8", rate=8_000_000, ops=[("shift", -1e6), ("gain", 0.25)], ntaps=300, D=16, n=1 << 19),
     "u8_d8_1536": dict(fmt="u8", rate=20_000_000, ops=[("shift", 2e6)], ntaps=1536, D=8, n=1 << 19),
     "u8_d16_2047": dict(fmt="u8", rate=20_000_000, ops=[("shift", -3e6)], ntaps=2047, D=16, n=1 << 20),
+    "u8_d32_1024": dict(fmt="u8", rate=20_000_000, ops=[("shift", -2.5e6)], ntaps=1024, D=32, n=1 << 20),
+    "i8_d32_200_program": dict(fmt="i8", rate=2_400_000, ops=[("gain", 0.7), ("shift", 3e5), ("rotate", 0.8 + 0.6j)], ntaps=200,
+                               D=32, n=1 << 20),
+    "u8_d64_1000": dict(fmt="u8", rate=20_000_000, ops=[("shift", 1.5e6)], ntaps=1000, D=64, n=1 << 21),
     "u8_d8_17": dict(fmt="u8", rate=20_000_000, ops=[("shift", 2e6)], ntaps=17, D=8, n=1 << 18),
 }
 
@@ -95,8 +99,8 @@ def test_matrix_form_against_the_oracle(hz, ctx, orc, name):
     x = rand_u8(31, n) if c["fmt"] == "u8" else rand_i8(31, n)
     fmt = hz.FMT_U8 if c["fmt"] == "u8" else hz.FMT_I8
     # three ragged calls: the second starts inside the clock run the first ended in (raw history),
-    # all cuts on the decimation grid
-    cuts = [0, n // 4 + 16 * 77, n - 16 * 8192, n]
+    # all cuts on the decimation grid (multiples of 64)
+    cuts = [0, n // 4 + 64 * 77, n - n // 4, n]
     # (the clock starts at 1 s: from 0 it runs through twenty short binades first, and a call that is
     # mostly clock boundaries stays on the transform kernels -- test_clock_boundaries_and_wrap)
     want, xmax = oracle(orc, x, c["rate"], c["ops"], taps, D, ts0=1.0)
@@ -226,8 +230,8 @@ def test_misaligned_device_buffers_take_the_transforms(hz, orc):
 def fuzz_case(seed):
     r = np.random.default_rng(7000 + seed)
     fmt = ["u8", "i8"][seed % 2]
-    D = [8, 16][(seed // 2) % 2]
-    ntaps = int(r.choice([16, 17, 63, 64, 65, 128, 255, 500, 777, 1024] + ([1025, 1400, 1536] if D == 8 else [1000, 1800, 2560])))
+    D = [8, 16, 32, 64][(seed // 2) % 4]
+    ntaps = int(r.choice([16, 17, 63, 64, 65, 128, 255, 500, 777, 1024] + ([1025, 1400, 1536] if D == 8 else [1000, 1800, 2560] if D == 16 else [1500, 3000, 4096])))
     rate = int(r.choice([250_000, 2_400_000, 20_000_000]))
     ops = []
     for _ in range(int(r.integers(0, 4))):
@@ -239,7 +243,7 @@ def fuzz_case(seed):
         else:
             ops.append(("rotate", complex(np.complex64(np.exp(1j * r.uniform(0, TAU))))))
     # ragged calls on the decimation grid, some too short for the matrix form
-    lens = [int(r.integers(3000, 60000)) * D for _ in range(int(r.integers(2, 5)))]
+    lens = [int(r.integers(3000, 60000 if D < 32 else 60000 * 16 // D)) * D for _ in range(int(r.integers(2, 5)))]
     if seed % 3 == 0:
         lens.insert(1, int(r.integers(10, 3000)) * D)
     # clock starts: inside a long binade, just under a binade edge, just under the 2*pi wrap
