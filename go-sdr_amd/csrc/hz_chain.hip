@@ -378,8 +378,8 @@ static double mm_scale(const hzsdr_chain *c) { return c->src_fmt == HZSDR_FMT_U8
 static bool mm_eligible(const hzsdr_chain *c) {
     if (getenv("HZ_FIR_FFT")) return false;
     if (c->src_fmt != HZSDR_FMT_U8 && c->src_fmt != HZSDR_FMT_I8) return false;
-    if (c->factor != 8 && c->factor != 16 && c->factor != 32 && c->factor != 64) return false;
-    return c->ntaps >= 16 && c->ntaps <= (c->factor == 8 ? 1536u : c->factor == 16 ? 2560u : 4096u);
+    if (!mm::factor_ok(c->factor)) return false;
+    return c->ntaps >= 16 && c->ntaps <= (c->factor == 8 ? 1536u : c->factor <= 24 ? 2560u : 4096u);
 }
 
 static void mm_geometry(hzsdr_chain *c) {
@@ -596,34 +596,11 @@ static bool mm_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in
     return fix_total <= 16384 && fix_total * 8 <= n_out;
 }
 
-template <int FMT>
 static int mm_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const EwProgram &P, const mm::Runs &R,
                      const mm::Fix &F) {
-    hzsdr_ctx *ctx = c->ctx;
-    const float2 *hist = (const float2 *)c->hist[c->hist_cur];
-    float2 *nhist = (float2 *)c->hist[c->hist_cur ^ 1];
-    const uint8_t *rh = (const uint8_t *)c->rhist[c->hist_cur];
-    uint8_t *nrh = (uint8_t *)c->rhist[c->hist_cur ^ 1];
-    const mm::Geom &g = c->mmg;
-    const int D = (int)c->factor;
-    const size_t lds = std::max(mm::chunk_bytes(D, g.ks) + mm::kLookAhead, (size_t)(2 * g.ntaps + D * (mm::kFixOut - 1)) * 8);
-    const unsigned grid = (unsigned)R.n_wg;  // (the fix-up and history tasks ride on the chunk workgroups)
-    if constexpr (FMT == HZSDR_FMT_U8 || FMT == HZSDR_FMT_I8) {
-        if (D == 8)
-            launch_fv(mm::fir_mm_kernel<FMT, 8>, dim3(grid), dim3(mm::kThreads), lds, ctx->stream, in, (float2 *)out, hist,
-                      nhist, rh, nrh, (const float2 *)c->taps_dev, n, g, P, R, F, (unsigned long long *)nullptr);
-        else if (D == 16)
-            launch_fv(mm::fir_mm_kernel<FMT, 16>, dim3(grid), dim3(mm::kThreads), lds, ctx->stream, in, (float2 *)out, hist,
-                      nhist, rh, nrh, (const float2 *)c->taps_dev, n, g, P, R, F, (unsigned long long *)nullptr);
-        else if (D == 32)
-            launch_fv(mm::fir_mm_kernel<FMT, 32>, dim3(grid), dim3(mm::kThreads), lds, ctx->stream, in, (float2 *)out, hist,
-                      nhist, rh, nrh, (const float2 *)c->taps_dev, n, g, P, R, F, (unsigned long long *)nullptr);
-        else
-            launch_fv(mm::fir_mm_kernel<FMT, 64>, dim3(grid), dim3(mm::kThreads), lds, ctx->stream, in, (float2 *)out, hist,
-                      nhist, rh, nrh, (const float2 *)c->taps_dev, n, g, P, R, F, (unsigned long long *)nullptr);
-        return HZSDR_OK;
-    }
-    return HZSDR_ERR_INVALID_ARGUMENT;
+    return mm::launch_fir(c->ctx->stream, c->src_fmt, c->factor, in, (float2 *)out, (const float2 *)c->hist[c->hist_cur],
+                          (float2 *)c->hist[c->hist_cur ^ 1], (const uint8_t *)c->rhist[c->hist_cur],
+                          (uint8_t *)c->rhist[c->hist_cur ^ 1], (const float2 *)c->taps_dev, n, c->mmg, P, R, F);
 }
 
 // The modulated filter of every clock run long enough to hold a whole block (lookups only).
@@ -737,7 +714,7 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
             mm::Runs R;
             mm::Fix F;
             if (mm_plan(c, P, n_cons, in, out, &R, &F)) {
-                HZ_TRY(mm_launch<FMT>(c, in, out, n_cons, P, R, F));
+                HZ_TRY(mm_launch(c, in, out, n_cons, P, R, F));
                 c->hist_cur ^= 1;
                 c->last_path = HZSDR_FIR_PATH_MATRIX;
                 // the raw history now ends in this call's last clock run

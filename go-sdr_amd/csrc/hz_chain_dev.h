@@ -982,10 +982,4 @@ __global__ __launch_bounds__((SynthGeom<N, FOLD>::BS)) void fir_synth_kernel16(
     }
 }
 
-__global__ void scale_c64_kernel(float2 *buf, size_t n, float r) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        buf[i] = make_float2(buf[i].x * r, buf[i].y * r);
-}
-
 }  // namespace hz

@@ -1,6 +1,6 @@
 // hz_firmm.h -- the FIR-decimate terminal of a chain over RAW 8-bit IQ as an int8 MFMA product.
 //
-// For a u8 / i8 source and a decimation D of 8, 16, 32 or 64 the filter runs in the time
+// For a u8 / i8 source and a decimation D of 8, 16, 24, 32, 40, 48 or 64 the filter runs in the time
 // domain on the matrix cores instead of through overlap-save transforms (hz_chain_dev.h):
 //
 //   * the late mixer (see fir_decimate_kernel16) already filters the CONVERTED samples with the
@@ -55,7 +55,7 @@ constexpr int kT = 16;                        // outputs per tile
 // CU), 2 at D = 16 (1024 outputs, the same 34 KB: with 4 a chunk was 67 KB, two workgroups per CU --
 // one wave per SIMD -- and the matrix form no faster than the transforms at 1024 taps), 1 at D = 32 (512
 // outputs, 34 KB: the table loads are no longer shared between blocks, but the matrix work is a quarter)
-constexpr int blocks_for(int D) { return D >= 32 ? 1 : D >= 16 ? 2 : 4; }
+constexpr int blocks_for(int D) { return D >= 32 ? 1 : D >= 16 ? 2 : 4; }  // (D = 24: 48 KB, 40 / 48 / 64: 40 / 48 / 64 KB)
 constexpr int chunk_tiles(int nb) { return 32 * nb; }
 constexpr int chunk_out(int nb) { return chunk_tiles(nb) * kT; }
 constexpr int kThreads = 128;                 // two waves
@@ -580,6 +580,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int task = wb; task < n_tasks; task += (int)gridDim.x) small_task(task);  // (uniform)
     }
 }
+
+// hz_firmm.hip: the decimations the kernel is instantiated for, and the launch (u8 / i8)
+bool factor_ok(unsigned D);
+int launch_fir(hipStream_t stream, int fmt, unsigned D, const void *in, float2 *out, const float2 *hist, float2 *new_hist,
+               const uint8_t *rhist, uint8_t *new_rhist, const float2 *taps, size_t n, const Geom &g, const EwProgram &P,
+               const Runs &R, const Fix &F);
 
 }  // namespace mm
 }  // namespace hz

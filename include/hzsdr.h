@@ -361,8 +361,8 @@ int hzsdr_chain_mix_in_order(hzsdr_chain *c, int in_order);
  * logs; the results are held to the same bound either way):
  *   HZSDR_FIR_PATH_NONE       no run yet / no FIR-decimate terminal
  *   HZSDR_FIR_PATH_TRANSFORM  overlap-save transforms (any source format, any factor)
- *   HZSDR_FIR_PATH_MATRIX     int8 matrix form (csrc/hz_firmm.h): u8 / i8 sources, factor 8, 16, 32 or 64,
- *                             16..1536 taps (factor 16: ..2560, 32 / 64: ..4096), default mixer order, 16-byte aligned device buffers,
+ *   HZSDR_FIR_PATH_MATRIX     int8 matrix form (csrc/hz_firmm.h): u8 / i8 sources, factor 8, 16, 24, 32,
+ *                             40, 48 or 64, 16..1536 taps (factor 16 / 24: ..2560, larger: ..4096), default mixer order, 16-byte aligned device buffers,
  *                             at least 4096 outputs per call.  Environment HZ_FIR_FFT=1 (read when
  *                             the terminal is created) keeps a chain on the transforms. */
 #define HZSDR_FIR_PATH_NONE 0

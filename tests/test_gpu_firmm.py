@@ -88,6 +88,9 @@ CASES = {
     "i8_d32_200_program": dict(fmt="i8", rate=2_400_000, ops=[("gain", 0.7), ("shift", 3e5), ("rotate", 0.8 + 0.6j)], ntaps=200,
                                D=32, n=1 << 20),
     "u8_d64_1000": dict(fmt="u8", rate=20_000_000, ops=[("shift", 1.5e6)], ntaps=1000, D=64, n=1 << 21),
+    "i8_d24_500": dict(fmt="i8", rate=2_400_000, ops=[("shift", -4e5)], ntaps=500, D=24, n=3 << 18),
+    "u8_d40_1024": dict(fmt="u8", rate=20_000_000, ops=[("shift", 2.5e6)], ntaps=1024, D=40, n=5 << 18),
+    "u8_d48_300": dict(fmt="u8", rate=20_000_000, ops=[("shift", 1e6), ("gain", 0.5)], ntaps=300, D=48, n=3 << 19),
     "u8_d8_17": dict(fmt="u8", rate=20_000_000, ops=[("shift", 2e6)], ntaps=17, D=8, n=1 << 18),
 }
 
@@ -99,8 +102,9 @@ def test_matrix_form_against_the_oracle(hz, ctx, orc, name):
     x = rand_u8(31, n) if c["fmt"] == "u8" else rand_i8(31, n)
     fmt = hz.FMT_U8 if c["fmt"] == "u8" else hz.FMT_I8
     # three ragged calls: the second starts inside the clock run the first ended in (raw history),
-    # all cuts on the decimation grid (multiples of 64)
-    cuts = [0, n // 4 + 64 * 77, n - n // 4, n]
+    # all cuts on the decimation grid 
+    g = 64 * D  # cuts on the decimation grid of every factor
+    cuts = [0, (n // 4) // g * g + 2 * g, (n - n // 4) // g * g, n]
     # (the clock starts at 1 s: from 0 it runs through twenty short binades first, and a call that is
     # mostly clock boundaries stays on the transform kernels -- test_clock_boundaries_and_wrap)
     want, xmax = oracle(orc, x, c["rate"], c["ops"], taps, D, ts0=1.0)
@@ -230,8 +234,8 @@ def test_misaligned_device_buffers_take_the_transforms(hz, orc):
 def fuzz_case(seed):
     r = np.random.default_rng(7000 + seed)
     fmt = ["u8", "i8"][seed % 2]
-    D = [8, 16, 32, 64][(seed // 2) % 4]
-    ntaps = int(r.choice([16, 17, 63, 64, 65, 128, 255, 500, 777, 1024] + ([1025, 1400, 1536] if D == 8 else [1000, 1800, 2560] if D == 16 else [1500, 3000, 4096])))
+    D = [8, 16, 32, 64, 24, 40, 48][(seed // 2) % 7]
+    ntaps = int(r.choice([16, 17, 63, 64, 65, 128, 255, 500, 777, 1024] + ([1025, 1400, 1536] if D == 8 else [1000, 1800, 2560] if D <= 24 else [1500, 3000, 4096])))
     rate = int(r.choice([250_000, 2_400_000, 20_000_000]))
     ops = []
     for _ in range(int(r.integers(0, 4))):
