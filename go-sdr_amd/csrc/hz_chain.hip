@@ -21,6 +21,7 @@
 
 #include "hz_chain_dev.h"
 #include "hz_firmm.h"
+#include "hz_firmm2.h"
 #include "hz_fft_api.h"
 
 // =============================================================================
@@ -58,6 +59,7 @@ struct hzsdr_chain {
     // int8 matrix form (hz_firmm.h): geometry, the taps on the device (fix-up workgroups) and
     // one digit table per distinct clock step (key 0: no Shift stage)
     bool mm_ok = false;
+    int mm_ver = 1;  // 1: hz_firmm.h (one round of chunk workgroups), 2: hz_firmm2.h (persistent passes; D = 8)
     hz::mm::Geom mmg{};
     void *taps_dev = nullptr;
     std::map<uint64_t, void *> mm_cache;
@@ -65,8 +67,9 @@ struct hzsdr_chain {
     // after a call on the matrix path; rh_step / rh_len describe the clock run they end in
     void *rhist[2] = {nullptr, nullptr};
     bool rh_valid = false;
-    double rh_step = 0.0;
+    double rh_step = 0.0, rh_next = 0.0;
     uint64_t rh_len = 0;
+    bool debug_mm = false;  // HZ_DEBUG_MM, read once at creation
     int last_path = HZSDR_FIR_PATH_NONE;
 };
 
@@ -382,16 +385,33 @@ static bool mm_eligible(const hzsdr_chain *c) {
     return c->ntaps >= 16 && c->ntaps <= (c->factor == 8 ? 1536u : c->factor <= 24 ? 2560u : 4096u);
 }
 
+// hz_firmm2.h (the persistent-pass form): D = 8, and a pass image / table that fit its fixed register counts.
+// HZ_MM_V1=1 keeps the first form (A/B measurements).
+static bool mm2_eligible(const hzsdr_chain *c) {
+    if (getenv("HZ_MM_V1") || !mm2::factor_ok(c->factor)) return false;
+    const mm2::Geom g = mm2::make_geom((int)c->ntaps, (int)c->factor, c->off, 0);
+    const int D = (int)c->factor;
+    return mm2::image_bytes(D, g.ks) <= (size_t)mm2::kU * 64 * 16 && mm2::table_bytes(g.ne) <= (size_t)4 * mm2::kThreads * 16 &&
+           mm2::lds_bytes(D, g.ks, g.ne) <= 160 * 1024;
+}
+
 static void mm_geometry(hzsdr_chain *c) {
     mm::Geom &g = c->mmg;
     const int D = (int)c->factor;
+    c->mm_ver = mm2_eligible(c) ? 2 : 1;
+    if (c->mm_ver == 2) {
+        const mm2::Geom g2 = mm2::make_geom((int)c->ntaps, D, c->off, 0);
+        g.ntaps = g2.ntaps, g.w0 = g2.w0, g.ks = g2.ks, g.ne = g2.ne, g.e0 = g2.e0, g.off = g2.off;
+    }
     g.ntaps = (int)c->ntaps;
-    g.w0 = (g.ntaps - 1 + 7) / 8 * 8;
-    const int window = g.w0 + D * (mm::kT - 1) + 1;  // samples a tile's outputs reach back over
-    g.ks = (2 * window + 31) / 32;
-    g.ks = (g.ks + D - 1) / D * D;  // whole groups of PPT / 2 = D steps (hz_firmm.h)
-    g.e0 = 2 * (g.ks + 4);
-    g.ne = g.e0 + (D / 8) * (mm::kT - 1) + 1;
+    if (c->mm_ver == 1) {
+        g.w0 = (g.ntaps - 1 + 7) / 8 * 8;
+        const int window = g.w0 + D * (mm::kT - 1) + 1;  // samples a tile's outputs reach back over
+        g.ks = (2 * window + 31) / 32;
+        g.ks = (g.ks + D - 1) / D * D;  // whole groups of PPT / 2 = D steps (hz_firmm.h)
+        g.e0 = 2 * (g.ks + 4);
+        g.ne = g.e0 + (D / 8) * (mm::kT - 1) + 1;
+    }
     g.off = c->off;
     // q = round(h' 2^S) with |q| <= 2^30: |h'[k]| <= |h[k]| * scale for every modulation
     double hmax = 0.0;
@@ -433,7 +453,11 @@ static int mm_table_for(hzsdr_chain *c, double step, double omega, void **dev, b
         sr += qr[k];
         si += qi[k];
     }
+    // (both forms keep 4 digits x ne x 2 parts x 16 bytes + the constant term; hz_firmm2.h orders them
+    // T[f][E][part][pl] with digit = 2 f + pl: a fragment row holds two digit planes)
+    const bool v2 = c->mm_ver == 2;
     std::vector<uint8_t> tab(mm::table_bytes(g.ne), 0);
+    static_assert(mm::table_bytes(100) == mm2::table_bytes(100), "one size for both layouts");
     for (int E = 0; E < g.ne; E++)
         for (int pout = 0; pout < 2; pout++)
             for (int e = 0; e < 16; e++) {
@@ -443,7 +467,8 @@ static int mm_table_for(hzsdr_chain *c, double step, double omega, void **dev, b
                 int64_t q = pout == 0 ? (pin == 0 ? qr[kap] : -qi[kap]) : (pin == 0 ? qi[kap] : qr[kap]);
                 for (int d = 3; d >= 0; d--) {  // balanced base-256 digits, d = 0 most significant
                     const int64_t r = ((q + 128) & 255) - 128;
-                    tab[(((size_t)d * g.ne + E) * 2 + pout) * 16 + e] = (uint8_t)(int8_t)r;
+                    const size_t at = v2 ? ((((size_t)(d >> 1) * g.ne + E) * 2 + pout) * 2 + (d & 1)) : (((size_t)d * g.ne + E) * 2 + pout);
+                    tab[at * 16 + e] = (uint8_t)(int8_t)r;
                     q = (q - r) >> 8;
                 }
             }
@@ -499,6 +524,7 @@ static bool mm_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in
     if (!c->mm_ok || c->mix_in_order || P.segs.big_n != 0 || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) return false;
     const uint64_t D = c->factor, n_out = n / D, nt = c->ntaps;
     const uint64_t chunk_out = mm::chunk_out(mm::blocks_for((int)D));  // 2048 outputs at D = 8, 1024 at D = 16
+    const uint64_t tile = mm::kT;
     if (n_out < 4096 || n_out >= (1ull << 31)) return false;  // (a call this short is launch-bound either way)
     for (int i = 0; i < P.n; i++)
         if (P.op[i].kind == EW_SHIFT && !(fabs(P.op[i].tau_shift) * 6.2832 < 1073741824.0)) return false;
@@ -508,7 +534,7 @@ static bool mm_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in
     // does run 0 continue the run the previous call ended in (same step, no reset in between)?  Then
     // the clock is exactly linear across the call boundary and the first windows may reach back
     // into the raw history instead of going to the fix-up tasks.
-    R->cont = c->rh_valid && (!c->has_shift || (P.segs.step[0] == c->rh_step && c->rh_len >= nt)) ? 1 : 0;
+    R->cont = c->rh_valid && (!c->has_shift || (P.segs.step[0] == c->rh_step && c->rh_len >= nt && c->rh_next == P.segs.t0[0])) ? 1 : 0;
     // outputs whose whole window lies in run r (and that has a table): [lo, hi), on the tile grid
     bool any = false;
     for (int r = 0; r < nr; r++) {
@@ -517,8 +543,8 @@ static bool mm_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in
         void *dev = nullptr;
         (void)mm_table_for(c, c->has_shift ? P.segs.step[r] : 0.0, 0.0, &dev, false);
         uint64_t lo = (r == 0 && R->cont) ? 0 : (a + nt - 1 + D - 1) / D, hi = std::min((b + D - 1) / D, n_out);
-        lo = (lo + mm::kT - 1) / mm::kT * mm::kT;
-        if (hi < n_out) hi = hi / mm::kT * mm::kT;
+        lo = (lo + tile - 1) / tile * tile;
+        if (hi < n_out) hi = hi / tile * tile;
         R->m_lo[r] = R->m_hi[r] = 0;
         R->tab[r] = dev;
         if (!dev || hi < lo + 64) continue;  // a run without a table, or too short to bother
@@ -584,7 +610,7 @@ static bool mm_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in
     }
     flush_fix();
     R->n_wg = (int)n_chunks;
-    if (getenv("HZ_DEBUG_MM")) {
+    if (c->debug_mm) {
         fprintf(stderr, "hzsdr mm: %d runs, cont %d, %llu chunks, %d fix intervals (%d tasks, %llu outputs)\n", nr, R->cont,
                 (unsigned long long)n_chunks, F->n, F->n_wg, (unsigned long long)fix_total);
         for (int r = 0; r < nr; r++)
@@ -601,6 +627,96 @@ static int mm_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const 
     return mm::launch_fir(c->ctx->stream, c->src_fmt, c->factor, in, (float2 *)out, (const float2 *)c->hist[c->hist_cur],
                           (float2 *)c->hist[c->hist_cur ^ 1], (const uint8_t *)c->rhist[c->hist_cur],
                           (uint8_t *)c->rhist[c->hist_cur ^ 1], (const float2 *)c->taps_dev, n, c->mmg, P, R, F);
+}
+
+// hz_firmm2.h: the plan of one call for the persistent-pass kernel.  Every clock run with a table gets the
+// outputs whose whole window lies in it (tile-aligned) and the passes of the call's 512-output grid that hold
+// them -- a pass that straddles a boundary is multiplied once per run, each time with that run's table and
+// valid range (a second short pass costs one wave 6 us; the fix-up tasks it replaces cost ~10 us EACH).  What
+// no run holds -- windows that cross a boundary, the stream's start, runs without a table -- are fix-up tasks
+// of 8 outputs.  false: the call stays on the transform kernels.
+static bool mm2_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in, const void *out, mm2::Plan *L,
+                     mm2::Fix *F) {
+    memset(L, 0, sizeof *L);
+    memset(F, 0, sizeof *F);
+    if (!c->mm_ok || c->mix_in_order || P.segs.big_n != 0 || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) return false;
+    const uint64_t D = c->factor, n_out = n / D, nt = c->ntaps, tile = mm2::kT, pass = (uint64_t)mm2::pass_out((int)D);
+    if (n_out < 4096 || n_out >= (1ull << 31)) return false;  // (a call this short is launch-bound either way)
+    for (int i = 0; i < P.n; i++)
+        if (P.op[i].kind == EW_SHIFT && !(fabs(P.op[i].tau_shift) * 6.2832 < 1073741824.0)) return false;
+    const int nr = c->has_shift ? P.segs.n : 1;
+    if (nr < 1 || nr > kNcoMaxSegs) return false;
+    L->cont = c->rh_valid && (!c->has_shift || (P.segs.step[0] == c->rh_step && c->rh_len >= nt && c->rh_next == P.segs.t0[0])) ? 1 : 0;
+    L->n_ops = P.n;
+    L->gain = 1.0f;
+    L->shift_op = -1;
+    int n_shift = 0;
+    for (int i = 0; i < P.n; i++)
+        if (P.op[i].kind == EW_SHIFT) {
+            L->shift_op = i;
+            n_shift++;
+        }
+    if (n_shift != 1) L->shift_op = -1;
+    uint64_t fix_total = 0, covered = 0;  // outputs below `covered` are planned
+    bool too_many = false;
+    auto add_fix = [&](uint64_t a, uint64_t b) {
+        if (b <= a) return;
+        fix_total += b - a;
+        if (F->n >= mm2::kMaxFix) {
+            too_many = true;
+            return;
+        }
+        F->m_a[F->n] = (uint32_t)a;
+        F->m_b[F->n] = (uint32_t)b;
+        F->task_first[F->n] = F->n_task;
+        F->n_task += (int)((b - a + mm2::kFixOut - 1) / mm2::kFixOut);
+        F->n++;
+    };
+    for (int r = 0; r < nr; r++) {
+        const uint64_t a = c->has_shift ? P.segs.first[r] : 0;
+        const uint64_t b = (c->has_shift && r + 1 < nr) ? P.segs.first[r + 1] : (uint64_t)n;
+        void *dev = nullptr;
+        (void)mm_table_for(c, c->has_shift ? P.segs.step[r] : 0.0, 0.0, &dev, false);
+        uint64_t lo = (r == 0 && L->cont) ? 0 : (a + nt - 1 + D - 1) / D, hi = std::min((b + D - 1) / D, n_out);
+        lo = (lo + tile - 1) / tile * tile;
+        if (hi < n_out) hi = hi / tile * tile;
+        if (!dev || hi < lo + 64) continue;  // a run without a table, or too short to bother
+        if (L->n >= mm2::kMaxRuns) return false;
+        mm2::Run &u = L->run[L->n];
+        u.tab = dev, u.m_lo = (uint32_t)lo, u.m_hi = (uint32_t)hi;
+        u.pass_first = (int)(lo / pass), u.pass_end = (int)((hi + pass - 1) / pass);
+        if (c->has_shift) u.first = P.segs.first[r], u.t0 = P.segs.t0[r], u.step = P.segs.step[r];
+        if (L->shift_op >= 0) mm2::phase_fix(P.op[L->shift_op].tau_shift, u.t0, u.step, u.first, &u.phi, &u.dphi);
+        L->pass_first[L->n] = u.pass_first, L->pass_end[L->n] = u.pass_end;
+        L->n++;
+        add_fix(covered, lo);
+        covered = hi;
+    }
+    if (L->n == 0) return false;
+    add_fix(covered, n_out);
+    L->n_pass = (int)((n_out + pass - 1) / pass);
+    L->n_task = F->n_task;
+    if (c->debug_mm) {
+        fprintf(stderr, "hzsdr mm2: %d of %d runs on the matrix path, cont %d, %d passes, %d fix intervals (%d tasks, %llu outputs)\n", L->n, nr,
+                L->cont, L->n_pass, F->n, F->n_task, (unsigned long long)fix_total);
+        for (int r = 0; r < L->n; r++)
+            fprintf(stderr, "   run first %llu valid [%u, %u) passes [%d, %d) table %p\n", (unsigned long long)L->run[r].first, L->run[r].m_lo,
+                    L->run[r].m_hi, L->run[r].pass_first, L->run[r].pass_end, L->run[r].tab);
+        for (int k = 0; k < F->n; k++) fprintf(stderr, "   fix [%u, %u) first task %d\n", F->m_a[k], F->m_b[k], F->task_first[k]);
+    }
+    // the fix-up tasks are the slow way: a call that is mostly boundaries keeps the transforms
+    return !too_many && fix_total <= 16384 && fix_total * 8 <= n_out;
+}
+
+static int mm2_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const EwProgram &P, const mm2::Plan &L,
+                      const mm2::Fix &F) {
+    mm2::Geom g2{};
+    g2.ntaps = c->mmg.ntaps, g2.w0 = c->mmg.w0, g2.ks = c->mmg.ks, g2.ne = c->mmg.ne, g2.e0 = c->mmg.e0, g2.shift = c->mmg.shift,
+    g2.off = c->mmg.off;
+    return mm2::launch_fir(c->ctx->stream, c->ctx->num_cus, c->src_fmt, c->factor, in, (float2 *)out,
+                           (const float2 *)c->hist[c->hist_cur], (float2 *)c->hist[c->hist_cur ^ 1],
+                           (const uint8_t *)c->rhist[c->hist_cur], (uint8_t *)c->rhist[c->hist_cur ^ 1],
+                           (const float2 *)c->taps_dev, n, g2, L, P, F);
 }
 
 // The modulated filter of every clock run long enough to hold a whole block (lookups only).
@@ -710,11 +826,25 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
         float2 *nhist = (float2 *)c->hist[c->hist_cur ^ 1];
         const unsigned D = c->factor;
         if (c->mm_ok) {
-            // byte source, D = 8 / 16: the int8 matrix form (hz_firmm.h), one launch
+            // byte source, D = 8, 16, ...: the int8 matrix form (hz_firmm2.h / hz_firmm.h), one launch
             mm::Runs R;
             mm::Fix F;
-            if (mm_plan(c, P, n_cons, in, out, &R, &F)) {
+            mm2::Plan L2;
+            mm2::Fix F2;
+            bool ran = false;
+            int cont = 0;
+            if (c->mm_ver == 2) {
+                if (mm2_plan(c, P, n_cons, in, out, &L2, &F2)) {
+                    HZ_TRY(mm2_launch(c, in, out, n_cons, P, L2, F2));
+                    ran = true;
+                    cont = L2.cont;
+                }
+            } else if (mm_plan(c, P, n_cons, in, out, &R, &F)) {
                 HZ_TRY(mm_launch(c, in, out, n_cons, P, R, F));
+                ran = true;
+                cont = R.cont;
+            }
+            if (ran) {
                 c->hist_cur ^= 1;
                 c->last_path = HZSDR_FIR_PATH_MATRIX;
                 // the raw history now ends in this call's last clock run
@@ -723,8 +853,12 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
                 if (c->has_shift) {
                     const int last = P.segs.n - 1;
                     const uint64_t len = n_cons - P.segs.first[last];
-                    c->rh_len = (last == 0 && R.cont) ? c->rh_len + len : len;
+                    c->rh_len = (last == 0 && cont) ? c->rh_len + len : len;
                     c->rh_step = P.segs.step[last];
+                    // the clock the run assigns to the NEXT sample: a call that continues the run starts there
+                    // (equal steps alone do not say so: with a sample rate whose 1/fs is a power of two every
+                    // binade has the same step, and a 2*pi wrap on a call boundary would pass unnoticed)
+                    c->rh_next = fma((double)len, P.segs.step[last], P.segs.t0[last]);
                 }
                 break;
             }
@@ -868,6 +1002,7 @@ int hzsdr_chain_create(hzsdr_ctx *ctx, int src_format, uint64_t sample_rate, hzs
     c->ctx = ctx;
     c->src_fmt = src_format;
     c->sample_rate = sample_rate;
+    c->debug_mm = getenv("HZ_DEBUG_MM") != nullptr;
     *out = c;
     return HZSDR_OK;
 }
