@@ -392,7 +392,7 @@ static bool mm2_eligible(const hzsdr_chain *c) {
     const mm2::Geom g = mm2::make_geom((int)c->ntaps, (int)c->factor, c->off, 0);
     const int D = (int)c->factor;
     return mm2::image_bytes(D, g.ks) <= (size_t)mm2::kU * 64 * 16 && mm2::table_bytes(g.ne) <= (size_t)4 * mm2::kThreads * 16 &&
-           mm2::lds_bytes(D, g.ks, g.ne) <= 160 * 1024;
+           mm2::lds_bytes(D, g.ks, g.ne, g.ntaps) <= 160 * 1024 && g.ntaps + D * (mm2::kFixOut - 1) <= 5 * 256;
 }
 
 static void mm_geometry(hzsdr_chain *c) {
@@ -685,11 +685,13 @@ static bool mm2_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *i
         mm2::Run &u = L->run[L->n];
         u.tab = dev, u.m_lo = (uint32_t)lo, u.m_hi = (uint32_t)hi;
         u.pass_first = (int)(lo / pass), u.pass_end = (int)((hi + pass - 1) / pass);
-        if (c->has_shift) u.first = P.segs.first[r], u.t0 = P.segs.t0[r], u.step = P.segs.step[r];
-        if (L->shift_op >= 0) mm2::phase_fix(P.op[L->shift_op].tau_shift, u.t0, u.step, u.first, &u.phi, &u.dphi);
+        u.seg = r;
+        if (c->has_shift) u.first = P.segs.first[r];
+        if (L->shift_op >= 0)
+            mm2::phase_fix(P.op[L->shift_op].tau_shift, P.segs.t0[r], P.segs.step[r], u.first, &u.phi, &u.dphi);
         L->pass_first[L->n] = u.pass_first, L->pass_end[L->n] = u.pass_end;
-        L->n++;
         add_fix(covered, lo);
+        L->n++;
         covered = hi;
     }
     if (L->n == 0) return false;
@@ -704,8 +706,10 @@ static bool mm2_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *i
                     L->run[r].m_hi, L->run[r].pass_first, L->run[r].pass_end, L->run[r].tab);
         for (int k = 0; k < F->n; k++) fprintf(stderr, "   fix [%u, %u) first task %d\n", F->m_a[k], F->m_b[k], F->task_first[k]);
     }
-    // the fix-up tasks are the slow way: a call that is mostly boundaries keeps the transforms
-    return !too_many && fix_total <= 16384 && fix_total * 8 <= n_out;
+    // the fix-up tasks are the slow way: a call that is mostly boundaries keeps the transforms; a workgroup takes
+    // them one at a time (hz_firmm2.h: the launch has min(CUs, passes) workgroups)
+    const int grid = std::max(1, std::min(c->ctx->num_cus, L->n_pass));
+    return !too_many && F->n_task <= 4 * grid && fix_total * 8 <= n_out;
 }
 
 static int mm2_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const EwProgram &P, const mm2::Plan &L,

@@ -59,7 +59,10 @@ __device__ __forceinline__ float2 ew_apply(const EwProgram &P, float2 v, uint64_
 // one-sample form serialises them behind the rolled op loop).
 // LATE: the call mixes FILTER OUTPUTS of a late block (error-bounded, not bit-defined):
 // Shift uses sincos_late instead of the operation-for-operation math.Sincos.
-template <int W, bool LATE = false>
+// LATE = 2: the Sincos of a late call through the phase in turns (sincos_turns32 below): the float64 product
+// tau ts as the reference forms it, reduced to a 32-bit fraction of a turn, float32 polynomials -- half the issue
+// cycles of sincos_late (the fix-up tasks of hz_firmm2.h, whose outputs are held to the FIR bound).
+template <int W, int LATE = 0>
 __device__ __forceinline__ void ew_apply_n(const EwProgram &P, float2 (&v)[W], uint64_t j0, NcoWin w,
                                            uint64_t stride = 1) {
     double ts[W];
@@ -82,7 +85,11 @@ __device__ __forceinline__ void ew_apply_n(const EwProgram &P, float2 (&v)[W], u
             double s[W], c[W];
 #pragma unroll
             for (int l = 0; l < W; l++) {
-                if constexpr (LATE) sincos_late(__dmul_rn(o.tau_shift, ts[l]), s[l], c[l]);
+                if constexpr (LATE == 2) {
+                    float sf, cf;
+                    sincos_turns32(turns32(__dmul_rn(o.tau_shift, ts[l])), sf, cf);
+                    s[l] = sf, c[l] = cf;
+                } else if constexpr (LATE == 1) sincos_late(__dmul_rn(o.tau_shift, ts[l]), s[l], c[l]);
                 else go_sincos(__dmul_rn(o.tau_shift, ts[l]), s[l], c[l]);
             }
 #pragma unroll

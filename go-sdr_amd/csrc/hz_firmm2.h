@@ -44,7 +44,7 @@ using mm::v4i;
 constexpr int kT = 8;        // outputs per tile
 constexpr int kWaves = 8;    // two per SIMD
 constexpr int kThreads = 64 * kWaves;
-constexpr int kFixOut = 8;   // outputs per fix-up task
+constexpr int kFixOut = 16;  // outputs per fix-up task
 constexpr int kHistPer = 64; // samples per history task
 constexpr int kMaxRuns = 8;   // clock runs of a call that take the matrix path (more: the call keeps the transforms)
 constexpr int kMaxFix = kNcoMaxSegs + 2;
@@ -69,8 +69,11 @@ constexpr size_t slot_bytes(int D, int ks) {
 // table: T[f][E][part][pl] of 16 bytes (digit plane 2 f + pl, most significant first), then (dc_re, dc_im)
 constexpr size_t table_bytes(int ne) { return (size_t)ne * 128 + 16; }
 constexpr size_t table_lds(int ne) { return (table_bytes(ne) + 255) / 256 * 256; }
-constexpr size_t kCtlBytes = 256;  // the queue's counter
-constexpr size_t lds_bytes(int D, int ks, int ne) { return 2 * table_lds(ne) + kCtlBytes + kWaves * slot_bytes(D, ks); }  // two tables
+constexpr size_t kCtlBytes = 512;  // the queue's counter; the mixer's step factors of the group's two runs
+// two tables, the queue's counter, a slot per wave, the fix-up task's window (ntaps + D (kFixOut - 1) samples) and taps
+constexpr size_t lds_bytes(int D, int ks, int ne, int ntaps) {
+    return 2 * table_lds(ne) + kCtlBytes + kWaves * slot_bytes(D, ks) + ((size_t)(2 * ntaps + D * (kFixOut - 1)) * 8 + 255) / 256 * 256;
+}
 
 struct Geom {
     int ntaps;
@@ -87,15 +90,16 @@ struct Geom {
 // first matrix loop took 4.5 us): the plan keeps what the main path reads in its first line and ONE 64-byte
 // line per clock run; the program P and the fix-up intervals F are read by the small tasks only.
 struct Run {
-    const void *tab;       // the run's digit table (null: no table -- its outputs are fix-up tasks)
+    const void *tab;       // the run's digit table
     uint32_t m_lo, m_hi;   // the outputs that take the matrix path (tile-aligned inside the call)
     int pass_first;        // the passes (512 outputs of the call's grid) that hold outputs of the run: a pass that
     int pass_end;          // straddles a boundary belongs to BOTH runs and is multiplied twice, once per table
     // programs with exactly ONE Shift stage: the stage's phase tau ts / 2 pi at the BUFFER's first sample by
     // the run's line, and its increment per sample, in 2^-64 turns (mod 1)
     uint64_t phi, dphi;
-    uint64_t first;        // the run's first sample, its clock there and the clock's step (programs with
-    double t0, step;       // several Shift stages)
+    uint64_t first;        // the run's first sample
+    int seg;               // the run's index in the program's clock table (programs with several Shift stages)
+    int pad[3];
 };
 static_assert(sizeof(Run) == 64, "one scalar-cache line per run");
 struct Plan {
@@ -105,7 +109,7 @@ struct Plan {
     int shift_op;   // index of the program's only Shift stage, -1: none or several
     int n_task;     // fix-up tasks (F)
     int n_ops;      // stages of the program
-    float gain;     // MIX kernels: the Gain behind the Shift (n_ops == 2)
+    float gain;     // (unused)
     int grid;       // workgroups of the launch (gridDim.x is a read of the dispatch packet: another miss)
     int pass_first[kMaxRuns], pass_end[kMaxRuns];  // (copies: a workgroup finds its runs without reading their lines)
     Run run[kMaxRuns];
@@ -131,32 +135,6 @@ inline void phase_fix(double tau, double t0, double step, uint64_t first, uint64
     *phi = fix((long double)tau * (long double)t0 * inv2pi) - first * *dphi;  // (mod 2^64: by the run's line at sample 0)
 }
 
-// sin and cos of 2 pi t / 2^32, float32 arithmetic only: within 0.8 ulp (0.30 ulp rms: a correctly rounded
-// result has 0.29).  The nearest quarter turn comes off the integer phase exactly; the rest r, |r| <= 1/8
-// turn, keeps 24 bits in r and its last six in e; odd / even polynomials in r with the leading coefficients
-// split, one rounding at the end of each.  (float64 Sincos here would queue behind the SIMD partner's MFMAs.)
-__device__ __forceinline__ void sincos_turns(uint32_t t, float &sn, float &cs) {
-    const uint32_t q = (t + 0x20000000u) >> 30;
-    const int32_t rf = (int32_t)(t - (q << 30));
-    const float r = (float)(rf & ~63) * 2.3283064365386963e-10f;  // 2^-32: exact
-    const float e = (float)(rf & 63) * 1.4629180792671596e-09f;   // 2 pi 2^-32
-    const float zh = r * r, zl = __fmaf_rn(r, r, -zh);
-    float ps = __fmaf_rn(zh, 42.058692932128906f, -76.70585632324219f);
-    ps = __fmaf_rn(ps, zh, 81.6052474975586f);
-    ps = __fmaf_rn(ps, zh, -41.34170150756836f);
-    float pc = __fmaf_rn(zh, -26.42625617980957f, 60.2446403503418f);
-    pc = __fmaf_rn(pc, zh, -85.45681762695312f);
-    pc = __fmaf_rn(pc, zh, 64.93939208984375f);
-    const float rin = r * __fmaf_rn(zh, ps, -1.7484555314695172e-07f);
-    const float small = __fmaf_rn(zh, zh * pc, __fmaf_rn(zl, -19.739208221435547f, zh * -5.807431762150372e-07f));
-    const float s0 = __fmaf_rn(r, 6.2831854820251465f, rin), c0 = __fmaf_rn(zh, -19.739208221435547f, small) + 1.0f;
-    const float s = __fmaf_rn(r, 6.2831854820251465f, __fmaf_rn(e, c0, rin));
-    const float c = __fmaf_rn(zh, -19.739208221435547f, __fmaf_rn(-e, s0, small)) + 1.0f;
-    const float a = (q & 1) ? c : s, b = (q & 1) ? s : c;
-    sn = (q & 2) ? -a : a;
-    cs = ((q + 1) & 2) ? -b : b;
-}
-
 // geometry of a chain with `ntaps` taps at decimation D (host)
 inline Geom make_geom(int ntaps, int D, unsigned off, int shift) {
     Geom g{};
@@ -172,49 +150,6 @@ inline Geom make_geom(int ntaps, int D, unsigned off, int shift) {
     return g;
 }
 
-// The same computation cut into seven short stages (with the product and an optional Gain as the last): the
-// mixer of a pass rides inside the NEXT pass's matrix loop, one stage per step, so that each gap between two
-// MFMAs takes two or three vector instructions and hides them (five is what a gap hides; a whole output per
-// step, ~50 instructions, made the step vector-bound: +1.4 us per pass, measured).
-struct MixState {
-    uint32_t q;
-    float r, e, zh, zl, ps, pc, rin, small, s, c;
-};
-template <int K>
-__device__ __forceinline__ void mix_stage(MixState &m, uint32_t t, float2 &y, float gain, bool has_gain) {
-    if constexpr (K == 0) {
-        m.q = (t + 0x20000000u) >> 30;
-        const int32_t rf = (int32_t)(t - (m.q << 30));
-        m.r = (float)(rf & ~63) * 2.3283064365386963e-10f;
-        m.e = (float)(rf & 63) * 1.4629180792671596e-09f;
-    } else if constexpr (K == 1) {
-        m.zh = m.r * m.r;
-        m.zl = __fmaf_rn(m.r, m.r, -m.zh);
-        m.ps = __fmaf_rn(m.zh, 42.058692932128906f, -76.70585632324219f);
-        m.pc = __fmaf_rn(m.zh, -26.42625617980957f, 60.2446403503418f);
-    } else if constexpr (K == 2) {
-        m.ps = __fmaf_rn(m.ps, m.zh, 81.6052474975586f);
-        m.ps = __fmaf_rn(m.ps, m.zh, -41.34170150756836f);
-        m.pc = __fmaf_rn(m.pc, m.zh, -85.45681762695312f);
-        m.pc = __fmaf_rn(m.pc, m.zh, 64.93939208984375f);
-    } else if constexpr (K == 3) {
-        m.rin = m.r * __fmaf_rn(m.zh, m.ps, -1.7484555314695172e-07f);
-        m.small = __fmaf_rn(m.zh, m.zh * m.pc, __fmaf_rn(m.zl, -19.739208221435547f, m.zh * -5.807431762150372e-07f));
-    } else if constexpr (K == 4) {
-        const float s0 = __fmaf_rn(m.r, 6.2831854820251465f, m.rin), c0 = __fmaf_rn(m.zh, -19.739208221435547f, m.small) + 1.0f;
-        m.s = __fmaf_rn(m.r, 6.2831854820251465f, __fmaf_rn(m.e, c0, m.rin));
-        m.c = __fmaf_rn(m.zh, -19.739208221435547f, __fmaf_rn(-m.e, s0, m.small)) + 1.0f;
-    } else if constexpr (K == 5) {
-        const float a = (m.q & 1) ? m.c : m.s, b = (m.q & 1) ? m.s : m.c;
-        m.s = (m.q & 2) ? -a : a;
-        m.c = ((m.q + 1) & 2) ? -b : b;
-    } else if constexpr (K == 6) {
-        float2 v = make_float2(__fmaf_rn(y.x, m.c, -(y.y * m.s)), __fmaf_rn(y.x, m.s, y.y * m.c));
-        if (has_gain) v = make_float2(__fmul_rn(v.x, gain), __fmul_rn(v.y, gain));
-        y = v;
-    }
-}
-
 using mm::find_le;
 using mm::task_window;
 
@@ -223,14 +158,7 @@ using mm::task_window;
 // NG: the window's groups (ks / GS) when the instantiation is for ONE tap count -- the matrix loop is then
 // straight-line code (a loop header drains the operand pipeline: the compiler cannot count outstanding
 // loads across a back edge); 0: any window, a loop over the groups.
-// MIX = 1: the elementwise program is ONE Shift stage, optionally followed by one Gain -- the program of the
-// headline chain.  Vector instructions of a wave that runs BESIDE its SIMD partner's matrix loop cost both
-// waves dearly (measured: ~600 of them took the one wave 7 us instead of 1.8, and the partner's loop twice its
-// time), while the same instructions between a wave's OWN MFMAs are nearly free (24 of an MFMA's 32 issue
-// cycles are open).  So with MIX = 1 a pass leaves its matrix loop with 16 floats per lane (the planes
-// combined), and its mixer and stores ride inside the NEXT pass's matrix loop, one output per eight steps.
-// MIX = 0: any program, applied behind the loop.
-template <int FMT, int D, int NG = 0, int MIX = 0, int EXP = 0>
+template <int FMT, int D, int NG = 0, int EXP = 0>
 __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     const void *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ hist,
     float2 *__restrict__ new_hist, const uint8_t *__restrict__ rhist, uint8_t *__restrict__ new_rhist,
@@ -248,6 +176,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     const size_t tab_lds = table_lds(G.ne), slot_sz = slot_bytes(D, G.ks);
     uint8_t *const tabp = mm_lds;
     unsigned *const ctr = reinterpret_cast<unsigned *>(mm_lds + 2 * tab_lds);
+    float4 *const wfac = reinterpret_cast<float4 *>(mm_lds + 2 * tab_lds + 16);  // [2 runs][8 outputs of a lane]
     uint8_t *const slot = mm_lds + 2 * tab_lds + kCtlBytes + (size_t)wave * slot_sz;
     const int64_t n_bytes = 2 * (int64_t)n_in;
     const uint8_t *src = (const uint8_t *)in;
@@ -263,99 +192,17 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     stamp(0);
     if constexpr ((EXP & 32) == 0) __builtin_amdgcn_s_setprio(1);
     const Run run0 = L.run[0];  // (read with the header: most workgroups of most calls are in run 0)
+    // Everything the way to the first loads reads from the kernel arguments, wanted HERE: the compiler then issues
+    // these scalar loads together and waits once (left alone it reads each next to its use: five load-wait
+    // groups, ~0.6 us each through the scalar cache while every wave of the chip asks, before the first byte was
+    // requested).
+    {
+        const uint64_t a0 = (uint64_t)(uintptr_t)in, a1 = (uint64_t)n_in, a2 = (uint64_t)(uintptr_t)run0.tab;
+        asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(G.w0), "s"(G.ks), "s"(G.ne), "s"(G.e0), "s"(G.ntaps), "s"(G.off), "s"(L.n),
+                     "s"(L.n_pass), "s"(L.grid), "s"(L.n_task), "s"(L.pass_first[0]), "s"(L.pass_end[0]), "s"(L.pass_first[1]),
+                     "s"(L.pass_end[1]), "s"(run0.m_lo), "s"(run0.m_hi));
+    }
 
-    // ---- the small tasks, one wave each --------------------------------------------------------------
-    const int n_hist_tasks = new_hist ? (int)((G.off + kHistPer - 1) / kHistPer) : 0;
-    const int n_tasks = L.n_task + n_hist_tasks;
-    auto small_task = [&](int task) {
-        using RW = typename Raw<FMT>::t;
-        if (task < L.n_task) {
-            // Up to 16 outputs in reference order: their window's samples (load, convert, elementwise
-            // program) go to the wave's slot, a chunk of the taps at a time; four lanes per output run the
-            // direct form in float64.
-            const int k = find_le(F.task_first, F.n, task);
-            const uint32_t m0 = F.m_a[k] + (uint32_t)(task - F.task_first[k]) * kFixOut;
-            const int cnt = (int)min((uint32_t)kFixOut, F.m_b[k] - m0);
-            float2 *xs = reinterpret_cast<float2 *>(slot);
-            const int kc = ((int)(slot_sz / 8) - D * (kFixOut - 1)) & ~7;  // taps per chunk
-            // eight lanes per output, four independent accumulation chains per lane (a single chain per component
-            // runs at the latency of a float64 fma, a quarter of the issue rate)
-            constexpr int kLanesPer = 64 / kFixOut;
-            const int o = l / kLanesPer, sl = l % kLanesPer;
-            double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
-#pragma unroll 1
-            for (int k0 = 0; k0 < G.ntaps; k0 += kc) {
-                const int k1 = min(G.ntaps, k0 + kc);
-                const int64_t p_lo = (int64_t)D * m0 - (k1 - 1);
-                const int n_s = (k1 - k0) + D * (cnt - 1);
-                const NcoWin tw = task_window(P, p_lo, p_lo + n_s - 1);
-                constexpr int W = 3;
-#pragma unroll 1
-                for (int i0 = l; i0 < n_s; i0 += W * 64) {
-                    float2 v[W];
-#pragma unroll
-                    for (int u = 0; u < W; u++) {
-                        const int64_t pu = p_lo + i0 + u * 64;
-                        const bool ok = i0 + u * 64 < n_s && pu >= 0;
-                        v[u] = Raw<FMT>::cvt(ok ? ((const RW *)in)[pu] : RW{});
-                    }
-                    ew_apply_n<W, true>(P, v, (uint64_t)(p_lo + i0), tw, (uint64_t)64);
-#pragma unroll
-                    for (int u = 0; u < W; u++) {
-                        const int idx = i0 + u * 64;
-                        const int64_t pu = p_lo + idx;
-                        if (idx < n_s)
-                            xs[idx] = pu >= 0 ? v[u] : ((hist && pu + (int64_t)G.off >= 0) ? hist[pu + (int64_t)G.off] : make_float2(0.f, 0.f));
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (o < cnt) {
-                    const float2 *xo = xs + D * o + (k1 - 1);
-#pragma unroll 4
-                    for (int kk = k0 + sl; kk < k1; kk += kLanesPer) {
-                        const float2 hk = taps[kk], x = xo[-kk];
-                        const double xr = x.x, xi = x.y, hr = hk.x, hi = hk.y;
-                        ar = __fma_rn(xr, hr, ar);
-                        br = __fma_rn(-xi, hi, br);
-                        ai = __fma_rn(xr, hi, ai);
-                        bi = __fma_rn(xi, hr, bi);
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-            ar += br;
-            ai += bi;
-#pragma unroll
-            for (int d = 1; d < kLanesPer; d <<= 1) {
-                ar += __shfl_xor(ar, d);
-                ai += __shfl_xor(ai, d);
-            }
-            if (o < cnt && sl == 0) out[m0 + o] = make_float2((float)ar, (float)ai);
-        } else {
-            // 64 samples of the history: the last `off` samples after the elementwise program, and the
-            // same samples as raw bytes
-            const unsigned idx = (unsigned)(task - L.n_task) * kHistPer + l;
-            const int64_t h_lo = (int64_t)n_in - (int64_t)G.off + (int64_t)(task - L.n_task) * kHistPer;
-            const NcoWin tw = task_window(P, h_lo, h_lo + kHistPer - 1);
-            if (idx < G.off) {
-                const int64_t p = (int64_t)n_in - (int64_t)G.off + idx;
-                new_hist[idx] = mm::ordered_sample<FMT>(in, P, p, hist, G.off, tw);
-                reinterpret_cast<RW *>(new_rhist)[idx] = p >= 0 ? ((const RW *)in)[p] : reinterpret_cast<const RW *>(rhist)[p + (int64_t)G.off];
-            }
-        }
-    };
-    // Task t goes to workgroup t % grid, wave 7 - (t / grid) % 8: the YOUNG waves first (they only fill the gaps
-    // of their SIMD partners' matrix loops), one task per workgroup before two, and behind the workgroup's
-    // first barrier -- a wave that is late for it holds up all eight.
-    bool tasks_done = false;
-    auto run_tasks = [&]() {
-        if (tasks_done) return;
-        tasks_done = true;
-        for (int task = (kWaves - 1 - wave) * L.grid + wb; task < n_tasks; task += kWaves * L.grid) small_task(task);  // (uniform per wave)
-    };
-    stamp(9);
     // ---- this workgroup's passes [pb0, pb1) of the call -------------------------------------------------
     const uint32_t NP = (uint32_t)L.n_pass;
     // (NP / grid passes each, the first NP % grid workgroups one more; 32-bit arithmetic)
@@ -381,6 +228,114 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
             else x[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p + 16 * min(l + u * 64, pieces - 1)));
         }
     };
+    // The first pass's bytes, requested before anything else is even fetched: the instruction cache is cold at every
+    // launch, and the path from the kernel's first instruction to this one decides when the matrix pipes start
+    // (measured: 2.4 us of the kernel's first 5.5 went by between two stamps with ~300 instructions in between).
+    // Waves 0-3 take passes pb0 .. pb0 + 3 when those lie in run 0 (the group loop below checks that it agrees).
+    v4i x[KU];
+    bool pre_issued = false;
+    if (wave < kWaves / 2) {
+        const uint32_t p = pb0 + (uint32_t)wave;
+        if (pb0 >= (uint32_t)L.pass_first[0] && p < min(pb1, (uint32_t)L.pass_end[0]) && inside(p)) {
+            issue(x, p);
+            pre_issued = true;
+        }
+    }
+    // ---- the small tasks: waves 4-7 of a workgroup, in front of and behind its first barrier -----------------
+    // A FIX-UP TASK = 16 outputs in reference order (direct form, float64).  One wave alone took 18-27 us over one
+    // (measured: ~3000 instructions per lane, every load a full trip): workgroup t takes task t, its four young
+    // waves stage the window's 1144 samples together (load, convert, the elementwise program: five per thread,
+    // all loads in flight at once) into a scratch of their own in LDS while the workgroup's first bytes and
+    // table are on their way, and behind the barrier the same 256 threads -- 16 per output, 64 taps each -- sum
+    // and store.  The matrix pipes are idle for the kernel's first ~5 us anyway.  At most ONE per workgroup: a
+    // call with more fix-up tasks than workgroups keeps the transform kernels (the host).
+    // A HISTORY TASK = 64 samples of the next call's history, one wave (4-7) each.
+    using RWT = typename Raw<FMT>::t;
+    const int n_hist_tasks = new_hist ? (int)((G.off + kHistPer - 1) / kHistPer) : 0;
+    float2 *const xs = reinterpret_cast<float2 *>(mm_lds + 2 * tab_lds + kCtlBytes + (size_t)kWaves * slot_sz);
+    float2 *const tl = xs + (G.ntaps + D * (kFixOut - 1));  // the taps, beside the window
+    uint32_t fix_m0 = 0;
+    int fix_cnt = 0;
+    bool tasks_done = false;
+    auto tasks_front = [&](int round) {  // round r: fix-up task wb + r grid
+        if (round == 0) {
+            if (tasks_done) return;
+            tasks_done = true;
+        }
+        if (wave < kWaves / 2) return;
+        const int ftask = wb + round * L.grid;
+        if (ftask < L.n_task) {
+            const int ct = tid - 64 * (kWaves / 2);  // 0 .. 255
+            const int k = find_le(F.task_first, F.n, ftask);
+            fix_m0 = F.m_a[k] + (uint32_t)(ftask - F.task_first[k]) * kFixOut;
+            fix_cnt = (int)min((uint32_t)kFixOut, F.m_b[k] - fix_m0);
+            if (round == 0)
+                for (int q = ct; q < G.ntaps; q += 256) tl[q] = taps[q];
+            const int64_t p_lo = (int64_t)D * fix_m0 - (G.ntaps - 1);
+            const int n_s = G.ntaps + D * (fix_cnt - 1);
+            const NcoWin tw = task_window(P, p_lo, p_lo + n_s - 1);
+#pragma unroll 1
+            for (int i0 = ct; i0 < n_s; i0 += 5 * 256) {  // (one trip up to 1280 samples: 1160 taps)
+                constexpr int W = 5;
+                float2 v[W];
+#pragma unroll
+                for (int u = 0; u < W; u++) {
+                    const int64_t pu = p_lo + i0 + u * 256;
+                    v[u] = Raw<FMT>::cvt((i0 + u * 256 < n_s && pu >= 0) ? ((const RWT *)in)[pu] : RWT{});
+                }
+                ew_apply_n<W, 2>(P, v, (uint64_t)(p_lo + i0), tw, (uint64_t)256);
+#pragma unroll
+                for (int u = 0; u < W; u++) {
+                    const int idx = i0 + u * 256;
+                    const int64_t pu = p_lo + idx;
+                    if (idx < n_s)
+                        xs[idx] = pu >= 0 ? v[u] : ((hist && pu + (int64_t)G.off >= 0) ? hist[pu + (int64_t)G.off] : make_float2(0.f, 0.f));
+                }
+            }
+        }
+        if (round > 0) return;
+        // history tasks: behind the fix-up tasks in the workgroup order, young waves last to first
+        for (int t = wb + L.grid * (kWaves - 1 - wave); t < L.n_task + n_hist_tasks; t += (kWaves / 2) * L.grid) {  // (uniform per wave)
+            const int j = t - L.n_task;
+            if (j < 0) continue;
+            const unsigned idx = (unsigned)j * kHistPer + l;
+            const int64_t h_lo = (int64_t)n_in - (int64_t)G.off + (int64_t)j * kHistPer;
+            const NcoWin tw = task_window(P, h_lo, h_lo + kHistPer - 1);
+            if (idx < G.off) {
+                const int64_t p = (int64_t)n_in - (int64_t)G.off + idx;
+                new_hist[idx] = mm::ordered_sample<FMT>(in, P, p, hist, G.off, tw);
+                reinterpret_cast<RWT *>(new_rhist)[idx] = p >= 0 ? ((const RWT *)in)[p] : reinterpret_cast<const RWT *>(rhist)[p + (int64_t)G.off];
+            }
+        }
+    };
+    auto tasks_back = [&]() {  // behind the barrier that follows tasks_front
+        if (wave < kWaves / 2 || fix_cnt == 0) return;
+        const int ct = tid - 64 * (kWaves / 2);
+        const int o = ct >> 4, sl = ct & 15;  // output, tap slice: sixteen lanes per output
+        double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
+        if (o < fix_cnt) {
+            const float2 *xo = xs + D * o + (G.ntaps - 1);
+#pragma unroll 8
+            for (int kk = sl; kk < G.ntaps; kk += 16) {
+                const float2 hk = tl[kk], x = xo[-kk];
+                const double xr = x.x, xi = x.y, hr = hk.x, hi = hk.y;
+                ar = __fma_rn(xr, hr, ar);
+                br = __fma_rn(-xi, hi, br);
+                ai = __fma_rn(xr, hi, ai);
+                bi = __fma_rn(xi, hr, bi);
+            }
+        }
+        ar += br;
+        ai += bi;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            ar += __shfl_xor(ar, d);
+            ai += __shfl_xor(ai, d);
+        }
+        if (o < fix_cnt && sl == 0) out[fix_m0 + o] = make_float2((float)ar, (float)ai);
+        fix_cnt = 0;
+    };
+    stamp(9);
     auto put = [&](int q, v4i v) {
         if constexpr (FMT == HZSDR_FMT_U8) v ^= (int)0x80808080;  // b - 128 as int8
         *reinterpret_cast<v4i *>(slot + TS * (q / PPT) + 16 * (q % PPT)) = v;
@@ -434,30 +389,135 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
 
     const Run run1 = L.run[1];
     bool first_seg = true, first_stamp = true;
-    int r = 0;
+    const double k3 = __hiloint2double((1023 - G.shift) << 20, 0), k2 = k3 * 256.0, k1 = k3 * 65536.0, k0 = k3 * 16777216.0;  // 2^-S 256^d
+    // a lane holds outputs 4 h + a (a = 0 .. 3) of tile n of each block: planes 2 f + pl at q = 4 a + 2 part + pl.
+    // The planes meet in float64 with power-of-two weights (exact; the constant part of a u8 stream and the scale
+    // 2^-S folded in), one rounding to float32.
+    auto planes = [&](const v16i(&acc)[2][NB], float2(&y)[NB][4], double dcr, double dci) {
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int aa = 0; aa < 4; aa++) {
+                float c2[2];
+#pragma unroll
+                for (int pt = 0; pt < 2; pt++) {
+                    const int q = 4 * aa + 2 * pt;
+                    double v = __fma_rn((double)acc[1][b][q + 1], k3, pt ? dci : dcr);
+                    v = __fma_rn((double)acc[1][b][q], k2, v);
+                    v = __fma_rn((double)acc[0][b][q + 1], k1, v);
+                    v = __fma_rn((double)acc[0][b][q], k0, v);
+                    c2[pt] = (float)v;
+                }
+                y[b][aa] = make_float2(c2[0], c2[1]);
+            }
+    };
+    // the elementwise program over a lane's outputs m = mb + 256 b + a of a pass in the run with phase line
+    // (phi_r, dphi) / clock-table entry seg: equally spaced in two directions inside one exactly-linear clock run
+    auto program = [&](float2(&y)[NB][4], uint32_t mb, uint64_t phi_r, uint64_t dphi, int seg, const float4 *wtab) {
 #pragma unroll 1
-    while (r < L.n && (uint32_t)L.pass_first[r] < pb1) {
-        // The passes of this workgroup that hold outputs of run r, and of the run behind it: TWO tables fit the
-        // LDS, so a workgroup whose range holds a clock boundary (one or two of the 256 in most calls) works
-        // through both runs' passes as ONE queue instead of draining the first behind a barrier.
-        const uint32_t a0 = max(pb0, (uint32_t)L.pass_first[r]), a1 = min(pb1, (uint32_t)L.pass_end[r]);
-        if (a0 >= a1) {
-            r++;
-            continue;
+        for (int oi = 0; oi < ((EXP & 4) ? 0 : L.n_ops); oi++) {  // uniform
+            const EwOp &o = P.op[oi];
+            if (o.kind == EW_SCALE) {
+#pragma unroll
+                for (int b = 0; b < NB; b++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) y[b][q] = make_float2(__fmul_rn(y[b][q].x, o.a), __fmul_rn(y[b][q].y, o.a));
+            } else if (o.kind == EW_ROTATE) {
+#pragma unroll
+                for (int b = 0; b < NB; b++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) y[b][q] = go_cmul(y[b][q], make_float2(o.a, o.b));
+            } else if (L.shift_op == oi) {
+                // The stage's phase is a 64-bit accumulator in turns (exact increments, no float64).  ONE Sincos per
+                // lane, for its first output; the other seven are that factor turned on by the group's step factors
+                // exp(2 pi i (256 b + a) D dphi) -- double-float constants in LDS, two fma pairs and an add per
+                // component (0.4 ulp rms against the 0.3 of a Sincos each, a third of the instructions: every vector
+                // instruction here runs beside the SIMD partner's matrix loop and costs both waves).
+                const uint64_t ph0 = phi_r + (uint64_t)D * mb * dphi;
+                float s0, c0;
+                sincos_turns32((uint32_t)(ph0 >> 32), s0, c0);
+#pragma unroll
+                for (int b = 0; b < NB; b++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        float cs = c0, sn = s0;
+                        if (b + q > 0) {
+                            const float4 w = wtab[4 * b + q];  // (cos hi, sin hi, cos lo, sin lo)
+                            cs = __fmaf_rn(c0, w.x, -(s0 * w.y)) + __fmaf_rn(c0, w.z, -(s0 * w.w));
+                            sn = __fmaf_rn(c0, w.y, s0 * w.x) + __fmaf_rn(c0, w.w, s0 * w.z);
+                        }
+                        y[b][q] = make_float2(__fmaf_rn(y[b][q].x, cs, -(y[b][q].y * sn)), __fmaf_rn(y[b][q].x, sn, y[b][q].y * cs));
+                    }
+            } else {
+                // (programs with several Shift stages: float64 phases, as hz_firmm.h)
+                const double step = P.segs.step[seg];
+                const int64_t dj = (int64_t)((uint64_t)D * mb) - (int64_t)P.segs.first[seg];
+                const double ts0 = __fma_rn((double)dj, step, P.segs.t0[seg]);
+                double cs0, cc0, fs, fc;
+                sincos_late(__dmul_rn(o.tau_shift, ts0), cs0, cc0);
+                const double mult = l == 0 ? (double)D : (double)(32 * kT * D);
+                sincos_late(__dmul_rn(o.tau_shift, __dmul_rn(mult, step)), fs, fc);
+                const double e_s = __shfl(fs, 0), e_c = __shfl(fc, 0), b_s = __shfl(fs, 1), b_c = __shfl(fc, 1);
+                auto mul32 = [](float2 v, double c, double sn) {
+                    const float cr = (float)c, ci = (float)sn;
+                    return make_float2(__fmaf_rn(v.x, cr, -(v.y * ci)), __fmaf_rn(v.x, ci, v.y * cr));
+                };
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    double zc = cc0, zs = cs0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        y[b][q] = mul32(y[b][q], zc, zs);
+                        if (q < 3) {
+                            const double nc = __fma_rn(zc, e_c, -(zs * e_s)), ns = __fma_rn(zc, e_s, zs * e_c);
+                            zc = nc;
+                            zs = ns;
+                        }
+                    }
+                    if (b + 1 < NB) {
+                        const double nc = __fma_rn(cc0, b_c, -(cs0 * b_s)), ns = __fma_rn(cc0, b_s, cs0 * b_c);
+                        cc0 = nc;
+                        cs0 = ns;
+                    }
+                }
+            }
         }
-        uint32_t b0 = 0, b1 = 0;
-        if (r + 1 < L.n) {
-            b0 = max(pb0, (uint32_t)L.pass_first[r + 1]);
-            b1 = min(pb1, (uint32_t)L.pass_end[r + 1]);
-            if (b0 >= b1) b0 = b1 = 0;
+    };
+    auto store_block = [&](float2(&y)[4], uint32_t mo, uint32_t lo, uint32_t hi) {
+        if constexpr ((EXP & 8) != 0) return;
+        if (mo >= lo && mo + 4 <= hi) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f *o4 = reinterpret_cast<v4f *>(out + mo);
+            __builtin_nontemporal_store(v4f{y[0].x, y[0].y, y[1].x, y[1].y}, o4);
+            __builtin_nontemporal_store(v4f{y[2].x, y[2].y, y[3].x, y[3].y}, o4 + 1);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (mo + q >= lo && mo + q < hi) out[mo + q] = y[q];
         }
-        const bool has_b = b1 > b0;  // uniform
-        const uint32_t n_a = a1 - a0, seg_b = n_a + (b1 - b0);  // items [0, seg_b): pass a0 + q, then b0 + (q - n_a)
+    };
+    // The runs that matter to this workgroup: those with passes in [pb0, pb1).  Two tables fit the LDS: run A of a
+    // group and the run B behind it are ONE queue (A's passes, B's passes); the next group slides on by one run (B
+    // becomes A, its table stays) behind a barrier.
+    auto has_passes = [&](int rr) { return rr < L.n && max(pb0, (uint32_t)L.pass_first[rr]) < min(pb1, (uint32_t)L.pass_end[rr]); };
+    int ra = 0;
+    while (ra < L.n && !has_passes(ra)) ra++;
+    bool a_done = false;
+    int slot_a = 0;  // the half of the table area that holds run A's table
+#pragma unroll 1
+    while (ra < L.n) {
+        const int rb = ra + 1;
+        const bool b_pass = has_passes(rb), b_here = b_pass;  // uniform
+        uint32_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+        if (!a_done && has_passes(ra)) a0 = max(pb0, (uint32_t)L.pass_first[ra]), a1 = min(pb1, (uint32_t)L.pass_end[ra]);
+        if (b_pass) b0 = max(pb0, (uint32_t)L.pass_first[rb]), b1 = min(pb1, (uint32_t)L.pass_end[rb]);
+        // items [0, seg_b): pass a0 + q of run A, then pass b0 + q of run B
+        const uint32_t n_a = a1 - a0, seg_b = n_a + (b1 - b0);
         auto pass_of = [&](uint32_t q) { return q < n_a ? a0 + q : b0 + (q - n_a); };
-        if (!first_seg) __syncthreads();  // every wave is done with the previous tables and queue
+        auto prefetchable = [&](uint32_t q) { return q < seg_b && inside(pass_of(q)); };
+        if (!first_seg) __syncthreads();  // every wave is done with the table that goes and with the queue
         const int first_seg_prio = first_seg ? 1 : 0;
-        first_seg = false;
-        // Waves 0-3 (one per SIMD) take the queue's first passes and put their bytes in flight at once;
+        // Waves 0-3 (one per SIMD) take the queue's first items and put their bytes in flight at once;
         // waves 4-7 start behind the barrier: the first burst is half as large, and the two waves of a SIMD
         // start out of phase.
         constexpr int kEarly = kWaves / 2;
@@ -466,58 +526,78 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
             if (l == 0) p = atomicAdd(ctr, 1u);
             return (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
         };
-        v4i x[KU];
         uint32_t cur = seg_b;
         bool in0 = false;
         constexpr int kTU = 4;  // table pieces per thread (32 KB at most: the host)
         if (wave < kEarly) {
             cur = min((uint32_t)wave, seg_b);
-            in0 = cur < seg_b && inside(pass_of(cur));  // uniform
-            if (in0) issue(x, pass_of(cur));
+            in0 = prefetchable(cur);  // uniform
+            // (pre_issued: the kernel's first lines have requested pass pb0 + wave -- this one, in the first group)
+            if (in0 && !(pre_issued && ra == 0 && !a_done && pass_of(cur) == pb0 + (uint32_t)wave)) issue(x, pass_of(cur));
+            pre_issued = false;
         }
         if (first_stamp) stamp(13);
+        tasks_front(0);
         // (everything the queue reads from the kernel arguments by run, at once)
         Run ru = run0, rv = run1;
-        if (r == 1) ru = run1;
-        else if (r > 1) ru = L.run[r];  // (one line)
-        if (has_b && r > 0) rv = L.run[r + 1];
-        const float gain = L.gain;
-        const bool has_gain = MIX && L.n_ops > 1;  // uniform
+        if (ra == 1) ru = run1;
+        else if (ra > 1) ru = L.run[ra];  // (one line)
+        if (b_here && ra > 0) rv = L.run[rb];
+        const int off_a = slot_a ? (int)tab_lds : 0, off_b = slot_a ? 0 : (int)tab_lds;
         {
             const int tp = (int)(table_bytes(G.ne) + 15) / 16;
             const v4i *tg = (const v4i *)ru.tab, *th = (const v4i *)rv.tab;
-            v4i tq[kTU], tr[kTU];
+            // (one table after the other: both in flight at once, beside the first pass's bytes, spilled registers)
+            v4i tq[kTU];
+            if (first_seg) {
 #pragma unroll
-            for (int u = 0; u < kTU; u++) tq[u] = tid + u * kThreads < tp ? tg[tid + u * kThreads] : v4i{0, 0, 0, 0};
-            if (has_b) {
-#pragma unroll
-                for (int u = 0; u < kTU; u++) tr[u] = tid + u * kThreads < tp ? th[tid + u * kThreads] : v4i{0, 0, 0, 0};
-            }
-            if (first_stamp) stamp(14);
-#pragma unroll
-            for (int u = 0; u < kTU; u++)
-                if (tid + u * kThreads < tp) *reinterpret_cast<v4i *>(tabp + 16 * (size_t)(tid + u * kThreads)) = tq[u];
-            if (has_b) {
+                for (int u = 0; u < kTU; u++) tq[u] = tid + u * kThreads < tp ? tg[tid + u * kThreads] : v4i{0, 0, 0, 0};
+                if (first_stamp) stamp(14);
 #pragma unroll
                 for (int u = 0; u < kTU; u++)
-                    if (tid + u * kThreads < tp) *reinterpret_cast<v4i *>(tabp + tab_lds + 16 * (size_t)(tid + u * kThreads)) = tr[u];
+                    if (tid + u * kThreads < tp) *reinterpret_cast<v4i *>(tabp + off_a + 16 * (size_t)(tid + u * kThreads)) = tq[u];
+            }
+            if (b_here) {
+#pragma unroll
+                for (int u = 0; u < kTU; u++) tq[u] = tid + u * kThreads < tp ? th[tid + u * kThreads] : v4i{0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < kTU; u++)
+                    if (tid + u * kThreads < tp) *reinterpret_cast<v4i *>(tabp + off_b + 16 * (size_t)(tid + u * kThreads)) = tq[u];
             }
         }
+        if (tid < 16 && L.shift_op >= 0) {
+            // the step factors of the group's runs (lane i of 0 .. 7: run A, 8 .. 15: run B), float64 once, kept as
+            // float pairs: (256 b + a) D dphi turns
+            const uint64_t dph = (tid & 8) ? rv.dphi : ru.dphi;
+            const uint64_t k = (uint64_t)(D * (32 * kT * ((tid & 7) >> 2) + (tid & 3)));
+            const double turns = (double)(k * dph) * 5.42101086242752217e-20;  // 2^-64
+            double sn, cs;
+            sincos_late(__dmul_rn(turns, 6.28318530717958647692), sn, cs);
+            const float ch = (float)cs, sh = (float)sn;
+            wfac[tid] = make_float4(ch, sh, (float)(cs - (double)ch), (float)(sn - (double)sh));
+        }
+        first_seg = false;
         if (first_stamp) stamp(10);
         if (tid == 0) *ctr = kEarly;
         __syncthreads();
         if (first_stamp) stamp(11);
-        // (a task is ~1500 float64 instructions per lane: beside a SIMD partner's matrix loop at equal or lower
-        // priority it took ~40 us, measured; first at the issue port it is done in a fraction of that)
-        if constexpr ((EXP & 32) == 0) __builtin_amdgcn_s_setprio(3);
-        run_tasks();
-        if constexpr ((EXP & 32) == 0) __builtin_amdgcn_s_setprio(0);
+        if (first_seg_prio) {  // (the first group of the workgroup: the small tasks)
+            if constexpr ((EXP & 32) == 0) __builtin_amdgcn_s_setprio(3);
+            tasks_back();
+            for (int round = 1; wb + round * L.grid < L.n_task; round++) {  // (uniform: calls with more tasks than workgroups)
+                __syncthreads();
+                tasks_front(round);
+                __syncthreads();
+                tasks_back();
+            }
+            if constexpr ((EXP & 32) == 0) __builtin_amdgcn_s_setprio(1);
+        }
         if constexpr ((EXP & 32) == 0) {
             if (first_seg_prio) __builtin_amdgcn_s_setprio(1);
         }
         if (wave >= kEarly) {
             cur = grab();
-            in0 = cur < seg_b && inside(pass_of(cur));
+            in0 = prefetchable(cur);
             if (in0) issue(x, pass_of(cur));
             if constexpr ((EXP & 16) != 0) __builtin_amdgcn_s_sleep(60);  // (experiment: a longer offset)
         }
@@ -527,50 +607,17 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         }
         if (first_stamp) stamp(12);
         first_stamp = false;
-        // (MIX) the pass whose mixer and stores are still owed: its combined planes, first output, valid range
-        float2 yp[NB][4];
-        uint32_t p_mb = 0, p_lo = 0, p_hi = 0;  // p_lo >= p_hi: nothing owed
-#pragma unroll
-        for (int b = 0; b < NB; b++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) yp[b][q] = make_float2(0.f, 0.f);
-        // one output of the owed pass: phase accumulator in turns, sincos_turns, product (+ Gain)
-        uint64_t p_ph = 0, p_dphi = 0;
-        MixState ms{};
-        auto mix_phase = [&](int b, int q) { return (uint32_t)((p_ph + (uint64_t)(D * (32 * kT * b + q)) * p_dphi) >> 32); };
-        auto mix_one = [&](int b, int q) {  // all stages of one output at once (drains)
-            const uint32_t t = mix_phase(b, q);
-            mix_stage<0>(ms, t, yp[b][q], gain, has_gain);
-            mix_stage<1>(ms, t, yp[b][q], gain, has_gain);
-            mix_stage<2>(ms, t, yp[b][q], gain, has_gain);
-            mix_stage<3>(ms, t, yp[b][q], gain, has_gain);
-            mix_stage<4>(ms, t, yp[b][q], gain, has_gain);
-            mix_stage<5>(ms, t, yp[b][q], gain, has_gain);
-            mix_stage<6>(ms, t, yp[b][q], gain, has_gain);
-        };
-        auto store_block = [&](float2(&y)[4], uint32_t mo, uint32_t lo, uint32_t hi) {
-            if constexpr ((EXP & 8) != 0) return;
-            if (mo >= lo && mo + 4 <= hi) {
-                typedef float v4f __attribute__((ext_vector_type(4)));
-                v4f *o4 = reinterpret_cast<v4f *>(out + mo);
-                __builtin_nontemporal_store(v4f{y[0].x, y[0].y, y[1].x, y[1].y}, o4);
-                __builtin_nontemporal_store(v4f{y[2].x, y[2].y, y[3].x, y[3].y}, o4 + 1);
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if (mo + q >= lo && mo + q < hi) out[mo + q] = y[q];
-            }
-        };
 #pragma unroll 1
         while (cur < seg_b) {
             const uint32_t nxt = grab();
-            const bool has_next = nxt < seg_b, in_next = has_next && inside(pass_of(nxt));  // uniform
+            const bool has_next = nxt < seg_b, in_next = prefetchable(nxt);  // uniform
             if (in_next) issue(x, pass_of(nxt));
             stamp_pass++;
             stamp(1);
-            const bool sel = cur >= n_a;  // uniform: the pass belongs to the second run of the queue
+            const bool sel = cur >= n_a;  // uniform: the pass belongs to run B
             const uint32_t m_lo = sel ? rv.m_lo : ru.m_lo, m_hi = sel ? rv.m_hi : ru.m_hi;
             const uint64_t dphi = sel ? rv.dphi : ru.dphi, phi_r = sel ? rv.phi : ru.phi;
+            const int tab_off = sel ? off_b : off_a;
             const uint32_t m_start = pass_of(cur) * (uint32_t)kPassOut;
             const uint32_t v_lo = max(m_lo, m_start), v_hi = min(m_hi, m_start + (uint32_t)kPassOut);
             const bool active = v_lo < v_hi;  // uniform
@@ -587,7 +634,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                 constexpr int KS = NG * GS;
                 // (NG > 0: the lane's LAST entry, and the compiler kept from folding the base back to the first
                 // one: DS offsets are unsigned, negative ones cost an address add per load)
-                int a_off = a_base - (NG > 0 ? 128 * KS : 0) + (sel ? (int)tab_lds : 0);
+                int a_off = a_base - (NG > 0 ? 128 * KS : 0) + tab_off;
                 if constexpr (NG > 0) asm volatile("" : "+v"(a_off));
                 const uint8_t *ap = tabp + a_off;
                 const uint8_t *bp = slot + TS * n + 16 * h;
@@ -610,7 +657,6 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                 load_b(b[0], 0, 0);
                 load_a(a[1], 1);
                 load_b(b[1], 0, 1);
-                static_assert(!MIX || NG == 0 || 8 * 4 * NB <= KS, "the owed pass's outputs take eight steps each");
                 // one step; SC: the step as a compile-time value (straight-line form), or -1
                 auto step = [&](auto sc, int g, int j) {
                     constexpr int SC = decltype(sc)::value;
@@ -624,22 +670,11 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
 #pragma unroll
                         for (int q = 0; q < NB; q++)
                             acc[f][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[sx % RG][f], b[sx % RG][q], acc[f][q], 0, 0, 0);
-                    // (MIX) output SC / 8 of the owed pass, stage SC % 8 (the eighth is empty); the stores at the end
-                    constexpr bool kMixHere = MIX && SC >= 0 && SC / 8 < 4 * NB && SC % 8 < 7;
-                    if constexpr (kMixHere) {
-                        constexpr int O = SC / 8;
-                        mix_stage<SC % 8>(ms, mix_phase(O / 4, O % 4), yp[O / 4][O % 4], gain, has_gain);
-                    }
-                    if constexpr (MIX && SC >= 0 && SC == (8 * 4 * NB < KS ? 8 * 4 * NB : KS - 1)) {
-#pragma unroll
-                        for (int bb = 0; bb < NB; bb++) store_block(yp[bb], p_mb + (uint32_t)(32 * kT) * bb, p_lo, p_hi);
-                    }
-                    // the step's loads (and the mixer's instructions) between its MFMAs, nothing moved across steps
+                    // the step's loads between its MFMAs, nothing moved across steps
 #pragma unroll
                     for (int q = 0; q < 2 + NB; q++) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // LDS read
-                        if constexpr (MIX && SC >= 0) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, 2 * NB - 2 - NB > 0 ? 2 * NB - 2 - NB : 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -665,121 +700,19 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                         g_done++;
                     }
                 }
-            } else if constexpr (MIX && NG > 0) {
-                // (no matrix work in this pass: what is owed, plainly)
-                if (p_lo < p_hi) {
-#pragma unroll
-                    for (int bb = 0; bb < NB; bb++) {
-#pragma unroll
-                        for (int q = 0; q < 4; q++) mix_one(bb, q);
-                        store_block(yp[bb], p_mb + (uint32_t)(32 * kT) * bb, p_lo, p_hi);
-                    }
-                }
             }
-            if constexpr (MIX && NG > 0) p_lo = p_hi = 0;  // paid
             stamp(2);
             if (in_next) land(x);
             else if (has_next) land_edge(pass_of(nxt));
             stamp(3);
             if (active) {
-                // a lane holds outputs 4 h + a (a = 0 .. 3) of tile n of each block: planes 2 f + pl at q = 4 a + 2 part + pl.
-                // The planes meet in float64 with power-of-two weights (exact; the constant part of a u8 stream and
-                // the scale 2^-S folded in), one rounding to float32.
-                const double k3 = __hiloint2double((1023 - G.shift) << 20, 0), k2 = k3 * 256.0, k1 = k3 * 65536.0, k0 = k3 * 16777216.0;
-                const double *dc = reinterpret_cast<const double *>(tabp + (sel ? tab_lds : 0) + (size_t)G.ne * 128);
-                const double dcr = dc[0] * k3, dci = dc[1] * k3;
+                const double *dc = reinterpret_cast<const double *>(tabp + tab_off + (size_t)G.ne * 128);
                 float2 y[NB][4];
-#pragma unroll
-                for (int b = 0; b < NB; b++)
-#pragma unroll
-                    for (int aa = 0; aa < 4; aa++) {
-                        float c2[2];
-#pragma unroll
-                        for (int pt = 0; pt < 2; pt++) {
-                            const int q = 4 * aa + 2 * pt;
-                            double v = __fma_rn((double)acc[1][b][q + 1], k3, pt ? dci : dcr);
-                            v = __fma_rn((double)acc[1][b][q], k2, v);
-                            v = __fma_rn((double)acc[0][b][q + 1], k1, v);
-                            v = __fma_rn((double)acc[0][b][q], k0, v);
-                            c2[pt] = (float)v;
-                        }
-                        y[b][aa] = make_float2(c2[0], c2[1]);
-                    }
+                planes(acc, y, dc[0] * k3, dc[1] * k3);
                 stamp(4);
                 const uint32_t mb = m_start + (uint32_t)n * kT + 4 * h;
-                if constexpr (MIX && NG > 0) {
-                    // owed: the next pass's matrix loop (or the drain behind the segment) mixes and stores them
-#pragma unroll
-                    for (int b = 0; b < NB; b++)
-#pragma unroll
-                        for (int q = 0; q < 4; q++) yp[b][q] = y[b][q];
-                    p_mb = mb;
-                    p_lo = v_lo;
-                    p_hi = v_hi;
-                    p_dphi = dphi;
-                    p_ph = phi_r + (uint64_t)D * mb * dphi;
-                } else {
-                    // the elementwise program: a lane's outputs m = mb + 256 b + a are equally spaced in two
-                    // directions inside one exactly-linear clock run (see hz_firmm.h)
-#pragma unroll 1
-                    for (int oi = 0; oi < ((EXP & 4) ? 0 : L.n_ops); oi++) {  // uniform
-                        const EwOp &o = P.op[oi];
-                        if (o.kind == EW_SCALE) {
-#pragma unroll
-                            for (int b = 0; b < NB; b++)
-#pragma unroll
-                                for (int q = 0; q < 4; q++) y[b][q] = make_float2(__fmul_rn(y[b][q].x, o.a), __fmul_rn(y[b][q].y, o.a));
-                        } else if (o.kind == EW_ROTATE) {
-#pragma unroll
-                            for (int b = 0; b < NB; b++)
-#pragma unroll
-                                for (int q = 0; q < 4; q++) y[b][q] = go_cmul(y[b][q], make_float2(o.a, o.b));
-                        } else if (L.shift_op == oi) {
-                            // the stage's phase as a 64-bit accumulator in turns: exact increments, no float64
-                            const uint64_t ph0 = phi_r + (uint64_t)D * mb * dphi;
-#pragma unroll
-                            for (int b = 0; b < NB; b++)
-#pragma unroll
-                                for (int q = 0; q < 4; q++) {
-                                    const uint64_t ph = ph0 + (uint64_t)(D * (32 * kT * b + q)) * dphi;
-                                    float sn, cs;
-                                    sincos_turns((uint32_t)(ph >> 32), sn, cs);
-                                    y[b][q] = make_float2(__fmaf_rn(y[b][q].x, cs, -(y[b][q].y * sn)), __fmaf_rn(y[b][q].x, sn, y[b][q].y * cs));
-                                }
-                        } else {
-                            // (programs with several Shift stages: float64 phases, as hz_firmm.h)
-                            const double step = sel ? rv.step : ru.step;
-                            const int64_t dj = (int64_t)((uint64_t)D * mb) - (int64_t)(sel ? rv.first : ru.first);
-                            const double ts0 = __fma_rn((double)dj, step, sel ? rv.t0 : ru.t0);
-                            double cs0, cc0, fs, fc;
-                            sincos_late(__dmul_rn(o.tau_shift, ts0), cs0, cc0);
-                            const double mult = l == 0 ? (double)D : (double)(32 * kT * D);
-                            sincos_late(__dmul_rn(o.tau_shift, __dmul_rn(mult, step)), fs, fc);
-                            const double e_s = __shfl(fs, 0), e_c = __shfl(fc, 0), b_s = __shfl(fs, 1), b_c = __shfl(fc, 1);
-                            auto mul32 = [](float2 v, double c, double sn) {
-                                const float cr = (float)c, ci = (float)sn;
-                                return make_float2(__fmaf_rn(v.x, cr, -(v.y * ci)), __fmaf_rn(v.x, ci, v.y * cr));
-                            };
-#pragma unroll
-                            for (int b = 0; b < NB; b++) {
-                                double zc = cc0, zs = cs0;
-#pragma unroll
-                                for (int q = 0; q < 4; q++) {
-                                    y[b][q] = mul32(y[b][q], zc, zs);
-                                    if (q < 3) {
-                                        const double nc = __fma_rn(zc, e_c, -(zs * e_s)), ns = __fma_rn(zc, e_s, zs * e_c);
-                                        zc = nc;
-                                        zs = ns;
-                                    }
-                                }
-                                if (b + 1 < NB) {
-                                    const double nc = __fma_rn(cc0, b_c, -(cs0 * b_s)), ns = __fma_rn(cc0, b_s, cs0 * b_c);
-                                    cc0 = nc;
-                                    cs0 = ns;
-                                }
-                            }
-                        }
-                    }
+                {
+                    program(y, mb, phi_r, dphi, sel ? rv.seg : ru.seg, wfac + (sel ? 8 : 0));
                     stamp(5);
 #pragma unroll
                     for (int b = 0; b < NB; b++) store_block(y[b], mb + (uint32_t)(32 * kT) * b, v_lo, v_hi);
@@ -789,24 +722,24 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
             // The matrix pipe goes to the wave of higher priority, then to the OLDER one -- it is not shared: the
             // second wave of a SIMD only fills the first one's gaps, and with equal priorities it would run its
             // last pass alone at the end.  A wave on its first pass outranks one that has finished a pass, so the
-            // two alternate pass by pass and finish together (measured: see DESIGN.md).
+            // two alternate pass by pass and finish together.
             if constexpr ((EXP & 32) == 0) __builtin_amdgcn_s_setprio(0);
             cur = nxt;
         }
-        if constexpr (MIX && NG > 0) {
-            // the segment's last pass of this wave
-            if (p_lo < p_hi) {
-#pragma unroll
-                for (int bb = 0; bb < NB; bb++) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) mix_one(bb, q);
-                    store_block(yp[bb], p_mb + (uint32_t)(32 * kT) * bb, p_lo, p_hi);
-                }
-            }
-        }
-        r += has_b ? 2 : 1;
+        if (!b_here) break;
+        ra = rb;
+        slot_a ^= 1;
+        a_done = true;
+        if (!has_passes(ra + 1)) break;
     }
-    run_tasks();  // (a workgroup without a pass on the matrix path)
+    if (!tasks_done) {  // (a workgroup without a pass on the matrix path)
+        for (int round = 0; round == 0 || wb + round * L.grid < L.n_task; round++) {
+            if (round) __syncthreads();
+            tasks_front(round);
+            __syncthreads();
+            tasks_back();
+        }
+    }
     stamp(7);
 }
 

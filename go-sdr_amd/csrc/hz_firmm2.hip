@@ -1,4 +1,6 @@
 // hz_firmm2.hip -- the instantiations of the persistent-pass int8 matrix FIR (hz_firmm2.h) and their launcher.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <mutex>
 #include <set>
@@ -33,20 +35,15 @@ static int launch_fmt(hipStream_t stream, int num_cus, unsigned D, const void *i
                       float2 *new_hist, const uint8_t *rhist, uint8_t *new_rhist, const float2 *taps, size_t n, const Geom &g,
                       Plan L, const EwProgram &P, const Fix &F) {
     if (D != 8) return HZSDR_ERR_INVALID_ARGUMENT;
-    const size_t lds = lds_bytes((int)D, g.ks, g.ne);
+    const size_t lds = lds_bytes((int)D, g.ks, g.ne, g.ntaps);
     // one workgroup per CU; a call with fewer passes than CUs: one pass per workgroup
     const int grid = std::max(1, std::min(num_cus, L.n_pass));
     L.grid = grid;
-    // the program of the headline chain -- one Shift, optionally one Gain behind it -- mixes inside the next
-    // pass's matrix loop (MIX); the straight-line loop exists for the 1024-tap window (17 groups)
-    const bool mix = L.shift_op == 0 && (P.n == 1 || (P.n == 2 && P.op[1].kind == EW_SCALE));
-    if (mix && P.n == 2) L.gain = P.op[1].a;
     unsigned long long *no_stamps = nullptr;
-    if (g.ks == 17 * 4) {
-        if (mix) return launch(fir_mm2_kernel<FMT, 8, 17, 1>, dim3(grid), lds, stream, in, out, hist, new_hist, rhist, new_rhist, taps, n, g, L, P, F, no_stamps);
-        return launch(fir_mm2_kernel<FMT, 8, 17, 0>, dim3(grid), lds, stream, in, out, hist, new_hist, rhist, new_rhist, taps, n, g, L, P, F, no_stamps);
-    }
-    return launch(fir_mm2_kernel<FMT, 8, 0, 0>, dim3(grid), lds, stream, in, out, hist, new_hist, rhist, new_rhist, taps, n, g, L, P, F, no_stamps);
+    // (the straight-line matrix loop exists for the 1024-tap window: 17 groups)
+    if (g.ks == 17 * 4)
+        return launch(fir_mm2_kernel<FMT, 8, 17>, dim3(grid), lds, stream, in, out, hist, new_hist, rhist, new_rhist, taps, n, g, L, P, F, no_stamps);
+    return launch(fir_mm2_kernel<FMT, 8, 0>, dim3(grid), lds, stream, in, out, hist, new_hist, rhist, new_rhist, taps, n, g, L, P, F, no_stamps);
 }
 
 int launch_fir(hipStream_t stream, int num_cus, int fmt, unsigned D, const void *in, float2 *out, const float2 *hist,
