@@ -202,33 +202,49 @@ def main():
     m = nfft // D
     flops = (D * 5 * m * (np.log2(m) - 1) + 256 * (24 * 6 + 30 * 2) + 5 * m * np.log2(m)) / valid * n
     matrix = chain.last_fir_path() == hz.FIR_PATH_MATRIX
-    # int8 matrix form: every output is 1024 complex taps x a complex sample = 4 real MACs per tap,
-    # in FOUR int8 digit planes (32-bit fixed-point taps x 8-bit samples): 2 ops per MAC
-    mm_ops = 4 * 4 * 2 * ntaps * (n // D)
+    kern = chain.last_fir_kernel() if hasattr(chain, "last_fir_kernel") else None
+    # ---- the roofline object follows SURVEY.md 8(d): the HBM view leads ------------------------------
+    #   achieved = algorithmic bytes per launch (3 B per input sample: 2 read + 8/D written) / the dominant
+    #   kernel's average launch duration (one HIP-event pair around the timed steps, on the kernel's stream)
+    #   fp32_vector_frac: 8(d)'s >= 170 flop per input sample against the 157.3 TFLOP/s vector peak
+    #   mfma_algorithmic_frac: the direct form's irreducible work -- taps x outputs x 4 real products per complex
+    #   tap x 2 ops -- against the dense int8 peak
+    #   mfma_issue: the int8 operations the kernel EXECUTES (x 4 digit planes of the 32-bit fixed-point taps,
+    #   and the tile windows' zero padding): an implementation figure, how busy the matrix pipe is
+    t_s = kernel_ms * 1e-3
     hbm = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": round(achieved / HBM_PEAK_GBS, 4)}
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None}
+    fp32_vec = 170.0 * n / t_s / 1e12 / FP32_PEAK_TFLOPS
     if matrix:
-        tops = mm_ops / (kernel_ms * 1e-3) / 1e12
-        roof = {
-            "bound": "mfma", "achieved": round(tops, 1), "peak": I8_PEAK_TOPS, "unit": "TFLOP/s",
-            "frac": round(tops / I8_PEAK_TOPS, 4), "traffic": None,
-            "kernel": "hz::mm::fir_mm_kernel<u8, D = 8>",
+        passes_form = kern == getattr(hz, "FIR_KERNEL_MATRIX_PASSES", -1)
+        tile, steps = (8, 68) if passes_form else (16, 72)       # outputs per tile, 32-byte window steps (hz_firmm2.h / hz_firmm.h)
+        alg_ops = 4 * 2 * ntaps * (n // D)                        # the direct form, no digit planes
+        exe_ops = 4 * (n // D // tile) * steps * 32 * 32 * 2      # planes x tiles x steps x (32 rows x 32 bytes) x 2
+        roof = dict(hbm)
+        roof.update({
+            "kernel": ("hz::mm2::fir_mm2_kernel<u8, D = 8, 17 groups>" if passes_form else "hz::mm::fir_mm_kernel<u8, D = 8>"),
             "kernel_ms": round(kernel_ms, 4),
             "kernel_ms_is": "device time per chain_run (one kernel), one HIP-event pair around the timed "
                             "loop / steps",
-            "algorithmic_ops_per_launch": int(mm_ops),
-            "ops_are": "int8 multiply-adds x 2: taps x outputs x 4 real products per complex tap x 4 digit "
-                       "planes of the 32-bit fixed-point taps (the zero padding of the tile windows, "
-                       "+12 %, is not counted)",
             "algorithmic_bytes_per_launch": int(alg_bytes),
-            "hbm": hbm,
-            "note": "the chain is above the HBM ridge (3 B/sample): the int8 matrix cores bind; the "
-                    "matrix pipe is busy 94 % of the matrix loop and ~44 % of the kernel "
-                    "(profiles/r02_mfma_fir.txt, r02_sq_counters.txt); the rest is the input burst before and "
-                    "the epilogue after the loop of workgroups that all run in phase",
-        }
+            "fp32_vector_frac": round(fp32_vec, 4),
+            "mfma_algorithmic_frac": round(alg_ops / t_s / 1e12 / I8_PEAK_TOPS, 4),
+            "mfma_issue": {
+                "executed_int8_ops_per_launch": int(exe_ops),
+                "ops_are": "int8 multiply-adds x 2 as issued: 4 base-256 digit planes of the 32-bit fixed-point "
+                           "taps x tiles x window steps x 32 rows x 32 bytes (the tile windows' zero padding "
+                           "included) -- an implementation figure, not algorithmic work",
+                "achieved": round(exe_ops / t_s / 1e12, 1), "peak": I8_PEAK_TOPS, "unit": "Top/s",
+                "frac": round(exe_ops / t_s / 1e12 / I8_PEAK_TOPS, 4),
+            },
+            "note": "3 B/sample puts the chain far above the HBM ridge (the 50 MB of a buffer are 8 us at 6.3 TB/s): "
+                    "what binds is the issue of int8 MFMAs at the clock the chip holds under them (~1.55 GHz: the "
+                    "1088 MFMAs per SIMD of a 2^24-sample buffer are 22.4 us, profiles/r03_mfma_fir2.txt), then the "
+                    "kernel's first ~5.5 us (cold instruction and scalar caches, the first bytes from HBM) and the "
+                    "vector instructions of the epilogues, which run beside the SIMD partner's matrix loop",
+        })
     else:
-        roof = dict(hbm, traffic=None,
+        roof = dict(hbm,
                     kernel="hz::fir_decimate_kernel16<4096, u8, fold 8, late> + hz::fir_synth_kernel16<4096, 8, late>",
                     kernel_ms=round(kernel_ms, 4),
                     kernel_ms_is="device time per chain_run (both kernels and the gap between them), one "
@@ -248,7 +264,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "u8 x int32 fixed-point taps (int8 MFMA digit planes, exact) -> c64(f32), NCO phase f64"
+        "dtype": "u8 x int32 fixed-point taps (int8 MFMA digit planes, exact) -> c64(f32), NCO phase 64-bit fixed point"
                  if matrix else "u8->c64(f32), NCO phase f64",
         "data": f"synthetic (splitmix64 u8 IQ, seeds 9+rank+101i; {nbuf} distinct buffers in rotation, "
                 f"{nbuf * 2 * n >> 20} MiB resident in HBM); windowed-sinc taps",
@@ -270,12 +286,12 @@ def main():
     chain.close()
     # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc
     # passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_summary.py), not from this process.
-    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
     if n == (1 << 24) and os.path.exists(tpath):
         try:
             tk = json.load(open(tpath))["kernels"]
             if matrix:
-                keys = [k for k in tk if "fir_mm_kernel<2, 8" in k]
+                keys = [k for k in tk if ("fir_mm2_kernel<2, 8, 17" in k if passes_form else "fir_mm_kernel<2, 8" in k)]
                 want = 1
             else:
                 keys = [k for k in tk if "fir_decimate_kernel16<4096, 2, 8, true" in k
@@ -283,7 +299,7 @@ def main():
                 want = 2
             if len(keys) == want:
                 result["roofline"]["traffic"] = sum(tk[k]["hbm_bytes"] for k in keys)
-                result["roofline"]["traffic_source"] = ("profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + "
+                result["roofline"]["traffic_source"] = ("profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + "
                                                         "WRITE_SIZE, the kernel(s) of a chain_run)")
         except (StopIteration, KeyError, ValueError):
             pass
@@ -316,6 +332,27 @@ def main():
         _, ms = timed(torch, lambda: ch.run(x, y), k, w)
         extra["chain_transform_kernels"] = rate(n, float(np.median(ms)), 2 + 8 / D)
         ch.close()
+        # the same chain on the first int8 matrix kernel (round 2: one round of 2048-output chunk workgroups)
+        os.environ["HZ_MM_V1"] = "1"
+        ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D)
+        del os.environ["HZ_MM_V1"]
+        ch.set_time(1.0)
+        _, ms = timed(torch, lambda: ch.run(x, y), k, w)
+        extra["chain_matrix_chunks_kernel"] = dict(rate(n, float(np.median(ms)), 2 + 8 / D), kernel=ch.last_fir_kernel())
+        ch.close()
+        # ONE launch over 2^26 samples (128 MiB of u8): the kernel's first and last microseconds once per 64 passes
+        # of a workgroup instead of once per 16
+        if args.log2n == 24:
+            n26 = 1 << 26
+            x26 = torch.from_numpy(synth_u8(77, n26)).cuda()
+            y26 = torch.zeros(n26 // D, dtype=torch.complex64, device="cuda")
+            ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D)
+            ch.set_time(1.0)
+            _, ms = timed(torch, lambda: ch.run(x26, y26), 10, 2)
+            extra["chain_2p26"] = dict(rate(n26, float(np.median(ms)), 2 + 8 / D), kernel=ch.last_fir_kernel(),
+                                       ms_per_2p24_samples=round(float(np.median(ms)) / 4, 4))
+            ch.close()
+            del x26, y26
         # the two implementations of the terminal over tap counts and factors (ms per 2^24 samples)
         paths = {}
         for dd, nt in ((8, 64), (8, 256), (8, 1024), (16, 256), (16, 1024), (16, 2047), (32, 1024), (64, 1024)):
@@ -368,6 +405,13 @@ def main():
         o8 = torch.zeros(n // 8, dtype=torch.complex64, device="cuda")
         _, ms = timed(torch, lambda: ctx.downsample(o8, xi, 8), k, w)
         extra["downsample8_i16"] = rate(n, float(np.median(ms)), 5)
+        # cfg 4, north-star form: a designed FIR-decimate by 8 from i16 (polyphase: 256 and 1024 taps; 4 + 8/8 B per
+        # input sample), on the overlap-save transform kernels (i16 has no matrix form)
+        for nt in (256, 1024):
+            ch = ctx.chain(hz.FMT_I16, 200_000_000).fir_decimate(lowpass_taps(nt, 1.0 / 16), 8)
+            _, ms = timed(torch, lambda: ch.run(xi, o8), 12, 2)
+            extra[f"fir_decimate8_i16_{nt}taps"] = dict(rate(n, float(np.median(ms)), 5), path=ch.last_fir_path())
+            ch.close()
         del xi, o8
         # cfg 5 on one GPU: 4-channel c64 beamform (40 B/output sample)
         chans = [torch.from_numpy(synth_c64(5 + i, n)).cuda() for i in range(4)]

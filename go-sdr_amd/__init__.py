@@ -21,7 +21,8 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (CONV_CONVOLVE, CONV_CROSS_CORRELATE, FFT_BACKWARD, FFT_FORWARD, FIR_PATH_MATRIX,
+from ._capi import (CONV_CONVOLVE, CONV_CROSS_CORRELATE, FFT_BACKWARD, FFT_FORWARD, FIR_KERNEL_MATRIX_CHUNKS,
+                    FIR_KERNEL_MATRIX_PASSES, FIR_KERNEL_NONE, FIR_KERNEL_TRANSFORM, FIR_PATH_MATRIX,
                     FIR_PATH_NONE, FIR_PATH_TRANSFORM, FMT_C64, FMT_I8, FMT_I16, FMT_U8, MEM_DEVICE,
                     MEM_HOST, lib)
 
@@ -589,6 +590,12 @@ class Chain:
         """FIR_PATH_NONE / _TRANSFORM / _MATRIX: the kernels the last run of a FIR-decimate chain used."""
         p = C.c_int32(0)
         self.ctx._ck(lib.hzsdr_chain_last_fir_path(self._h, C.byref(p)))
+        return p.value
+
+    def last_fir_kernel(self):
+        """FIR_KERNEL_NONE / _TRANSFORM / _MATRIX_CHUNKS (csrc/hz_firmm.h) / _MATRIX_PASSES (csrc/hz_firmm2.h)."""
+        p = C.c_int32(0)
+        self.ctx._ck(lib.hzsdr_chain_last_fir_kernel(self._h, C.byref(p)))
         return p.value
 
     def ring(self, slot_length, slots=4):

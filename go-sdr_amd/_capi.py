@@ -51,6 +51,7 @@ FMT_C64, FMT_U8, FMT_I16, FMT_I8 = 1, 2, 3, 4
 MEM_HOST, MEM_DEVICE = 0, 1
 FFT_BACKWARD, FFT_FORWARD = 0, 1
 FIR_PATH_NONE, FIR_PATH_TRANSFORM, FIR_PATH_MATRIX = 0, 1, 2
+FIR_KERNEL_NONE, FIR_KERNEL_TRANSFORM, FIR_KERNEL_MATRIX_CHUNKS, FIR_KERNEL_MATRIX_PASSES = 0, 1, 2, 3
 CONV_CONVOLVE, CONV_CROSS_CORRELATE = 0, 1
 
 (OK, ERR_FORMAT_MISMATCH, ERR_FORMAT_UNKNOWN, ERR_DST_TOO_SMALL, ERR_CONVERSION_NOT_IMPLEMENTED,
@@ -154,6 +155,7 @@ SIGNATURES = {
     "hzsdr_chain_set_time": (i32, [vp, f64]),
     "hzsdr_chain_time": (i32, [vp, C.POINTER(f64)]),
     "hzsdr_chain_last_fir_path": (i32, [vp, C.POINTER(i32)]),
+    "hzsdr_chain_last_fir_kernel": (i32, [vp, C.POINTER(i32)]),
     "hzsdr_chain_free": (i32, [vp]),
     "hzsdr_ring_create": (i32, [vp, sz, i32, pvp]),
     "hzsdr_ring_iq_buffer": (i32, [vp, pvp, psz, psz]),

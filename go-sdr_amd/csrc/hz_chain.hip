@@ -1268,6 +1268,13 @@ int hzsdr_chain_last_fir_path(const hzsdr_chain *c, int *path) {
     return HZSDR_OK;
 }
 
+int hzsdr_chain_last_fir_kernel(const hzsdr_chain *c, int *kernel) {
+    if (!c || !kernel) return HZSDR_ERR_INVALID_ARGUMENT;
+    *kernel = c->last_path == HZSDR_FIR_PATH_MATRIX ? (c->mm_ver == 2 ? HZSDR_FIR_KERNEL_MATRIX_PASSES : HZSDR_FIR_KERNEL_MATRIX_CHUNKS)
+                                                    : c->last_path;
+    return HZSDR_OK;
+}
+
 int hzsdr_chain_mix_in_order(hzsdr_chain *c, int in_order) {
     if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
     c->mix_in_order = in_order != 0;

@@ -46,7 +46,7 @@ constexpr int kWaves = 8;    // two per SIMD
 constexpr int kThreads = 64 * kWaves;
 constexpr int kFixOut = 16;  // outputs per fix-up task
 constexpr int kHistPer = 64; // samples per history task
-constexpr int kMaxRuns = 8;   // clock runs of a call that take the matrix path (more: the call keeps the transforms)
+constexpr int kMaxRuns = 16;  // clock runs of a call that take the matrix path (more: the call keeps the transforms)
 constexpr int kMaxFix = kNcoMaxSegs + 2;
 constexpr int kU = 12;       // 16-byte pieces per lane of a pass image, any window (768 pieces = 12 KB at most)
 

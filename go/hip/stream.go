@@ -227,6 +227,14 @@ func (ch *Chain) LastFIRPath() (int, error) {
 	rc := C.hzsdr_chain_last_fir_path(ch.c, &p)
 	return int(p), toErr(ch.x.c, rc)
 }
+
+// LastFIRKernel reports which kernel that was (C.HZSDR_FIR_KERNEL_TRANSFORM, _MATRIX_CHUNKS, _MATRIX_PASSES;
+// C.HZSDR_FIR_KERNEL_NONE before the first run): for logs and benchmarks.
+func (ch *Chain) LastFIRKernel() (int, error) {
+	var k C.int
+	rc := C.hzsdr_chain_last_fir_kernel(ch.c, &k)
+	return int(k), toErr(ch.x.c, rc)
+}
 func (ch *Chain) Close() error { return toErr(ch.x.c, C.hzsdr_chain_free(ch.c)) }
 
 // Reader wraps the chain as ONE sdr.Reader behind stream.ReadTransformer: `block` input

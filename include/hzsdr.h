@@ -369,6 +369,17 @@ int hzsdr_chain_mix_in_order(hzsdr_chain *c, int in_order);
 #define HZSDR_FIR_PATH_TRANSFORM 1
 #define HZSDR_FIR_PATH_MATRIX 2
 int hzsdr_chain_last_fir_path(const hzsdr_chain *c, int *path);
+/* The same question one level down: WHICH matrix kernel (logs, benchmarks, the tests that pin a kernel):
+ *   HZSDR_FIR_KERNEL_MATRIX_PASSES  csrc/hz_firmm2.h -- one persistent workgroup per CU, the tap table in LDS,
+ *                                   512-output passes from a queue: factor 8, up to ~1150 taps
+ *   HZSDR_FIR_KERNEL_MATRIX_CHUNKS  csrc/hz_firmm.h -- one round of 2048-output chunk workgroups: the other
+ *                                   factors and tap counts of HZSDR_FIR_PATH_MATRIX (and HZ_MM_V1=1)
+ * (no reference counterpart: stream.* Readers have one implementation each.) */
+#define HZSDR_FIR_KERNEL_NONE 0
+#define HZSDR_FIR_KERNEL_TRANSFORM 1
+#define HZSDR_FIR_KERNEL_MATRIX_CHUNKS 2
+#define HZSDR_FIR_KERNEL_MATRIX_PASSES 3
+int hzsdr_chain_last_fir_kernel(const hzsdr_chain *c, int *kernel);
 /* Samples the chain would produce for n_in input samples, and how many input
  * samples it consumes (whole blocks only for block-structured terminals). */
 int hzsdr_chain_plan(const hzsdr_chain *c, size_t n_in, size_t *n_consumed, size_t *n_out);

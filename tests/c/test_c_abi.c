@@ -250,6 +250,9 @@ static void chain_and_ring(void) { /* go/hip/stream.go Chain, go/hip/ring.go */
     int path = -1;
     OK(hzsdr_chain_last_fir_path(c, &path));
     CHECK(path == HZSDR_FIR_PATH_TRANSFORM || path == HZSDR_FIR_PATH_MATRIX);
+    int kern = -1;
+    OK(hzsdr_chain_last_fir_kernel(c, &kern));
+    CHECK(kern >= HZSDR_FIR_KERNEL_TRANSFORM && kern <= HZSDR_FIR_KERNEL_MATRIX_PASSES);
     OK(hzsdr_chain_set_time(c, 1.0));
     OK(hzsdr_chain_reset(c));
     /* the ring: ONE pinned region for all slots (IQBufferAllocator), acquire / fill / submit / pop */

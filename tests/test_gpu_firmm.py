@@ -114,6 +114,10 @@ def test_matrix_form_against_the_oracle(hz, ctx, orc, name):
     for a, b in zip(cuts[:-1], cuts[1:]):
         assert ch.run(x[a:b], out[a // D:b // D]) == (b - a, (b - a) // D)
         assert ch.last_fir_path() == hz.FIR_PATH_MATRIX, (name, a)
+        # factor 8 up to ~1150 taps: the persistent-pass kernel (csrc/hz_firmm2.h); the rest: chunk workgroups
+        want_kernel = hz.FIR_KERNEL_MATRIX_PASSES if D == 8 and c["ntaps"] <= 1100 and not os.environ.get("HZ_MM_V1") \
+            else hz.FIR_KERNEL_MATRIX_CHUNKS
+        assert ch.last_fir_kernel() == want_kernel, (name, a, ch.last_fir_kernel())
     assert_fir_close(out, want, taps, xmax, name)
     # exact integer filter sums: what is left is one float32 rounding of the filter output and one per
     # elementwise stage (the transform path: 1.7e-7 with a single stage)

@@ -4,7 +4,7 @@
 # (FETCH_SIZE / WRITE_SIZE in separate passes), SQ wave-state counters, big-FFT timings.
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02'
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/prof_$tag
 export TMPDIR=/tmp
 mkdir -p $out
@@ -24,8 +24,10 @@ tools/bin/fir_ablate > $out/fir_ablate.txt 2>&1
 REPS=6 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $out/sq3 -- python3 tools/prof_kernels.py chain > /dev/null 2>&1
 python3 tools/pmc_sq.py $out/sq3 >> $out/sq_counters.txt
 tools/bin/mfma_fir > $out/mfma_fir.txt 2>&1
+tools/bin/mfma_fir2 > $out/mfma_fir2.txt 2>&1
 tools/bin/mfma_rate > $out/mfma_rate.txt 2>&1
 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" > $out/firmm_probe.txt
+HZ_MM_V1=1 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" >> $out/firmm_probe.txt
 HZ_FIR_FFT=1 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" >> $out/firmm_probe.txt
 for f in $out/bench_trace/*/*kernel_stats.csv $out/fft_trace/*/*kernel_stats.csv $out/kern_trace/*/*kernel_stats.csv; do echo "== $f"; cut -d, -f1-4 $f | cut -c1-160 | head -14; done
 cat $out/sq_counters.txt | head -60

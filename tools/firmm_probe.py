@@ -34,7 +34,9 @@ def main():
         ev[i + 1].record(s)
     torch.cuda.synchronize()
     per = [ev[i].elapsed_time(ev[i + 1]) * 1e3 for i in range(40)]
-    print("path:", "transform kernels" if os.environ.get("HZ_FIR_FFT") else "int8 matrix form",
+    kern = {hz.FIR_KERNEL_TRANSFORM: "transform kernels", hz.FIR_KERNEL_MATRIX_CHUNKS: "int8 matrix form, chunk workgroups (hz_firmm.h)",
+            hz.FIR_KERNEL_MATRIX_PASSES: "int8 matrix form, persistent passes (hz_firmm2.h)"}.get(ch.last_fir_kernel(), "?")
+    print("path:", kern,
           "D", D, "taps", ntaps)
     print("mean %.1f us  median %.1f us  min %.1f us  max %.1f us" %
           (sum(per) / len(per), sorted(per)[len(per) // 2], min(per), max(per)))
