@@ -1,0 +1,364 @@
+//go:build sdr.hip
+
+package hip
+
+// #include <hzsdr.h>
+import "C"
+
+import (
+	"fmt"
+
+	"hz.tools/rf"
+	"hz.tools/sdr"
+	"hz.tools/sdr/fft"
+	"hz.tools/sdr/stream"
+)
+
+// Readers has the reference's stream.* Reader constructors, name for name and argument for
+// argument, over one GPU context:
+//
+//	s := ctx.Readers()
+//	r, err := s.ShiftReader(r, 100*rf.KHz)   // stream.ShiftReader(r, 100*rf.KHz)
+//	r = s.Gain(r, 0.5)                       // stream.Gain(r, 0.5)
+//
+// so a caller swaps `stream.` for `s.` and keeps the rest of its pipeline. Each Reader does what
+// the reference's does in the same order (same format checks, same sentinel errors, same
+// pull-style Read for Shift / Gain / Multiply / Add, the same ReadTransformer scaffold with
+// 32 Ki-sample blocks for Decimate / Downsample and filter-length blocks for Convolution);
+// only the buffer arithmetic runs on the GPU. A 32 Ki block is launch-bound (INTEGRATION.md,
+// "What the drop-in costs"): pipelines that care about throughput fuse their stages with
+// Context.NewChain and feed it blocks of 2^20 samples or the pinned ring.
+type Readers struct{ x *Context }
+
+// Readers returns the constructor set bound to this context.
+func (x *Context) Readers() Readers { return Readers{x} }
+
+// ---- stream.ShiftReader (stream/shifter.go:89-102) ----------------------------------------
+
+type shiftReader struct {
+	r     sdr.Reader
+	shift rf.Hz
+	sh    *Shifter
+}
+
+func (sr *shiftReader) SampleFormat() sdr.SampleFormat { return sr.r.SampleFormat() }
+func (sr *shiftReader) SampleRate() uint               { return sr.r.SampleRate() }
+
+// Read is shiftReader.Read (stream/shifter.go:44-64): c64 only, the clock carries on from
+// buffer to buffer.
+func (sr *shiftReader) Read(s sdr.Samples) (int, error) {
+	if s.Format() != sdr.SampleFormatC64 {
+		return 0, sdr.ErrSampleFormatUnknown
+	}
+	n, err := sr.r.Read(s)
+	if err != nil {
+		return n, err
+	}
+	sr.sh.ShiftBuffer(sr.shift, s.Slice(0, n).(sdr.SamplesC64))
+	return n, nil
+}
+
+// Close releases the clock held on the C side (the reference's closure is garbage collected).
+func (sr *shiftReader) Close() error { return sr.sh.Close() }
+
+// ShiftReader is stream.ShiftReader (stream/shifter.go:89).
+func (s Readers) ShiftReader(r sdr.Reader, shift rf.Hz) (sdr.Reader, error) {
+	if r.SampleFormat() != sdr.SampleFormatC64 {
+		return nil, sdr.ErrSampleFormatUnknown
+	}
+	sh, err := s.x.NewShifter(r.SampleRate())
+	if err != nil {
+		return nil, err
+	}
+	return &shiftReader{r: r, shift: shift, sh: sh}, nil
+}
+
+// ---- stream.Gain (stream/gain.go:30-64) -------------------------------------------------
+
+type gain struct {
+	x *Context
+	v float32
+	r sdr.Reader
+}
+
+func (g *gain) SampleFormat() sdr.SampleFormat { return g.r.SampleFormat() }
+func (g *gain) SampleRate() uint               { return g.r.SampleRate() }
+
+// Scale is gain.Scale (stream/gain.go:39-48): c64 only.
+func (g *gain) Scale(s sdr.Samples) error {
+	c, ok := s.(sdr.SamplesC64)
+	if !ok {
+		return sdr.ErrSampleFormatUnknown
+	}
+	return g.x.Scale(c, g.v)
+}
+
+func (g *gain) Read(s sdr.Samples) (int, error) {
+	i, err := g.r.Read(s)
+	if err != nil {
+		return i, err
+	}
+	return i, g.Scale(s.Slice(0, i))
+}
+
+// Gain is stream.Gain (stream/gain.go:30).
+func (s Readers) Gain(r sdr.Reader, v float32) sdr.Reader { return &gain{x: s.x, v: v, r: r} }
+
+// ---- stream.Multiply (stream/multiply.go:27-238) ------------------------------------------
+
+// MultiplyReader is what Multiply returns: an sdr.Reader with the reference's undocumented
+// SetMultiplier (stream/multiply.go:34-36; Beamform.SetPhaseAngles calls it).
+type MultiplyReader interface {
+	sdr.Reader
+	SetMultiplier(m complex64)
+}
+
+type multiplyReader struct {
+	x *Context
+	m complex64
+	r sdr.Reader
+}
+
+func (mr *multiplyReader) SetMultiplier(m complex64)      { mr.m = m }
+func (mr *multiplyReader) SampleFormat() sdr.SampleFormat { return mr.r.SampleFormat() }
+func (mr *multiplyReader) SampleRate() uint               { return mr.r.SampleRate() }
+
+// Read is multiplyReader.Read (stream/multiply.go:46-70), the m == 1 short cut included.
+func (mr *multiplyReader) Read(s sdr.Samples) (int, error) {
+	if s.Format() != sdr.SampleFormatC64 {
+		return 0, sdr.ErrSampleFormatMismatch
+	}
+	i, err := mr.r.Read(s)
+	if err != nil {
+		return i, err
+	}
+	if mr.m == 1 {
+		return i, nil
+	}
+	return i, mr.x.Multiply(s.Slice(0, i).(sdr.SamplesC64), mr.m)
+}
+
+// tableMultiplyReader is uint8MultiplyReader / int8MultiplyReader (stream/multiply.go:91-238):
+// the 65 536-entry table of rotated samples lives on the GPU, rebuilt by SetMultiplier.
+type tableMultiplyReader struct {
+	t *MultiplyTable
+	r sdr.Reader
+}
+
+func (tr *tableMultiplyReader) SetMultiplier(m complex64)      { _ = tr.t.SetMultiplier(m) }
+func (tr *tableMultiplyReader) SampleFormat() sdr.SampleFormat { return tr.r.SampleFormat() }
+func (tr *tableMultiplyReader) SampleRate() uint               { return tr.r.SampleRate() }
+func (tr *tableMultiplyReader) Close() error                   { return tr.t.Close() }
+
+func (tr *tableMultiplyReader) Read(s sdr.Samples) (int, error) {
+	if s.Format() != tr.r.SampleFormat() {
+		return 0, sdr.ErrSampleFormatMismatch
+	}
+	i, err := tr.r.Read(s)
+	if err != nil {
+		return i, err
+	}
+	return i, tr.t.Apply(s.Slice(0, i))
+}
+
+// Multiply is stream.Multiply (stream/multiply.go:74): c64 by arithmetic, u8 / i8 by table.
+func (s Readers) Multiply(r sdr.Reader, m complex64) (sdr.Reader, error) {
+	switch r.SampleFormat() {
+	case sdr.SampleFormatI8, sdr.SampleFormatU8:
+		t, err := s.x.NewMultiplyTable(r.SampleFormat(), m)
+		if err != nil {
+			return nil, err
+		}
+		return &tableMultiplyReader{t: t, r: r}, nil
+	case sdr.SampleFormatC64:
+		return &multiplyReader{x: s.x, r: r, m: m}, nil
+	default:
+		return nil, sdr.ErrSampleFormatUnknown
+	}
+}
+
+// ---- stream.Add (stream/add.go:41-185) ----------------------------------------------------
+
+type addReader struct {
+	x            *Context
+	sampleFormat sdr.SampleFormat
+	sampleRate   uint
+	readers      []sdr.Reader
+	err          error
+}
+
+func (ar *addReader) SampleFormat() sdr.SampleFormat { return ar.sampleFormat }
+func (ar *addReader) SampleRate() uint               { return ar.sampleRate }
+
+// Read is addReader.Read (stream/add.go:121-185): ReadFull of every reader in order, then
+// out = ((+0 + b0) + b1) + ... in ONE kernel (hzsdr_sum) instead of K + 1 passes; sticky errors.
+func (ar *addReader) Read(s sdr.Samples) (int, error) {
+	if ar.err != nil {
+		return 0, ar.err
+	}
+	switch s.Format() {
+	case sdr.SampleFormatC64, sdr.SampleFormatI16, sdr.SampleFormatI8:
+	default:
+		return 0, sdr.ErrSampleFormatUnknown
+	}
+	buffers := make([]sdr.Samples, len(ar.readers))
+	for i, reader := range ar.readers {
+		var err error
+		buffers[i], err = sdr.MakeSamples(s.Format(), s.Length())
+		if err != nil {
+			ar.err = err
+			return 0, err
+		}
+		if _, err = sdr.ReadFull(reader, buffers[i]); err != nil {
+			ar.err = err
+			return 0, err
+		}
+	}
+	if err := ar.x.Sum(s, buffers); err != nil {
+		ar.err = err
+		return 0, err
+	}
+	return s.Length(), nil
+}
+
+// Add is stream.Add (stream/add.go:41): c64, i16 or i8 readers of one format and rate; at most
+// sixteen of them on the GPU (hzsdr_sum).
+func (s Readers) Add(readers ...sdr.Reader) (sdr.Reader, error) {
+	switch len(readers) {
+	case 0:
+		return nil, fmt.Errorf("stream.Add: No readers passed")
+	case 1:
+		return readers[0], nil
+	}
+	if len(readers) > 16 {
+		return nil, fmt.Errorf("hip.Add: at most 16 readers")
+	}
+	sampleFormat, sampleRate := readers[0].SampleFormat(), readers[0].SampleRate()
+	switch sampleFormat {
+	case sdr.SampleFormatC64, sdr.SampleFormatI16, sdr.SampleFormatI8:
+	default:
+		return nil, sdr.ErrSampleFormatUnknown
+	}
+	for _, reader := range readers {
+		if reader.SampleFormat() != sampleFormat {
+			return nil, fmt.Errorf("stream.Add: Readers are not all the same format")
+		}
+		if reader.SampleRate() != sampleRate {
+			return nil, fmt.Errorf("stream.Add: Readers are not all the same rate")
+		}
+	}
+	return &addReader{x: s.x, sampleFormat: sampleFormat, sampleRate: sampleRate, readers: readers}, nil
+}
+
+// ---- stream.DecimateReader / DownsampleReader (stream/decimate.go:34-57, downsample.go:47-66) ----
+
+// DecimateReader is stream.DecimateReader: 32 Ki-sample blocks, the offset counted (and, as in
+// the reference, ignored by DecimateBuffer: the phase restarts with every block).
+func (s Readers) DecimateReader(in sdr.Reader, factor uint) (sdr.Reader, error) {
+	offset := 0
+	return stream.ReadTransformer(in, stream.ReadTransformerConfig{
+		InputBufferLength:  32 * 1024,
+		OutputBufferLength: 32 * 1024,
+		OutputSampleRate:   in.SampleRate() / factor,
+		OutputSampleFormat: in.SampleFormat(),
+		Proc: func(inBuf sdr.Samples, outBuf sdr.Samples) (int, error) {
+			n, err := s.x.DecimateBuffer(outBuf, inBuf, factor, offset)
+			offset += inBuf.Length()
+			return n, err
+		},
+	})
+}
+
+// DownsampleReader is stream.DownsampleReader: the boxcar mean of `factor` samples, c64 out.
+func (s Readers) DownsampleReader(in sdr.Reader, factor uint) (sdr.Reader, error) {
+	offset := 0
+	return stream.ReadTransformer(in, stream.ReadTransformerConfig{
+		InputBufferLength:  32 * 1024,
+		OutputBufferLength: 32 * 1024,
+		OutputSampleRate:   in.SampleRate() / factor,
+		OutputSampleFormat: sdr.SampleFormatC64,
+		Proc: func(inBuf sdr.Samples, outBuf sdr.Samples) (int, error) {
+			n, err := s.x.DownsampleBuffer(outBuf, inBuf, factor, offset)
+			offset += inBuf.Length()
+			return n, err
+		},
+	})
+}
+
+// ---- stream.ConvolutionReader (stream/convolution.go:36-82) -------------------------------
+
+// ConvolutionReader is stream.ConvolutionReader: block-circular filtering with blocks of
+// len(filter) samples, the filter given in the frequency domain. `planner` keeps the
+// reference's signature and is not called: forward transform, bin product and backward
+// transform of a block are one kernel (hzsdr_convolution_blocks); pass ctx.Planner or nil.
+func (s Readers) ConvolutionReader(r sdr.Reader, planner fft.Planner, filter []complex64) (sdr.Reader, error) {
+	_ = planner
+	if r.SampleFormat() != sdr.SampleFormatC64 {
+		return nil, sdr.ErrSampleFormatUnknown
+	}
+	fftLength := len(filter)
+	return stream.ReadTransformer(r, stream.ReadTransformerConfig{
+		InputBufferLength:  fftLength,
+		OutputBufferLength: fftLength,
+		OutputSampleFormat: sdr.SampleFormatC64,
+		OutputSampleRate:   r.SampleRate(),
+		Proc: func(inI sdr.Samples, outI sdr.Samples) (int, error) {
+			in, ok := inI.(sdr.SamplesC64)
+			if !ok {
+				return 0, sdr.ErrSampleFormatUnknown
+			}
+			out, ok := outI.(sdr.SamplesC64)
+			if !ok {
+				return 0, sdr.ErrSampleFormatUnknown
+			}
+			return s.x.ConvolutionBlocks(out[:in.Length()], in, filter)
+		},
+	})
+}
+
+// ---- stream.ReadBeamform (stream/beamform.go:131-171) -------------------------------------
+
+// Beamform is stream.Beamform: the weighted sum of coherent readers as one sdr.Reader.
+type Beamform struct {
+	sdr.Reader
+	readers sdr.Readers
+	config  stream.BeamformConfig
+}
+
+// SetPhaseAngles is Beamform.SetPhaseAngles (stream/beamform.go:131-139): applied between reads.
+func (b *Beamform) SetPhaseAngles(angles []complex64) error {
+	if len(angles) != len(b.readers) {
+		return fmt.Errorf("Beamform.SetPhaseAngles: angles must match the reader length")
+	}
+	for i, reader := range b.readers {
+		reader.(MultiplyReader).SetMultiplier(angles[i])
+	}
+	return nil
+}
+
+// ReadBeamform is stream.ReadBeamform (stream/beamform.go:148): ConvertReader to c64, Multiply
+// by the channel's weight, Add -- the reference's own composition over the GPU Readers, so the
+// order of the sum (and its +0 start) is the reference's. (One fused kernel for the whole
+// thing: Context.Beamform; several GPUs: MultiGPU.Beamform.)
+func (s Readers) ReadBeamform(rs sdr.Readers, cfg stream.BeamformConfig) (*Beamform, error) {
+	multReaders := make(sdr.Readers, len(rs))
+	for i := range rs {
+		reader, err := s.x.ConvertReader(rs[i], sdr.SampleFormatC64)
+		if err != nil {
+			return nil, err
+		}
+		multReaders[i], err = s.Multiply(reader, 1)
+		if err != nil {
+			return nil, err
+		}
+	}
+	addReader, err := s.Add(multReaders...)
+	if err != nil {
+		return nil, err
+	}
+	b := &Beamform{Reader: addReader, readers: multReaders, config: cfg}
+	if err := b.SetPhaseAngles(cfg.Angles); err != nil {
+		return nil, err
+	}
+	return b, nil
+}

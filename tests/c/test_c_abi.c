@@ -294,6 +294,64 @@ static void chain_and_ring(void) { /* go/hip/stream.go Chain, go/hip/ring.go */
     free(y);
 }
 
+/* go/hip/readers.go: the call sequence of one Read of each reference-named Reader, block by block as
+ * the Reader scaffold (stream/read_transformer.go:92-137) would hand them over */
+static void readers(void) {
+    enum { B = 32 * 1024 }; /* the reference's Reader block (stream/convert.go:43-44) */
+    static uint8_t u8[2 * B];
+    static float c64[2 * B], tmp[2 * B], acc[2 * B];
+    size_t n = 0;
+    for (int i = 0; i < 2 * B; i++) u8[i] = (uint8_t)(i * 37 + 11);
+    /* ReadBeamform = ConvertReader -> Multiply(w) -> Add, two channels (stream/beamform.go:148-171) */
+    OK(hzsdr_convert(ctx, HZSDR_FMT_C64, c64, B, HZSDR_FMT_U8, u8, B, &n));
+    CHECK(n == B && c64[0] == (11.0f - 127.5f) / 127.5f);
+    memcpy(tmp, c64, sizeof tmp);
+    OK(hzsdr_rotate(ctx, tmp, B, 0.0f, -1.0f)); /* Multiply.Read with m = -i; m == 1 is skipped by the Reader */
+    const void *two[2] = {c64, tmp};
+    OK(hzsdr_sum(ctx, HZSDR_FMT_C64, acc, two, 2, B)); /* addReader.Read: zero, then += in order */
+    CHECK(acc[0] == (0.0f + c64[0]) + tmp[0]);
+    /* ShiftReader.Read twice: the clock carries on across Reads (stream/shifter.go:66-85) */
+    hzsdr_nco *nco = NULL;
+    double t1 = 0, t2 = 0;
+    OK(hzsdr_nco_create(ctx, 2048000, &nco));
+    OK(hzsdr_nco_shift(nco, 100e3, c64, B));
+    OK(hzsdr_nco_get_time(nco, &t1));
+    OK(hzsdr_nco_shift(nco, 100e3, c64, B));
+    OK(hzsdr_nco_get_time(nco, &t2));
+    CHECK(t1 > 0 && t2 > t1);
+    OK(hzsdr_nco_free(nco));
+    /* Gain.Read (stream/gain.go:50-57) */
+    OK(hzsdr_scale(ctx, acc, B, 0.5f));
+    /* Multiply on a u8 reader: the table, SetMultiplier between Reads (stream/multiply.go:91-172) */
+    hzsdr_rotlut *rt = NULL;
+    OK(hzsdr_rotlut_create(ctx, HZSDR_FMT_U8, 1.0f, 0.0f, &rt));
+    OK(hzsdr_rotlut_apply(rt, u8, B));
+    OK(hzsdr_rotlut_set_multiplier(rt, 0.0f, 1.0f));
+    OK(hzsdr_rotlut_apply(rt, u8, B));
+    OK(hzsdr_rotlut_free(rt));
+    /* DecimateReader / DownsampleReader: the Proc of a 32 Ki block, offset counted per block
+     * (stream/decimate.go:45-49, downsample.go:56-60) */
+    OK(hzsdr_decimate(ctx, HZSDR_FMT_C64, tmp, B, HZSDR_FMT_C64, c64, B, 10, 0, &n));
+    CHECK(n == B / 10); /* 3276: stream/decimate_test.go */
+    OK(hzsdr_decimate(ctx, HZSDR_FMT_C64, tmp, B, HZSDR_FMT_C64, c64, B, 10, B, &n));
+    CHECK(n == B / 10);
+    OK(hzsdr_downsample(ctx, HZSDR_FMT_C64, tmp, B, HZSDR_FMT_C64, c64, B, 8, 0, &n));
+    CHECK(n == B / 8);
+    /* ConvolutionReader: blocks of len(filter), all-ones filter bins = identity up to the transforms'
+     * rounding (stream/convolution.go:57-80; the reference leaves the backward transform unscaled:
+     * the caller's bins carry 1/N) */
+    static float filt[2 * 1024], blk[2 * 1024], fout[2 * 1024];
+    for (int i = 0; i < 1024; i++) {
+        filt[2 * i] = 1.0f / 1024.0f;
+        filt[2 * i + 1] = 0.0f;
+        blk[2 * i] = c64[2 * i];
+        blk[2 * i + 1] = c64[2 * i + 1];
+    }
+    OK(hzsdr_convolution_blocks(ctx, fout, 1024, blk, 1024, filt, 1024, &n));
+    CHECK(n == 1024);
+    for (int i = 0; i < 2048; i++) CHECK(fabsf(fout[i] - blk[i]) < 1e-4f);
+}
+
 int main(void) {
     int count = 0;
     printf("backend %s version %s c64 = %d bytes\n", hzsdr_backend(), hzsdr_version(), hzsdr_format_size(HZSDR_FMT_C64));
@@ -311,6 +369,7 @@ int main(void) {
     fft_and_convolution();
     beamform();
     chain_and_ring();
+    readers();
     OK(hzsdr_synchronize(ctx));
     OK(hzsdr_close(ctx));
     ctx = NULL;

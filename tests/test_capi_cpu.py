@@ -180,6 +180,38 @@ def test_go_package_binds_every_declaration():
     assert used - declared - {"hzsdr_nco_segment"} == set(), sorted(used - declared)
 
 
+def test_go_package_has_the_reference_reader_constructors():
+    """go/hip/readers.go: the reference's stream.* Reader constructors with their own names and
+    argument lists (stream/shifter.go:89, gain.go:30, multiply.go:74 (+ SetMultiplier :34), add.go:41,
+    decimate.go:34, downsample.go:47, convolution.go:36, beamform.go:148 (+ SetPhaseAngles :131)), as
+    methods of ctx.Readers(); each must end in a call of the C-ABI (directly or through the package's
+    buffer-level wrappers)."""
+    import re
+    src = open(os.path.join(ROOT, "go", "hip", "readers.go")).read()
+    want = {
+        "ShiftReader": r"func \(s Readers\) ShiftReader\(r sdr\.Reader, shift rf\.Hz\) \(sdr\.Reader, error\)",
+        "Gain": r"func \(s Readers\) Gain\(r sdr\.Reader, v float32\) sdr\.Reader",
+        "Multiply": r"func \(s Readers\) Multiply\(r sdr\.Reader, m complex64\) \(sdr\.Reader, error\)",
+        "Add": r"func \(s Readers\) Add\(readers \.\.\.sdr\.Reader\) \(sdr\.Reader, error\)",
+        "DecimateReader": r"func \(s Readers\) DecimateReader\(in sdr\.Reader, factor uint\) \(sdr\.Reader, error\)",
+        "DownsampleReader": r"func \(s Readers\) DownsampleReader\(in sdr\.Reader, factor uint\) \(sdr\.Reader, error\)",
+        "ConvolutionReader": r"func \(s Readers\) ConvolutionReader\(r sdr\.Reader, planner fft\.Planner, filter \[\]complex64\) \(sdr\.Reader, error\)",
+        "ReadBeamform": r"func \(s Readers\) ReadBeamform\(rs sdr\.Readers, cfg stream\.BeamformConfig\) \(\*Beamform, error\)",
+        "SetMultiplier": r"func \(mr \*multiplyReader\) SetMultiplier\(m complex64\)",
+        "SetPhaseAngles": r"func \(b \*Beamform\) SetPhaseAngles\(angles \[\]complex64\) error",
+    }
+    for name, pat in want.items():
+        assert re.search(pat, src), name
+    # the buffer-level calls the Readers stand on exist in the package and reach the C-ABI
+    pkg = "".join(open(f).read() for f in sorted(__import__("glob").glob(os.path.join(ROOT, "go", "hip", "*.go"))))
+    for method, cfn in (("ShiftBuffer", "hzsdr_nco_shift"), ("Scale", "hzsdr_scale"), ("Multiply", "hzsdr_rotate"),
+                        ("Apply", "hzsdr_rotlut_apply"), ("Sum", "hzsdr_sum"), ("DecimateBuffer", "hzsdr_decimate"),
+                        ("DownsampleBuffer", "hzsdr_downsample"), ("ConvolutionBlocks", "hzsdr_convolution_blocks"),
+                        ("ConvertBuffer", "hzsdr_convert")):
+        assert re.search(r"\." + method + r"\(", src) or method in ("ConvertBuffer",), method
+        assert "C." + cfn + "(" in pkg, cfn
+
+
 def test_plain_c_walkthrough_compiles_as_c99_and_covers_the_header():
     """tests/c/test_c_abi.c compiles with gcc -std=c99 -Werror against the header alone (no
     GPU needed to compile) and names every declared function."""
