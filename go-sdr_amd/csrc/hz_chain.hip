@@ -640,76 +640,45 @@ static bool mm2_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *i
     memset(L, 0, sizeof *L);
     memset(F, 0, sizeof *F);
     if (!c->mm_ok || c->mix_in_order || P.segs.big_n != 0 || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) return false;
-    const uint64_t D = c->factor, n_out = n / D, nt = c->ntaps, tile = mm2::kT, pass = (uint64_t)mm2::pass_out((int)D);
-    if (n_out < 4096 || n_out >= (1ull << 31)) return false;  // (a call this short is launch-bound either way)
     for (int i = 0; i < P.n; i++)
         if (P.op[i].kind == EW_SHIFT && !(fabs(P.op[i].tau_shift) * 6.2832 < 1073741824.0)) return false;
     const int nr = c->has_shift ? P.segs.n : 1;
     if (nr < 1 || nr > kNcoMaxSegs) return false;
-    L->cont = c->rh_valid && (!c->has_shift || (P.segs.step[0] == c->rh_step && c->rh_len >= nt && c->rh_next == P.segs.t0[0])) ? 1 : 0;
-    L->n_ops = P.n;
-    L->gain = 1.0f;
-    L->shift_op = -1;
+    // the planner itself is host-only code (hz_firmm2_plan.h: sanitizer-built and fuzzed in tests/host/)
+    mm2::PlanIn pin{};
+    pin.n_in = n, pin.D = c->factor, pin.ntaps = (int)c->ntaps, pin.has_shift = c->has_shift;
+    pin.cont = c->rh_valid && (!c->has_shift || (P.segs.step[0] == c->rh_step && c->rh_len >= c->ntaps && c->rh_next == P.segs.t0[0]));
+    pin.n_ops = P.n;
+    pin.max_grid = c->ctx->num_cus;
+    pin.shift_op = -1;
     int n_shift = 0;
     for (int i = 0; i < P.n; i++)
         if (P.op[i].kind == EW_SHIFT) {
-            L->shift_op = i;
+            pin.shift_op = i;
             n_shift++;
         }
-    if (n_shift != 1) L->shift_op = -1;
-    uint64_t fix_total = 0, covered = 0;  // outputs below `covered` are planned
-    bool too_many = false;
-    auto add_fix = [&](uint64_t a, uint64_t b) {
-        if (b <= a) return;
-        fix_total += b - a;
-        if (F->n >= mm2::kMaxFix) {
-            too_many = true;
-            return;
-        }
-        F->m_a[F->n] = (uint32_t)a;
-        F->m_b[F->n] = (uint32_t)b;
-        F->task_first[F->n] = F->n_task;
-        F->n_task += (int)((b - a + mm2::kFixOut - 1) / mm2::kFixOut);
-        F->n++;
-    };
+    if (n_shift != 1) pin.shift_op = -1;
+    else pin.tau = P.op[pin.shift_op].tau_shift;
+    const void *tabs[kNcoMaxSegs];
+    const uint64_t zero_first = 0;
+    const double zero = 0.0;
     for (int r = 0; r < nr; r++) {
-        const uint64_t a = c->has_shift ? P.segs.first[r] : 0;
-        const uint64_t b = (c->has_shift && r + 1 < nr) ? P.segs.first[r + 1] : (uint64_t)n;
         void *dev = nullptr;
         (void)mm_table_for(c, c->has_shift ? P.segs.step[r] : 0.0, 0.0, &dev, false);
-        uint64_t lo = (r == 0 && L->cont) ? 0 : (a + nt - 1 + D - 1) / D, hi = std::min((b + D - 1) / D, n_out);
-        lo = (lo + tile - 1) / tile * tile;
-        if (hi < n_out) hi = hi / tile * tile;
-        if (!dev || hi < lo + 64) continue;  // a run without a table, or too short to bother
-        if (L->n >= mm2::kMaxRuns) return false;
-        mm2::Run &u = L->run[L->n];
-        u.tab = dev, u.m_lo = (uint32_t)lo, u.m_hi = (uint32_t)hi;
-        u.pass_first = (int)(lo / pass), u.pass_end = (int)((hi + pass - 1) / pass);
-        u.seg = r;
-        if (c->has_shift) u.first = P.segs.first[r];
-        if (L->shift_op >= 0)
-            mm2::phase_fix(P.op[L->shift_op].tau_shift, P.segs.t0[r], P.segs.step[r], u.first, &u.phi, &u.dphi);
-        L->pass_first[L->n] = u.pass_first, L->pass_end[L->n] = u.pass_end;
-        add_fix(covered, lo);
-        L->n++;
-        covered = hi;
+        tabs[r] = dev;
     }
-    if (L->n == 0) return false;
-    add_fix(covered, n_out);
-    L->n_pass = (int)((n_out + pass - 1) / pass);
-    L->n_task = F->n_task;
+    mm2::ClockRuns cr{nr, c->has_shift ? P.segs.first : &zero_first, c->has_shift ? P.segs.t0 : &zero, c->has_shift ? P.segs.step : &zero, tabs};
+    uint64_t fix_total = 0;
+    const bool ok = mm2::plan_call(pin, cr, L, F, &fix_total);
     if (c->debug_mm) {
-        fprintf(stderr, "hzsdr mm2: %d of %d runs on the matrix path, cont %d, %d passes, %d fix intervals (%d tasks, %llu outputs)\n", L->n, nr,
-                L->cont, L->n_pass, F->n, F->n_task, (unsigned long long)fix_total);
+        fprintf(stderr, "hzsdr mm2: %s: %d of %d runs on the matrix path, cont %d, %d passes, %d fix intervals (%d tasks, %llu outputs)\n",
+                ok ? "matrix path" : "transform kernels", L->n, nr, L->cont, L->n_pass, F->n, F->n_task, (unsigned long long)fix_total);
         for (int r = 0; r < L->n; r++)
             fprintf(stderr, "   run first %llu valid [%u, %u) passes [%d, %d) table %p\n", (unsigned long long)L->run[r].first, L->run[r].m_lo,
                     L->run[r].m_hi, L->run[r].pass_first, L->run[r].pass_end, L->run[r].tab);
         for (int k = 0; k < F->n; k++) fprintf(stderr, "   fix [%u, %u) first task %d\n", F->m_a[k], F->m_b[k], F->task_first[k]);
     }
-    // the fix-up tasks are the slow way: a call that is mostly boundaries keeps the transforms; a workgroup takes
-    // them one at a time (hz_firmm2.h: the launch has min(CUs, passes) workgroups)
-    const int grid = std::max(1, std::min(c->ctx->num_cus, L->n_pass));
-    return !too_many && F->n_task <= 4 * grid && fix_total * 8 <= n_out;
+    return ok;
 }
 
 static int mm2_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const EwProgram &P, const mm2::Plan &L,

@@ -37,8 +37,8 @@ static int launch_fmt(hipStream_t stream, int num_cus, unsigned D, const void *i
     if (D != 8) return HZSDR_ERR_INVALID_ARGUMENT;
     const size_t lds = lds_bytes((int)D, g.ks, g.ne, g.ntaps);
     // one workgroup per CU; a call with fewer passes than CUs: one pass per workgroup
-    const int grid = std::max(1, std::min(num_cus, L.n_pass));
-    L.grid = grid;
+    const int grid = std::max(1, L.grid);  // (the planner's: min(CUs, passes))
+    (void)num_cus;
     unsigned long long *no_stamps = nullptr;
     // (the straight-line matrix loop exists for the 1024-tap window: 17 groups)
     if (g.ks == 17 * 4)

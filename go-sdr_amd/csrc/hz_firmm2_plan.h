@@ -1,0 +1,209 @@
+// hz_firmm2_plan.h -- the HOST side of the persistent-pass matrix FIR (hz_firmm2.h): geometry, the kernel's
+// argument structures and the planner that cuts one call into clock runs, passes and fix-up tasks.  No HIP in
+// here: the library includes it through hz_firmm2.h, and tests/host/ builds it with gcc -fsanitize=address,
+// undefined and fuzzes the planner's invariants (the GPU box offers no device sanitizers).
+#pragma once
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+namespace hz {
+namespace mm2 {
+
+constexpr int kT = 8;        // outputs per tile
+constexpr int kWaves = 8;    // two per SIMD
+constexpr int kThreads = 64 * kWaves;
+constexpr int kFixOut = 16;  // outputs per fix-up task
+constexpr int kHistPer = 64; // samples per history task
+constexpr int kMaxRuns = 16;  // clock runs of a call that take the matrix path (more: the call keeps the transforms)
+constexpr int kMaxClockRuns = 32;  // hz_nco.h: kNcoMaxSegs, the runs of the clock that travel in the kernel arguments
+constexpr int kMaxFix = kMaxClockRuns + 2;
+constexpr int kU = 12;       // 16-byte pieces per lane of a pass image, any window (768 pieces = 12 KB at most)
+
+constexpr bool factor_ok(unsigned D) { return D == 8; }
+constexpr int blocks_for(int D) { return D >= 16 ? 1 : 2; }
+constexpr int tile_bytes(int D) { return 2 * D * kT; }
+constexpr int pass_tiles(int D) { return 32 * blocks_for(D); }
+constexpr int pass_out(int D) { return pass_tiles(D) * kT; }
+// bytes of a pass: the windows of its tiles, 32 ks = (ks / GS) tile_bytes
+constexpr size_t image_bytes(int D, int ks) { return (size_t)(pass_tiles(D) - 1) * tile_bytes(D) + 32 * (size_t)ks; }
+// In LDS a tile is followed by 16 bytes of padding: a fragment read (one piece of 16 consecutive tiles per
+// lane group) then falls on 16 different 16-byte bank groups (9 t + p mod 16 for 128-byte tiles), and --
+// unlike an XOR swizzle -- every address of the matrix loop is ONE per-lane base plus a constant: tile
+// n + g, piece 2 j + h, block b sit at base + tile_stride g + 32 j + 32 tile_stride b.
+constexpr int tile_stride(int D) { return tile_bytes(D) + 16; }
+// (the loop's look-ahead reads two steps past the last window: one tile behind the image)
+constexpr size_t slot_bytes(int D, int ks) {
+    return ((image_bytes(D, ks) / tile_bytes(D) + 1) * tile_stride(D) + 255) / 256 * 256;
+}
+// table: T[f][E][part][pl] of 16 bytes (digit plane 2 f + pl, most significant first), then (dc_re, dc_im)
+constexpr size_t table_bytes(int ne) { return (size_t)ne * 128 + 16; }
+constexpr size_t table_lds(int ne) { return (table_bytes(ne) + 255) / 256 * 256; }
+constexpr size_t kCtlBytes = 512;  // the queue's counter; the mixer's step factors of the group's two runs
+// two tables, the queue's counter, a slot per wave, the fix-up task's window (ntaps + D (kFixOut - 1) samples) and taps
+constexpr size_t lds_bytes(int D, int ks, int ne, int ntaps) {
+    return 2 * table_lds(ne) + kCtlBytes + kWaves * slot_bytes(D, ks) + ((size_t)(2 * ntaps + D * (kFixOut - 1)) * 8 + 255) / 256 * 256;
+}
+
+struct Geom {
+    int ntaps;
+    int w0;     // window start before a tile's first output sample: ntaps - 1 rounded up to 8
+    int ks;     // 32-byte steps over a tile's window (a multiple of D / 2: whole groups)
+    int ne;     // entries E of one fragment row of the table
+    int e0;     // E of (i = 0, h = 0, s = 0)
+    int shift;  // S: taps are q = round(h' 2^S)
+    unsigned off;
+};
+
+// What a call hands the kernel.  The kernel arguments are read through the scalar cache, where a miss costs
+// ~0.9 us while every wave of the chip is asking (measured: five dependent groups of reads in front of the
+// first matrix loop took 4.5 us): the plan keeps what the main path reads in its first line and ONE 64-byte
+// line per clock run; the program P and the fix-up intervals F are read by the small tasks only.
+struct Run {
+    const void *tab;       // the run's digit table
+    uint32_t m_lo, m_hi;   // the outputs that take the matrix path (tile-aligned inside the call)
+    int pass_first;        // the passes (512 outputs of the call's grid) that hold outputs of the run: a pass that
+    int pass_end;          // straddles a boundary belongs to BOTH runs and is multiplied twice, once per table
+    // programs with exactly ONE Shift stage: the stage's phase tau ts / 2 pi at the BUFFER's first sample by
+    // the run's line, and its increment per sample, in 2^-64 turns (mod 1)
+    uint64_t phi, dphi;
+    uint64_t first;        // the run's first sample
+    int seg;               // the run's index in the program's clock table (programs with several Shift stages)
+    int pad[3];
+};
+static_assert(sizeof(Run) == 64, "one scalar-cache line per run");
+struct Plan {
+    int n;          // clock runs with outputs on the matrix path, in stream order (at most kMaxRuns)
+    int n_pass;     // passes of the call
+    int cont;       // run 0 continues the previous call's last run: windows may reach into the raw history
+    int shift_op;   // index of the program's only Shift stage, -1: none or several
+    int n_task;     // fix-up tasks (F)
+    int n_ops;      // stages of the program
+    float gain;     // (unused)
+    int grid;       // workgroups of the launch (gridDim.x is a read of the dispatch packet: another miss)
+    int pass_first[kMaxRuns], pass_end[kMaxRuns];  // (copies: a workgroup finds its runs without reading their lines)
+    Run run[kMaxRuns];
+};
+struct Fix {
+    int n;
+    int n_task;
+    uint32_t m_a[kMaxFix], m_b[kMaxFix];
+    int task_first[kMaxFix];
+};
+
+// phase accumulator constants of a run (host): frac(tau step / 2 pi) and frac(tau t0 / 2 pi) - first * the increment,
+// in 2^-64 turns.
+// Extended precision: the increment is multiplied by up to 2^27 samples.
+inline void phase_fix(double tau, double t0, double step, uint64_t first, uint64_t *phi, uint64_t *dphi) {
+    const long double inv2pi = 0.159154943091895335768883763372514362L;
+    auto fix = [](long double turns) {
+        turns -= floorl(turns);  // [0, 1)
+        const long double v = turns * 18446744073709551616.0L;
+        return v >= 18446744073709551615.0L ? ~0ull : (uint64_t)v;
+    };
+    *dphi = fix((long double)tau * (long double)step * inv2pi);
+    *phi = fix((long double)tau * (long double)t0 * inv2pi) - first * *dphi;  // (mod 2^64: by the run's line at sample 0)
+}
+
+// geometry of a chain with `ntaps` taps at decimation D (host)
+inline Geom make_geom(int ntaps, int D, unsigned off, int shift) {
+    Geom g{};
+    g.ntaps = ntaps;
+    g.w0 = (ntaps - 1 + 7) / 8 * 8;
+    const int window = g.w0 + D * (kT - 1) + 1;  // samples a tile's outputs reach back over
+    const int gs = D / 2;                        // steps per group
+    g.ks = ((2 * window + 31) / 32 + gs - 1) / gs * gs;
+    g.e0 = 2 * (g.ks + 4);
+    g.ne = g.e0 + (D / 8) * (kT - 1) + 1;
+    g.shift = shift;
+    g.off = off;
+    return g;
+}
+
+
+// ---- the planner ---------------------------------------------------------------------------------------------
+// The exactly-linear runs of the NCO clock over the call's samples (hzsdr_nco_segments): run r starts at sample
+// first[r] with clock t0[r] and advances by step[r]; tab[r]: the run's digit table (null: none was prepared).
+// A chain without a Shift stage passes n = 1, first[0] = 0.
+struct ClockRuns {
+    int n;
+    const uint64_t *first;
+    const double *t0, *step;
+    const void *const *tab;
+};
+struct PlanIn {
+    uint64_t n_in;     // samples of the call (a multiple of D is consumed)
+    unsigned D;
+    int ntaps;
+    bool has_shift;
+    bool cont;         // run 0 continues the run the previous call ended in: its windows may reach into the raw history
+    int shift_op;      // the program's only Shift stage (-1: none or several) and its fl(2 pi f)
+    double tau;
+    int n_ops;
+    int max_grid;      // CUs
+};
+// Every clock run with a table gets the outputs whose whole window lies in it (tile-aligned) and the passes of
+// the call's 512-output grid that hold them -- a pass that straddles a boundary is multiplied once per run, each
+// time with that run's table and valid range.  What no run holds -- windows that cross a boundary, the stream's
+// start, runs without a table -- are fix-up tasks of kFixOut outputs.  false: the call keeps the transform
+// kernels (too short, too many runs or intervals, mostly boundaries).
+inline bool plan_call(const PlanIn &in, const ClockRuns &cr, Plan *L, Fix *F, uint64_t *fix_outputs = nullptr) {
+    memset(L, 0, sizeof *L);
+    memset(F, 0, sizeof *F);
+    const uint64_t D = in.D, n_out = in.n_in / D, nt = (uint64_t)in.ntaps, tile = kT, pass = (uint64_t)pass_out((int)D);
+    if (fix_outputs) *fix_outputs = 0;
+    if (n_out < 4096 || n_out >= (1ull << 31)) return false;  // (a call this short is launch-bound either way)
+    if (cr.n < 1 || cr.n > kMaxClockRuns) return false;
+    L->cont = in.cont ? 1 : 0;
+    L->n_ops = in.n_ops;
+    L->gain = 1.0f;
+    L->shift_op = in.shift_op;
+    uint64_t fix_total = 0, covered = 0;  // outputs below `covered` are planned
+    bool too_many = false;
+    auto add_fix = [&](uint64_t a, uint64_t b) {
+        if (b <= a) return;
+        fix_total += b - a;
+        if (F->n >= kMaxFix) {
+            too_many = true;
+            return;
+        }
+        F->m_a[F->n] = (uint32_t)a;
+        F->m_b[F->n] = (uint32_t)b;
+        F->task_first[F->n] = F->n_task;
+        F->n_task += (int)((b - a + kFixOut - 1) / kFixOut);
+        F->n++;
+    };
+    for (int r = 0; r < cr.n; r++) {
+        const uint64_t a = cr.first[r];
+        const uint64_t b = r + 1 < cr.n ? cr.first[r + 1] : in.n_in;
+        uint64_t lo = (r == 0 && in.cont) ? 0 : (a + nt - 1 + D - 1) / D, hi = (b + D - 1) / D < n_out ? (b + D - 1) / D : n_out;
+        lo = (lo + tile - 1) / tile * tile;
+        if (hi < n_out) hi = hi / tile * tile;
+        if (!cr.tab[r] || hi < lo + 64) continue;  // a run without a table, or too short to bother
+        if (L->n >= kMaxRuns) return false;
+        Run &u = L->run[L->n];
+        u.tab = cr.tab[r], u.m_lo = (uint32_t)lo, u.m_hi = (uint32_t)hi;
+        u.pass_first = (int)(lo / pass), u.pass_end = (int)((hi + pass - 1) / pass);
+        u.seg = r;
+        u.first = a;
+        if (in.shift_op >= 0) phase_fix(in.tau, cr.t0[r], cr.step[r], u.first, &u.phi, &u.dphi);
+        L->pass_first[L->n] = u.pass_first, L->pass_end[L->n] = u.pass_end;
+        add_fix(covered, lo);
+        L->n++;
+        covered = hi;
+    }
+    if (L->n == 0) return false;
+    add_fix(covered, n_out);
+    L->n_pass = (int)((n_out + pass - 1) / pass);
+    L->n_task = F->n_task;
+    L->grid = in.max_grid < L->n_pass ? in.max_grid : L->n_pass;
+    if (L->grid < 1) L->grid = 1;
+    if (fix_outputs) *fix_outputs = fix_total;
+    // the fix-up tasks are the slow way: a call that is mostly boundaries keeps the transforms; a workgroup takes
+    // them one at a time
+    return !too_many && F->n_task <= 4 * L->grid && fix_total * 8 <= n_out;
+}
+
+}  // namespace mm2
+}  // namespace hz

@@ -1,0 +1,159 @@
+// plan_fuzz.cpp -- the host-only planners under AddressSanitizer + UndefinedBehaviorSanitizer (the GPU box offers
+// no device sanitizers; the reference runs `go test -race` on everything, Makefile:35,42).  Built by
+// tests/test_host_sanitizers.py:
+//     g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all -I go-sdr_amd/csrc -I include
+//         tests/host/plan_fuzz.cpp go-sdr_amd/csrc/hz_host.cpp -o plan_fuzz
+// Random sample rates (incl. power-of-two rates, whose clock steps never change), clock starts (0, binade
+// edges, just below the 2 pi wrap), buffer lengths, tap counts and tables present / absent; asserts
+//   * hzsdr_nco_segments: the counts add up to n, run k starts where run k - 1 ended, and the runs reproduce the
+//     serial recurrence of stream/shifter.go:76-79 (ts += 1/fs; if ts > 2 pi { ts -= 2 pi }) sample for sample;
+//   * mm2::plan_call (hz_firmm2_plan.h): every output lies in EXACTLY one run's valid range or one fix-up
+//     interval; ranges and intervals ascend; a run's passes hold its outputs; tile alignment; task counts;
+//     windows of valid outputs lie inside their run (or the raw history when the call continues a run).
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+
+#include "hz_firmm2_plan.h"
+#include "hzsdr.h"
+
+using namespace hz;
+
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint64_t rnd() {
+    uint64_t z = (rng_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static double urand() { return (double)(rnd() >> 11) / 9007199254740992.0; }
+
+#define REQUIRE(cond)                                                                  \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            printf("FAIL %s:%d: %s (case %d)\n", __FILE__, __LINE__, #cond, g_case);   \
+            exit(1);                                                                   \
+        }                                                                              \
+    } while (0)
+static int g_case = 0;
+
+int main(int argc, char **argv) {
+    const int cases = argc > 1 ? atoi(argv[1]) : 3000;
+    const double tau = 6.283185307179586476925286766559;
+    const uint64_t rates[] = {250000, 1000000, 1048576, 1800000, 2048000, 2097152, 2400000, 8000000, 20000000, 200000000};
+    long planned = 0, fell_back = 0;
+    for (g_case = 0; g_case < cases; g_case++) {
+        const uint64_t fs = rates[rnd() % (sizeof rates / sizeof rates[0])];
+        double ts0;
+        switch (rnd() % 6) {
+        case 0: ts0 = 0.0; break;
+        case 1: ts0 = ldexp(1.0, -(int)(rnd() % 30)); break;                         // a binade edge
+        case 2: ts0 = tau - (double)(rnd() % 100000) / (double)fs; break;            // just below the wrap
+        case 3: ts0 = nextafter(ldexp(1.0, (int)(rnd() % 3)), 0.0); break;           // just below a binade edge
+        default: ts0 = urand() * tau; break;
+        }
+        const uint64_t n = (rnd() % 8 == 0) ? (rnd() % 70000) : ((uint64_t)1 << (15 + rnd() % 10)) + 8 * (rnd() % 4096);
+        std::vector<hzsdr_nco_segment> segs(4096);
+        size_t need = 0;
+        double ts_end = 0;
+        const int rc = hzsdr_nco_segments(fs, ts0, n, segs.data(), segs.size(), &need, &ts_end);
+        REQUIRE(rc == HZSDR_OK);
+        REQUIRE(need <= segs.size());
+        // ---- the clock runs against the serial recurrence
+        uint64_t total = 0;
+        for (size_t k = 0; k < need; k++) {
+            REQUIRE(segs[k].first == total);
+            REQUIRE(segs[k].count > 0);
+            total += segs[k].count;
+        }
+        REQUIRE(total == n);
+        if (n <= (1u << 21)) {  // sample for sample (the long buffers: at the runs' ends only)
+            double ts = ts0;
+            const double inc = 1.0 / (double)fs;
+            size_t k = 0;
+            for (uint64_t j = 0; j < n; j++) {
+                ts += inc;
+                if (ts > tau) ts -= tau;
+                while (j >= segs[k].first + segs[k].count) k++;
+                const double planned_ts = fma((double)(j - segs[k].first), segs[k].step, segs[k].t0);
+                REQUIRE(planned_ts == ts);
+            }
+            REQUIRE(ts == ts_end);
+        }
+        // ---- the pass planner over these runs
+        if (need > (size_t)mm2::kMaxClockRuns) continue;
+        const unsigned D = 8;
+        const int ntaps = 16 + (int)(rnd() % 1140);
+        std::vector<uint64_t> first(need);
+        std::vector<double> t0(need), step(need);
+        std::vector<const void *> tab(need);
+        static const char dummy = 0;
+        for (size_t k = 0; k < need; k++) {
+            first[k] = segs[k].first, t0[k] = segs[k].t0, step[k] = segs[k].step;
+            // tables exist for the long runs (prepare_mm_tables), sometimes not at all
+            tab[k] = (segs[k].count >= 8ull * (uint64_t)ntaps && rnd() % 16 != 0) ? &dummy : nullptr;
+        }
+        mm2::ClockRuns cr{(int)need, first.data(), t0.data(), step.data(), tab.data()};
+        mm2::PlanIn in{};
+        in.n_in = n / D * D, in.D = D, in.ntaps = ntaps, in.has_shift = true, in.cont = rnd() % 2 == 0;
+        in.shift_op = rnd() % 4 ? 0 : -1, in.tau = tau * 2.5e6 * (urand() - 0.5), in.n_ops = 1, in.max_grid = 1 + (int)(rnd() % 256);
+        mm2::Plan L;
+        mm2::Fix F;
+        uint64_t fix_outputs = 0;
+        const bool ok = mm2::plan_call(in, cr, &L, &F, &fix_outputs);
+        if (!ok) {
+            fell_back++;
+            continue;
+        }
+        planned++;
+        const uint64_t n_out = in.n_in / D, pass = (uint64_t)mm2::pass_out((int)D);
+        REQUIRE(L.n >= 1 && L.n <= mm2::kMaxRuns && F.n <= mm2::kMaxFix);
+        REQUIRE((uint64_t)L.n_pass == (n_out + pass - 1) / pass);
+        REQUIRE(L.grid >= 1 && L.grid <= in.max_grid && L.grid <= L.n_pass);
+        REQUIRE(F.n_task == L.n_task && F.n_task <= 4 * L.grid);
+        std::vector<uint8_t> cover(n_out, 0);
+        uint64_t prev_hi = 0, fixed = 0;
+        int tasks = 0;
+        for (int r = 0; r < L.n; r++) {
+            const mm2::Run &u = L.run[r];
+            REQUIRE(u.tab != nullptr);
+            REQUIRE(u.m_lo < u.m_hi && u.m_hi <= n_out && u.m_lo >= prev_hi);
+            REQUIRE(u.m_lo % mm2::kT == 0 && (u.m_hi % mm2::kT == 0 || u.m_hi == n_out));
+            REQUIRE((uint64_t)u.pass_first == u.m_lo / pass && (uint64_t)u.pass_end == (u.m_hi + pass - 1) / pass);
+            REQUIRE(L.pass_first[r] == u.pass_first && L.pass_end[r] == u.pass_end);
+            REQUIRE(u.seg >= 0 && u.seg < (int)need && u.first == first[u.seg]);
+            // every valid output's window lies in the run (run 0 of a continuing call: or in the raw history)
+            const uint64_t run_end = (size_t)u.seg + 1 < need ? first[u.seg + 1] : in.n_in;
+            const int64_t w_lo = (int64_t)D * u.m_lo - (ntaps - 1);
+            REQUIRE(w_lo >= (int64_t)u.first || (u.seg == 0 && in.cont));
+            REQUIRE((uint64_t)D * (u.m_hi - 1) < run_end);
+            for (uint64_t m = u.m_lo; m < u.m_hi; m++) cover[m]++;
+            prev_hi = u.m_hi;
+        }
+        uint32_t prev_b = 0;
+        for (int k = 0; k < F.n; k++) {
+            REQUIRE(F.m_a[k] < F.m_b[k] && F.m_b[k] <= n_out && F.m_a[k] >= prev_b);
+            REQUIRE(F.task_first[k] == tasks);
+            tasks += (int)((F.m_b[k] - F.m_a[k] + mm2::kFixOut - 1) / mm2::kFixOut);
+            for (uint64_t m = F.m_a[k]; m < F.m_b[k]; m++) cover[m]++;
+            fixed += F.m_b[k] - F.m_a[k];
+            prev_b = F.m_b[k];
+        }
+        REQUIRE(tasks == F.n_task && fixed == fix_outputs);
+        for (uint64_t m = 0; m < n_out; m++) REQUIRE(cover[m] == 1);
+        // the workgroups' pass ranges (hz_firmm2.h) partition the passes
+        const uint32_t NP = (uint32_t)L.n_pass, per = NP / (uint32_t)L.grid, rem = NP - per * (uint32_t)L.grid;
+        uint32_t at = 0;
+        for (uint32_t wb = 0; wb < (uint32_t)L.grid; wb++) {
+            const uint32_t pb0 = wb * per + (wb < rem ? wb : rem), pb1 = pb0 + per + (wb < rem ? 1u : 0u);
+            REQUIRE(pb0 == at && pb1 > pb0);
+            at = pb1;
+        }
+        REQUIRE(at == NP);
+    }
+    printf("plan_fuzz ok: %d cases, %ld planned, %ld kept the transforms\n", cases, planned, fell_back);
+    return 0;
+}
