@@ -232,6 +232,15 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         if constexpr (FMT == HZSDR_FMT_U8) v ^= (int)0x80808080;  // b - 128 as int8
         *reinterpret_cast<v4i *>(slot + TS * (q / PPT) + 16 * (q % PPT)) = v;
     };
+    // The compiler's s_waitcnt pass keeps a load "pending" on every path it cannot prove a wait on (a conditional
+    // consumer is enough), right around the pass loop; with stores in flight as well -- loads and stores return out of
+    // order -- each later write of such a register becomes s_waitcnt vmcnt(0).  Two of those sat in the pass loop:
+    // at its head (the previous pass's stores drained before the queue was read) and in front of the matrix loop
+    // (the prefetch just issued waited for, instead of flying under the matrix loop).  An explicit vmcnt(0) where
+    // nothing is in flight anyway -- after a landing -- tells the pass so.
+    auto vm_clear = [&]() {
+        if constexpr ((EXP & 128) == 0) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), the other counters untouched
+    };
     auto land = [&](v4i(&x)[KU]) {
         // piece l + 64 u is piece l % PPT of tile l / PPT + (64 / PPT) u: one address and constants
         uint8_t *lp = slot + TS * (l / PPT) + 16 * (l % PPT);
@@ -499,6 +508,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         }
         if (first_stamp) stamp(12);
         first_stamp = false;
+        vm_clear();
 #pragma unroll 1
         while (cur < seg_b) {
             const uint32_t nxt = grab();
@@ -520,6 +530,18 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                 for (int b = 0; b < NB; b++)
 #pragma unroll
                     for (int q = 0; q < 16; q++) acc[f][b][q] = 0;
+            // Every MFMA of the pass reads its accumulator from registers.  Left alone, the straight-line form
+            // starts each accumulator with the constant 0 as the C operand (v_mfma ..., 0); on this chip, with two
+            // waves of different priority alternating on the SIMD's matrix pipe, that form lost one step's term in
+            // a quarter of one accumulator (sixteen columns of one output row off by ~3e-6, a few passes per call:
+            // tests/test_gpu_fullsize.py caught it, the loop form -- which cannot use the constant -- never showed
+            // it, and neither does this: bit-stable results over repeated runs).
+            if constexpr (NG > 0) {
+#pragma unroll
+                for (int f = 0; f < 2; f++)
+#pragma unroll
+                    for (int b = 0; b < NB; b++) asm volatile("" : "+v"(acc[f][b]));
+            }
             if (active && (EXP & 2) == 0) {
                 // step s = GS g + j of the window: the A entries 2 s below the lane's first, B piece 2 j + h of
                 // tile n + g -- constants off two per-lane addresses (NG > 0) or off two running ones
@@ -596,6 +618,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
             stamp(2);
             if (in_next) land(x);
             else if (has_next) land_edge(pass_of(nxt));
+            vm_clear();
             stamp(3);
             if (active) {
                 const double *dc = reinterpret_cast<const double *>(tabp + tab_off + (size_t)G.ne * 128);
