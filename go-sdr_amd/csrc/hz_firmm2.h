@@ -78,7 +78,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     auto stamp = [&](int k) {
         if constexpr ((EXP & 64) != 0) {
             if (l == 0 && stamp_pass < 4)
-                stamps[(((size_t)wb * kWaves + wave) * 4 + (k == 0 || k == 7 ? 0 : k >= 8 ? 0 : stamp_pass)) * 8 + (k & 7)] = __builtin_amdgcn_s_memrealtime();
+                stamps[(((size_t)wb * kWaves + wave) * 4 + (k == 0 || k == 7 || (k >= 8 && k < 16) ? 0 : stamp_pass)) * 8 + (k & 7)] = __builtin_amdgcn_s_memrealtime();
         }
     };
     stamp(0);
@@ -288,7 +288,6 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     const int f_stride = G.ne * 64;
     const int groups = G.ks / GS;  // (NG > 0: the host launches this instantiation for ks = NG GS only)
 
-    const Run run1 = L.run[1];
     bool first_seg = true, first_stamp = true;
     const double k3 = __hiloint2double((1023 - G.shift) << 20, 0), k2 = k3 * 256.0, k1 = k3 * 65536.0, k0 = k3 * 16777216.0;  // 2^-S 256^d
     // a lane holds outputs 4 h + a (a = 0 .. 3) of tile n of each block: planes 2 f + pl at q = 4 a + 2 part + pl.
@@ -403,6 +402,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     auto has_passes = [&](int rr) { return rr < L.n && max(pb0, (uint32_t)L.pass_first[rr]) < min(pb1, (uint32_t)L.pass_end[rr]); };
     int ra = 0;
     while (ra < L.n && !has_passes(ra)) ra++;
+    Run ru = run0, rv = run0;
     bool a_done = false;
     int slot_a = 0;  // the half of the table area that holds run A's table
 #pragma unroll 1
@@ -440,10 +440,10 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         if (first_stamp) stamp(13);
         tasks_front(0);
         // (everything the queue reads from the kernel arguments by run, at once)
-        Run ru = run0, rv = run1;
-        if (ra == 1) ru = run1;
-        else if (ra > 1) ru = L.run[ra];  // (one line)
-        if (b_here && ra > 0) rv = L.run[rb];
+        // (run A of a later group is the previous group's run B: the lines stay in registers, one at a time is read)
+        if (!first_seg) ru = rv;
+        else if (ra > 0) ru = L.run[ra];  // (one line)
+        if (b_here) rv = L.run[rb];
         const int off_a = slot_a ? (int)tab_lds : 0, off_b = slot_a ? 0 : (int)tab_lds;
         {
             const int tp = (int)(table_bytes(G.ne) + 15) / 16;
@@ -511,10 +511,12 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         vm_clear();
 #pragma unroll 1
         while (cur < seg_b) {
+            stamp_pass++;
+            stamp(16);
             const uint32_t nxt = grab();
             const bool has_next = nxt < seg_b, in_next = prefetchable(nxt);  // uniform
+            stamp(23);
             if (in_next) issue(x, pass_of(nxt));
-            stamp_pass++;
             stamp(1);
             const bool sel = cur >= n_a;  // uniform: the pass belongs to run B
             const uint32_t m_lo = sel ? rv.m_lo : ru.m_lo, m_hi = sel ? rv.m_hi : ru.m_hi;
@@ -535,7 +537,9 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
             // waves of different priority alternating on the SIMD's matrix pipe, that form lost one step's term in
             // a quarter of one accumulator (sixteen columns of one output row off by ~3e-6, a few passes per call:
             // tests/test_gpu_fullsize.py caught it, the loop form -- which cannot use the constant -- never showed
-            // it, and neither does this: bit-stable results over repeated runs).
+            // it, and neither does this: bit-stable results over repeated runs).  (Sixteen registers of zeros kept
+            // for the kernel's life as the first step's C operand would save the 64 moves per pass, but the untied
+            // destination costs more registers than there are: spills in the pass loop.)
             if constexpr (NG > 0) {
 #pragma unroll
                 for (int f = 0; f < 2; f++)

@@ -132,6 +132,7 @@ template <int EXP, int MIXT = 1, int NGT = 17> static void run(void *const *in, 
                 printf("    wg %d wave %d: start %.2f tasks %.2f x-issued %.2f tab-issued %.2f tab-landed %.2f barrier %.2f landed %.2f |", wgx, w, (double)(s[0] - t0) / 100, (double)(s[1] - t0) / 100, (double)(s[5] - t0) / 100, (double)(s[6] - t0) / 100, (double)(s[2] - t0) / 100, (double)(s[3] - t0) / 100, (double)(s[4] - t0) / 100);
                 for (int pp = 1; pp <= 2; pp++) {
                     const unsigned long long *q = s + 8 * pp;
+                    if (q[1]) printf(" top %.2f grabbed %.2f", (double)(q[0] - t0) / 100, (double)(q[7] - t0) / 100);
                     if (q[1]) printf(" loop %.2f-%.2f land %.2f planes %.2f mixer %.2f stores %.2f |", (double)(q[1] - t0) / 100, (double)(q[2] - t0) / 100,
                                      (double)(q[3] - t0) / 100, (double)(q[4] - t0) / 100, (double)(q[5] - t0) / 100, (double)(q[6] - t0) / 100);
                 }
