@@ -391,6 +391,11 @@ def main():
         _, ms = timed(torch, lambda: ch.run(c, out), k, w)
         extra["shift_gain_c64"] = rate(n, float(np.median(ms)), 16)
         ch.close()
+        # ... and with the opt-in <= 1-ulp rotation factor (hzsdr_chain_shift_ulp1: not bit-identical, not `value`)
+        ch = ctx.chain(hz.FMT_C64, fs).shift(2.5e6).gain(0.5).shift_ulp1()
+        _, ms = timed(torch, lambda: ch.run(c, out), k, w)
+        extra["shift_gain_c64_ulp1"] = rate(n, float(np.median(ms)), 16)
+        ch.close()
         # cfg 3: reference ConvolutionReader semantics, 1024 bins (16 B/sample)
         H = torch.from_numpy(np.fft.fft(np.asarray(taps, np.complex128) / ntaps).astype(np.complex64)).cuda()
         _, ms = timed(torch, lambda: ctx.convolution_blocks(out, c, H), k, w)

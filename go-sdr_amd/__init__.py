@@ -561,6 +561,11 @@ class Chain:
         self.ctx._ck(lib.hzsdr_chain_mix_in_order(self._h, int(in_order)))
         return self
 
+    def shift_ulp1(self, on=True):
+        """Opt in to the <= 1-ulp Shift of terminal-less chains (include/hzsdr.h: hzsdr_chain_shift_ulp1)."""
+        self.ctx._ck(lib.hzsdr_chain_shift_ulp1(self._h, int(on)))
+        return self
+
     def plan(self, n_in):
         a, b = C.c_size_t(0), C.c_size_t(0)
         self.ctx._ck(lib.hzsdr_chain_plan(self._h, n_in, C.byref(a), C.byref(b)))

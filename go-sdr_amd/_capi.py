@@ -141,6 +141,7 @@ SIGNATURES = {
     "hzsdr_chain_convolution": (i32, [vp, vp, sz, u32]),
     "hzsdr_chain_fir_decimate": (i32, [vp, C.POINTER(f32), sz, u32]),
     "hzsdr_chain_mix_in_order": (i32, [vp, i32]),
+    "hzsdr_chain_shift_ulp1": (i32, [vp, i32]),
     "hzsdr_chain_plan": (i32, [vp, sz, psz, psz]),
     "hzsdr_chain_run": (i32, [vp, vp, sz, vp, sz, psz, psz]),
     "hzsdr_mgpu_open": (i32, [C.POINTER(C.c_int), i32, pvp]),

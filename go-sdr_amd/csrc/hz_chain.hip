@@ -55,6 +55,7 @@ struct hzsdr_chain {
     std::vector<double> taps_host;  // (re, im) pairs, exact copies of the caller's float32 taps
     std::map<uint64_t, void *> late_cache;
     bool mix_in_order = false;
+    bool shift_ulp1 = false;  // hzsdr_chain_shift_ulp1
     bool poly = false;  // hfreq / late_cache hold the polyphase layout (fold_poly)
     // int8 matrix form (hz_firmm.h): geometry, the taps on the device (fix-up workgroups) and
     // one digit table per distinct clock step (key 0: no Shift stage)
@@ -88,18 +89,8 @@ namespace hz {
 // raised once (160 KiB per CU on gfx950).
 template <class K, class... A>
 static void launch_fv(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, A... args) {
-    if (lds > 48 * 1024) {
-        // once per kernel instantiation AND device (a process may hold contexts on several GPUs:
-        // hzsdr_mgpu_*), to the CU's whole 160 KiB: a later launch of the same instantiation may ask
-        // for more than the first did (the matrix FIR's chunk grows with the tap count)
-        static unsigned long long raised = 0;  // bit per device
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev >= 0 && dev < 64 && !((raised >> dev) & 1)) {
-            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            raised |= 1ull << dev;
-        }
-    }
+    // (a failure here makes the launch below fail, which the stage's hipGetLastError reports)
+    if (lds > 48 * 1024) (void)raise_dynamic_lds((const void *)kernel);
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
 }
 
@@ -187,7 +178,7 @@ static int conv_generic_device(hzsdr_ctx *ctx, void *dst, const void *src1, cons
 }
 
 template <int FMT>
-static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, const EwProgram &P) {
+static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, const EwProgram &P, bool ulp1) {
     using R = typename Raw<FMT>::t;
     // four samples per lane (four interleaved Sincos chains) when both pointers allow the
     // wider vectors, else two; the ragged end, or everything for a sample-aligned Go
@@ -200,7 +191,13 @@ static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, cons
     if (ok(4) && n >= 4) {
         const size_t nvec = n / 4;
         const dim3 grid(blocks_for(ctx, nvec)), block(kThreads);
-        if (shape == SHAPE_SHIFT_GAIN)
+        if (shape == SHAPE_SHIFT_GAIN && ulp1)
+            hipLaunchKernelGGL((chain_map_kernel<FMT, 4, SHAPE_SHIFT_GAIN_ULP1>), grid, block, 0, ctx->stream, in,
+                               (float2 *)out, nvec, (uint64_t)0, P);
+        else if (shape == SHAPE_SHIFT && ulp1)
+            hipLaunchKernelGGL((chain_map_kernel<FMT, 4, SHAPE_SHIFT_ULP1>), grid, block, 0, ctx->stream, in,
+                               (float2 *)out, nvec, (uint64_t)0, P);
+        else if (shape == SHAPE_SHIFT_GAIN)
             hipLaunchKernelGGL((chain_map_kernel<FMT, 4, SHAPE_SHIFT_GAIN>), grid, block, 0, ctx->stream, in,
                                (float2 *)out, nvec, (uint64_t)0, P);
         else if (shape == SHAPE_SHIFT)
@@ -780,7 +777,7 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
                    const EwProgram &P) {
     hzsdr_ctx *ctx = c->ctx;
     switch (c->term) {
-    case TERM_NONE: launch_map<FMT>(ctx, in, out, n_cons, P); break;
+    case TERM_NONE: launch_map<FMT>(ctx, in, out, n_cons, P, c->shift_ulp1); break;
     case TERM_DECIMATE:
         hipLaunchKernelGGL((chain_decimate_kernel<FMT>), dim3(blocks_for(ctx, n_out)), dim3(kThreads), 0,
                            ctx->stream, in, (float2 *)out, n_out, kReaderBlock / c->factor,
@@ -808,12 +805,20 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
             int cont = 0;
             if (c->mm_ver == 2) {
                 if (mm2_plan(c, P, n_cons, in, out, &L2, &F2)) {
-                    HZ_TRY(mm2_launch(c, in, out, n_cons, P, L2, F2));
+                    const int rc = mm2_launch(c, in, out, n_cons, P, L2, F2);
+                    if (rc != HZSDR_OK) {  // (nothing was committed: the histories are the previous call's)
+                        c->rh_valid = false;
+                        return rc;
+                    }
                     ran = true;
                     cont = L2.cont;
                 }
             } else if (mm_plan(c, P, n_cons, in, out, &R, &F)) {
-                HZ_TRY(mm_launch(c, in, out, n_cons, P, R, F));
+                const int rc = mm_launch(c, in, out, n_cons, P, R, F);
+                if (rc != HZSDR_OK) {
+                    c->rh_valid = false;
+                    return rc;
+                }
                 ran = true;
                 cont = R.cont;
             }
@@ -1241,6 +1246,12 @@ int hzsdr_chain_last_fir_kernel(const hzsdr_chain *c, int *kernel) {
     if (!c || !kernel) return HZSDR_ERR_INVALID_ARGUMENT;
     *kernel = c->last_path == HZSDR_FIR_PATH_MATRIX ? (c->mm_ver == 2 ? HZSDR_FIR_KERNEL_MATRIX_PASSES : HZSDR_FIR_KERNEL_MATRIX_CHUNKS)
                                                     : c->last_path;
+    return HZSDR_OK;
+}
+
+int hzsdr_chain_shift_ulp1(hzsdr_chain *c, int on) {
+    if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
+    c->shift_ulp1 = on != 0;
     return HZSDR_OK;
 }
 

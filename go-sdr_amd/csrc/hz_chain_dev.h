@@ -173,11 +173,24 @@ __device__ __forceinline__ void ew_apply_seq(const EwProgram &P, float2 (&v)[W],
 // The two most common programs -- Shift, and Shift then Gain (BASELINE config 2) -- spelt
 // out, without the op loop: same operations in the same order, but straight-line code the
 // scheduler can overlap with the loads and stores around it.  SHAPE 0 = interpret.
-enum EwShape { SHAPE_ANY = 0, SHAPE_SHIFT = 1, SHAPE_SHIFT_GAIN = 2 };
+// SHAPE_*_ULP1 (hzsdr_chain_shift_ulp1): the rotation factor through the phase in turns and float32 polynomials
+// (sincos_turns32) -- within one float32 ulp of the factor the reference forms from math.Sincos of the same
+// float64 product, a third of the vector instructions.
+enum EwShape { SHAPE_ANY = 0, SHAPE_SHIFT = 1, SHAPE_SHIFT_GAIN = 2, SHAPE_SHIFT_ULP1 = 3, SHAPE_SHIFT_GAIN_ULP1 = 4 };
 template <int W, int SHAPE>
 __device__ __forceinline__ void ew_apply_shape(const EwProgram &P, float2 (&v)[W], uint64_t j0, NcoWin w) {
     if constexpr (SHAPE == SHAPE_ANY) {
         ew_apply_n<W>(P, v, j0, w);
+    } else if constexpr (SHAPE == SHAPE_SHIFT_ULP1 || SHAPE == SHAPE_SHIFT_GAIN_ULP1) {
+        float s[W], c[W];
+#pragma unroll
+        for (int l = 0; l < W; l++) sincos_turns32(turns32(__dmul_rn(P.op[0].tau_shift, nco_ts(P.segs, w, j0 + l))), s[l], c[l]);
+#pragma unroll
+        for (int l = 0; l < W; l++) {
+            v[l] = go_cmul(v[l], make_float2(c[l], s[l]));
+            if constexpr (SHAPE == SHAPE_SHIFT_GAIN_ULP1)
+                v[l] = make_float2(__fmul_rn(v[l].x, P.op[1].a), __fmul_rn(v[l].y, P.op[1].a));
+        }
     } else {
         double s[W], c[W];
 #pragma unroll

@@ -13,6 +13,12 @@
 
 #include "../../include/hzsdr.h"
 
+namespace hz {
+// Dynamic LDS above the default needs the kernel's limit raised (to the CU's whole 160 KiB: a later launch of the
+// same instantiation may ask for more than the first did), once per (kernel, device); hz_ctx.hip.  Thread-safe.
+int raise_dynamic_lds(const void *kernel);
+}  // namespace hz
+
 struct hzsdr_ctx {
     int device = 0;
     int memspace = HZSDR_MEM_HOST;

@@ -1,6 +1,24 @@
 // hz_ctx.hip -- context lifecycle, memory, staging (C-ABI: library / context section).
 #include "hz_common.h"
 
+#include <mutex>
+#include <set>
+#include <utility>
+
+namespace hz {
+int raise_dynamic_lds(const void *kernel) {
+    static std::mutex mu;
+    static std::set<std::pair<const void *, int>> raised;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return HZSDR_ERR_HIP;
+    std::lock_guard<std::mutex> lock(mu);
+    if (raised.count({kernel, dev})) return HZSDR_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return HZSDR_ERR_HIP;
+    raised.insert({kernel, dev});
+    return HZSDR_OK;
+}
+}  // namespace hz
+
 namespace hz {
 
 int ensure_slot(hzsdr_ctx *ctx, int slot, size_t bytes) {

@@ -288,8 +288,9 @@ __device__ __forceinline__ void sincos_turns32(uint32_t t, float &sn, float &cs)
 // turns from the product, 2^-33 from the rounding)
 __device__ __forceinline__ uint32_t turns32(double x) {
     const double t = __dmul_rn(x, 0.15915494309189534561);
-    const double f = t - floor(t);  // [0, 1)
-    return (uint32_t)__double2ll_rn(__dmul_rn(f, 4294967296.0));  // (2^32 wraps to 0: a whole turn)
+    const double f = __builtin_amdgcn_fract(t);  // [0, 1): one instruction (t - floor(t) is three)
+    // (one conversion instruction; a fraction that rounds up to a whole turn saturates to 2^32 - 1: 2^-32 turns off)
+    return __double2uint_rn(__dmul_rn(f, 4294967296.0));
 }
 
 }  // namespace hz

@@ -209,18 +209,8 @@ __global__ __launch_bounds__(fv::block(N)) void fft_plan_kernel16(const float2 *
 
 template <class K, class... A>
 static void launch_dyn(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, A... args) {
-    if (lds > 48 * 1024) {
-        // once per kernel instantiation AND device (a process may hold contexts on several GPUs:
-        // hzsdr_mgpu_*), to the CU's whole 160 KiB: a later launch of the same instantiation may ask
-        // for more than the first did (the matrix FIR's chunk grows with the tap count)
-        static unsigned long long raised = 0;  // bit per device
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev >= 0 && dev < 64 && !((raised >> dev) & 1)) {
-            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            raised |= 1ull << dev;
-        }
-    }
+    // (a failure here makes the launch below fail, which the stage's hipGetLastError reports)
+    if (lds > 48 * 1024) (void)raise_dynamic_lds((const void *)kernel);
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
 }
 

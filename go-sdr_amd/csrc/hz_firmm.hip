@@ -9,18 +9,10 @@ namespace hz {
 namespace mm {
 
 template <class K, class... A>
-static void launch(K kernel, dim3 grid, size_t lds, hipStream_t stream, A... args) {
-    if (lds > 48 * 1024) {
-        // once per kernel instantiation AND device, to the CU's whole 160 KiB (see launch_fv in hz_chain.hip)
-        static unsigned long long raised = 0;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev >= 0 && dev < 64 && !((raised >> dev) & 1)) {
-            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            raised |= 1ull << dev;
-        }
-    }
+static int launch(K kernel, dim3 grid, size_t lds, hipStream_t stream, A... args) {
+    if (lds > 48 * 1024) HZ_TRY(raise_dynamic_lds((const void *)kernel));
     hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, stream, args...);
+    return hipGetLastError() == hipSuccess ? HZSDR_OK : HZSDR_ERR_HIP;
 }
 
 bool factor_ok(unsigned D) { return D == 8 || D == 16 || D == 24 || D == 32 || D == 40 || D == 48 || D == 64; }
@@ -33,9 +25,8 @@ static int launch_fmt(hipStream_t stream, unsigned D, const void *in, float2 *ou
     const dim3 grid((unsigned)R.n_wg);  // (the fix-up and history tasks ride on the chunk workgroups)
 #define HZ_MM_CASE(DD)                                                                                              \
     case DD:                                                                                                        \
-        launch(fir_mm_kernel<FMT, DD>, grid, lds, stream, in, out, hist, new_hist, rhist, new_rhist, taps, n, g, P, R, F, \
-               (unsigned long long *)nullptr);                                                                      \
-        return HZSDR_OK;
+        return launch(fir_mm_kernel<FMT, DD>, grid, lds, stream, in, out, hist, new_hist, rhist, new_rhist, taps, n, g, P, R, \
+                      F, (unsigned long long *)nullptr);
     switch (D) {
         HZ_MM_CASE(8)
         HZ_MM_CASE(16)

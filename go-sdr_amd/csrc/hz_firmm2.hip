@@ -2,30 +2,15 @@
 #include <stdlib.h>
 
 #include <algorithm>
-#include <mutex>
-#include <set>
-#include <utility>
 
 #include "hz_firmm2.h"
 
 namespace hz {
 namespace mm2 {
 
-// Dynamic LDS above the default needs the kernel's limit raised, once per (kernel, device).
 template <class K, class... A>
 static int launch(K kernel, dim3 grid, size_t lds, hipStream_t stream, A... args) {
-    static std::mutex mu;
-    static std::set<std::pair<const void *, int>> raised;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return HZSDR_ERR_HIP;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        if (!raised.count({(const void *)kernel, dev})) {
-            if (hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return HZSDR_ERR_HIP;
-            raised.insert({(const void *)kernel, dev});
-        }
-    }
+    if (lds > 48 * 1024) HZ_TRY(raise_dynamic_lds((const void *)kernel));
     hipLaunchKernelGGL(kernel, grid, dim3(kThreads), lds, stream, args...);
     return hipGetLastError() == hipSuccess ? HZSDR_OK : HZSDR_ERR_HIP;
 }

@@ -141,7 +141,9 @@ int hzsdr_mgpu_open(const int *devices, int n_devices, hzsdr_mgpu **out) {
             hzsdr_mgpu_close(m);
             return rc;
         }
-        if (hipEventCreateWithFlags(&m->ready[s], hipEventDisableTiming) != hipSuccess ||
+        // (the events belong to the shard's device, whatever hzsdr_open left current)
+        if (hipSetDevice(devices[s]) != hipSuccess ||
+            hipEventCreateWithFlags(&m->ready[s], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&m->done[s], hipEventDisableTiming) != hipSuccess) {
             hzsdr_mgpu_close(m);
             return HZSDR_ERR_HIP;
@@ -155,7 +157,10 @@ int hzsdr_mgpu_open(const int *devices, int n_devices, hzsdr_mgpu **out) {
                 int can = 0;
                 if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
                     (void)hipSetDevice(devices[a]);
-                    (void)hipDeviceEnablePeerAccess(devices[b], 0);
+                    const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                        m->last_error = "peer access " + std::to_string(devices[a]) + " -> " + std::to_string(devices[b]) +
+                                        " could not be enabled (" + hipGetErrorString(e) + "): copies between them stage through the host";
                 }
                 (void)hipGetLastError();
             }

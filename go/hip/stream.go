@@ -199,6 +199,10 @@ func (ch *Chain) FIRDecimate(taps []complex64, factor uint) error {
 
 func (ch *Chain) MixInOrder(inOrder bool) error { return toErr(ch.x.c, C.hzsdr_chain_mix_in_order(ch.c, cbool(inOrder))) }
 
+// ShiftULP1 opts a terminal-less chain (ShiftReader, ShiftReader -> Gain) in to the Shift whose rotation
+// factor is within one float32 ulp of the reference's instead of bit-identical to it (include/hzsdr.h).
+func (ch *Chain) ShiftULP1(on bool) error { return toErr(ch.x.c, C.hzsdr_chain_shift_ulp1(ch.c, cbool(on))) }
+
 func (ch *Chain) Plan(nIn int) (consumed, out int, err error) {
 	var a, b C.size_t
 	rc := C.hzsdr_chain_plan(ch.c, C.size_t(nIn), &a, &b)

@@ -357,6 +357,15 @@ int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps_c64, size_t n_tap
  * bound, not to bits).  in_order = 1: every block mixes each input sample before the
  * filter, exactly as nested stream.ShiftReader -> filter Readers would. */
 int hzsdr_chain_mix_in_order(hzsdr_chain *c, int in_order);
+/* OPT-IN, off by default: a chain WITHOUT a terminal (ShiftReader, or ShiftReader -> Gain: BASELINE config 2)
+ * whose buffers allow four samples per lane forms the Shift's rotation factor from the phase in turns with
+ * float32 polynomials instead of an operation-for-operation math.Sincos in float64.  The float64 product
+ * (tau*shift)*ts and the clock are the reference's (stream/shifter.go:76-82); the factor complex64(cos, sin) is
+ * then within ONE float32 ulp per component of the reference's (0.8 ulp from the polynomials, 2^-53 |phase| / 2 pi
+ * turns from the reduction: phases up to 1e8 rad), so the outputs are no longer bit-identical to the
+ * reference's -- about three times fewer vector instructions: the kernel runs at the HBM rate.  Other
+ * programs and terminals are unaffected. */
+int hzsdr_chain_shift_ulp1(hzsdr_chain *c, int on);
 /* Which kernels the LAST hzsdr_chain_run of a FIR-decimate chain used (for tests, benchmarks and
  * logs; the results are held to the same bound either way):
  *   HZSDR_FIR_PATH_NONE       no run yet / no FIR-decimate terminal

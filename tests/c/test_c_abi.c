@@ -238,6 +238,7 @@ static void chain_and_ring(void) { /* go/hip/stream.go Chain, go/hip/ring.go */
     OK(hzsdr_chain_fir_decimate(c, taps, T, D));
     CHECK(hzsdr_chain_decimate(c, 2) == HZSDR_ERR_INVALID_ARGUMENT); /* one terminal stage */
     OK(hzsdr_chain_mix_in_order(c, 0));
+    OK(hzsdr_chain_shift_ulp1(c, 0));
     size_t cons = 0, outn = 0;
     OK(hzsdr_chain_plan(c, N, &cons, &outn));
     CHECK(cons == N && outn == N / D);

@@ -665,6 +665,40 @@ def test_chain_convert_shift_gain_equals_separate_ops(env, orc):
     ch.close()
 
 
+def test_chain_shift_ulp1_is_within_one_ulp_of_the_factor(env, orc):
+    """hzsdr_chain_shift_ulp1 (opt-in): unit inputs, so the output IS the rotation factor times the gain 1.
+    The reference's factor is complex64(math.Sincos(float64 phase)) = the true value rounded once (half an
+    ulp); the opt-in's is within one ulp of the true value: at most 1.5 ulp of 1.0-sized components apart
+    (2^-24 each: the bound below), over clock values on both sides of the 2*pi wrap and phases up to 1e8
+    rad.  Off (the default), the chain stays bit-identical to the reference."""
+    rate, shift = 20_000_000, 2.5e6
+    n = 1 << 20
+    x = np.zeros(n, np.complex64)
+    x[:] = 1.0
+    dx = env.put(x)
+    for t0 in (0.0, 3.0, 2 * math.pi - 0.02):
+        want = x.copy()
+        ref = orc.Shifter(rate)
+        ref.ts.value = t0
+        ref(shift, want)
+        for on in (False, True):
+            ch = env.ctx.chain(env.hz.FMT_C64, rate).shift(shift).gain(1.0)
+            if on:
+                ch.shift_ulp1()
+            ch.set_time(t0)
+            out = env.zeros("c64", n)
+            assert ch.run(dx, out) == (n, n)
+            got = env.get(out)
+            assert ch.time() == ref.ts.value
+            ch.close()
+            if not on:
+                assert bits_equal(got, want)
+                continue
+            d = got.view(np.float32).astype(np.float64) - want.view(np.float32).astype(np.float64)
+            assert np.abs(d).max() <= 1.5 * 2.0 ** -24, (t0, np.abs(d).max() * 2.0 ** 24)
+            assert not bits_equal(got, want)  # (it really is the other kernel)
+
+
 def test_chain_shift_roundtrip_two_ncos(env, orc, kats):
     k = kats["shift_roundtrip"]
     cw = orc.cw(k["n"], k["freq"], k["rate"], 0.0)
