@@ -46,11 +46,11 @@ using mm::find_le;
 using mm::task_window;
 
 // EXP (tools/mfma_fir2.hip; 0 in the library): 1 = no input loads, 2 = no matrix loop, 4 = no mixer,
-// 8 = no stores, 16 = no stagger, 64 = stamps.
+// 8 = no stores, 16 = no stagger, 32 = wave priorities (see the pass loop's end), 64 = stamps, 128 = no explicit vmcnt(0).
 // NG: the window's groups (ks / GS) when the instantiation is for ONE tap count -- the matrix loop is then
 // straight-line code (a loop header drains the operand pipeline: the compiler cannot count outstanding
 // loads across a back edge); 0: any window, a loop over the groups.
-template <int FMT, int D, int NG = 0, int EXP = 0>
+template <int FMT, int D, int NG = 0, int EXP = 0, int UG = 0>
 __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     const void *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ hist,
     float2 *__restrict__ new_hist, const uint8_t *__restrict__ rhist, uint8_t *__restrict__ new_rhist,
@@ -60,6 +60,8 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     constexpr int TB = tile_bytes(D), TS = tile_stride(D), PPT = TB / 16, GS = PPT / 2, NB = blocks_for(D);
     constexpr int kPassOut = pass_out(D);
     // pieces per lane of a pass image: known when the window is (NG groups: pass_tiles - 1 + NG tiles of PPT pieces)
+    // the matrix loop as straight-line code (NG > 0, UG = 0) or as a loop of UG groups per trip
+    constexpr bool STRAIGHT = NG > 0 && UG == 0;
     constexpr int KU = NG > 0 ? ((pass_tiles(D) - 1 + NG) * PPT + 63) / 64 : kU;
     constexpr bool kWhole = NG > 0 && ((pass_tiles(D) - 1 + NG) * PPT) % 64 == 0;  // every lane has KU pieces
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         }
     };
     stamp(0);
-    if constexpr ((EXP & 32) == 0) __builtin_amdgcn_s_setprio(1);
+    if constexpr ((EXP & 32) != 0) __builtin_amdgcn_s_setprio(1);
     const Run run0 = L.run[0];  // (read with the header: most workgroups of most calls are in run 0)
     // Everything the way to the first loads reads from the kernel arguments, wanted HERE: the compiler then issues
     // these scalar loads together and waits once (left alone it reads each next to its use: five load-wait
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     const int i_row = 4 * ((n >> 2) & 1) + (n >> 3);
     const int a_base = 64 * ((D / 8) * i_row - h + G.e0) + 16 * (n & 3);
     const int f_stride = G.ne * 64;
-    const int groups = G.ks / GS;  // (NG > 0: the host launches this instantiation for ks = NG GS only)
+    const int groups = NG > 0 ? NG : G.ks / GS;  // (NG > 0: the host launches this instantiation for ks = NG GS only)
 
     bool first_seg = true, first_stamp = true;
     const double k3 = __hiloint2double((1023 - G.shift) << 20, 0), k2 = k3 * 256.0, k1 = k3 * 65536.0, k0 = k3 * 16777216.0;  // 2^-S 256^d
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         __syncthreads();
         if (first_stamp) stamp(11);
         if (first_seg_prio) {  // (the first group of the workgroup: the small tasks)
-            if constexpr ((EXP & 32) == 0) __builtin_amdgcn_s_setprio(3);
+            if constexpr ((EXP & 32) != 0) __builtin_amdgcn_s_setprio(3);
             tasks_back();
             for (int round = 1; wb + round * L.grid < L.n_task; round++) {  // (uniform: calls with more tasks than workgroups)
                 __syncthreads();
@@ -491,9 +493,9 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                 __syncthreads();
                 tasks_back();
             }
-            if constexpr ((EXP & 32) == 0) __builtin_amdgcn_s_setprio(1);
+            if constexpr ((EXP & 32) != 0) __builtin_amdgcn_s_setprio(1);
         }
-        if constexpr ((EXP & 32) == 0) {
+        if constexpr ((EXP & 32) != 0) {
             if (first_seg_prio) __builtin_amdgcn_s_setprio(1);
         }
         if (wave >= kEarly) {
@@ -532,15 +534,9 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                 for (int b = 0; b < NB; b++)
 #pragma unroll
                     for (int q = 0; q < 16; q++) acc[f][b][q] = 0;
-            // Every MFMA of the pass reads its accumulator from registers.  Left alone, the straight-line form
-            // starts each accumulator with the constant 0 as the C operand (v_mfma ..., 0); on this chip, with two
-            // waves of different priority alternating on the SIMD's matrix pipe, that form lost one step's term in
-            // a quarter of one accumulator (sixteen columns of one output row off by ~3e-6, a few passes per call:
-            // tests/test_gpu_fullsize.py caught it, the loop form -- which cannot use the constant -- never showed
-            // it, and neither does this: bit-stable results over repeated runs).  (Sixteen registers of zeros kept
-            // for the kernel's life as the first step's C operand would save the 64 moves per pass, but the untied
-            // destination costs more registers than there are: spills in the pass loop.)
-            if constexpr (NG > 0) {
+            // (the accumulators as opaque registers: the straight-line form then starts them like every other
+            // step -- v_mfma acc, a, b, acc -- instead of with the constant 0 as the C operand)
+            if constexpr (STRAIGHT) {
 #pragma unroll
                 for (int f = 0; f < 2; f++)
 #pragma unroll
@@ -552,15 +548,15 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                 constexpr int KS = NG * GS;
                 // (NG > 0: the lane's LAST entry, and the compiler kept from folding the base back to the first
                 // one: DS offsets are unsigned, negative ones cost an address add per load)
-                int a_off = a_base - (NG > 0 ? 128 * KS : 0) + tab_off;
-                if constexpr (NG > 0) asm volatile("" : "+v"(a_off));
+                int a_off = a_base - (STRAIGHT ? 128 * KS : 0) + tab_off;
+                if constexpr (STRAIGHT) asm volatile("" : "+v"(a_off));
                 const uint8_t *ap = tabp + a_off;
                 const uint8_t *bp = slot + TS * n + 16 * h;
                 int s_done = 0, g_done = 0;  // (compile-time values when the groups are unrolled)
                 auto load_a = [&](v4i(&a)[2], int s) {
 #pragma unroll
                     for (int f = 0; f < 2; f++) {
-                        if constexpr (NG > 0) a[f] = *reinterpret_cast<const v4i *>(ap + f * (2 * (KS + 4) + (D / 8) * (kT - 1) + 1) * 64 + 128 * (KS - s));
+                        if constexpr (STRAIGHT) a[f] = *reinterpret_cast<const v4i *>(ap + f * (2 * (KS + 4) + (D / 8) * (kT - 1) + 1) * 64 + 128 * (KS - s));
                         else a[f] = *reinterpret_cast<const v4i *>(ap + f * f_stride - 128 * (s - s_done));
                     }
                 };
@@ -569,17 +565,17 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                     for (int q = 0; q < NB; q++) b[q] = *reinterpret_cast<const v4i *>(bp + TS * (g - g_done) + 32 * j + q * 32 * TS);
                 };
                 // operands two steps ahead of their MFMAs, in rings of three (straight-line code) or four
-                constexpr int RG = NG > 0 ? 3 : 4;
+                constexpr int RG = STRAIGHT ? 3 : 4;
                 v4i a[RG][2], b[RG][NB];
                 load_a(a[0], 0);
                 load_b(b[0], 0, 0);
                 load_a(a[1], 1);
                 load_b(b[1], 0, 1);
                 // one step; SC: the step as a compile-time value (straight-line form), or -1
-                auto step = [&](auto sc, int g, int j) {
+                auto step = [&](auto sc, int g, int j, int jx = 0) {
                     constexpr int SC = decltype(sc)::value;
                     const int s = SC >= 0 ? SC : GS * g + j;
-                    const int sx = SC >= 0 ? SC : j;  // (ring positions: the step mod 3, or j mod 4 of every group)
+                    const int sx = SC >= 0 ? SC : jx;  // (ring positions: the step mod 3, or the step of the trip mod 4)
                     load_a(a[(sx + 2) % RG], s + 2);
                     if (j + 2 < GS) load_b(b[(sx + 2) % RG], g, j + 2);
                     else load_b(b[(sx + 2) % RG], g + 1, j + 2 - GS);
@@ -598,7 +594,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 static_assert(GS == 4 || GS == 8, "ring indices repeat per group");
-                if constexpr (NG > 0) {
+                if constexpr (STRAIGHT) {
                     auto all = [&](auto self, auto sc) {
                         constexpr int S = decltype(sc)::value;
                         if constexpr (S < KS) {
@@ -608,14 +604,31 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                     };
                     all(all, std::integral_constant<int, 0>{});
                 } else {
+                    // UG groups per trip: a back edge costs a drain of the operand pipeline (the compiler cannot count
+                    // outstanding loads across it)
+                    constexpr int UGv = UG > 0 ? UG : 1;
+                    int g = 0;
 #pragma unroll 1
-                    for (int g = 0; g < groups; g++) {
+                    for (; g + UGv <= groups; g += UGv) {
 #pragma unroll
-                        for (int j = 0; j < GS; j++) step(std::integral_constant<int, -1>{}, g, j);
-                        ap -= 128 * GS;
-                        bp += TS;
-                        s_done += GS;
-                        g_done++;
+                        for (int gq = 0; gq < UGv; gq++)
+#pragma unroll
+                            for (int j = 0; j < GS; j++) step(std::integral_constant<int, -1>{}, g + gq, j, GS * gq + j);
+                        ap -= 128 * GS * UGv;
+                        bp += TS * UGv;
+                        s_done += GS * UGv;
+                        g_done += UGv;
+                    }
+                    if constexpr (UGv > 1) {
+#pragma unroll 1
+                        for (; g < groups; g++) {
+#pragma unroll
+                            for (int j = 0; j < GS; j++) step(std::integral_constant<int, -1>{}, g, j, j);
+                            ap -= 128 * GS;
+                            bp += TS;
+                            s_done += GS;
+                            g_done++;
+                        }
                     }
                 }
             }
@@ -638,11 +651,11 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                 }
             }
             stamp(6);
-            // The matrix pipe goes to the wave of higher priority, then to the OLDER one -- it is not shared: the
-            // second wave of a SIMD only fills the first one's gaps, and with equal priorities it would run its
-            // last pass alone at the end.  A wave on its first pass outranks one that has finished a pass, so the
-            // two alternate pass by pass and finish together.
-            if constexpr ((EXP & 32) == 0) __builtin_amdgcn_s_setprio(0);
+            // No wave priorities in the library (EXP & 32 turns them on for study: the matrix pipe goes to the wave of
+            // higher priority, then to the OLDER one, and ranking a wave on its first pass above one that has finished
+            // a pass makes the two waves of a SIMD alternate pass by pass): the kernel is as fast without them
+            // (tools/mfma_fir2.hip: 38.6 against 38.9 us).
+            if constexpr ((EXP & 32) != 0) __builtin_amdgcn_s_setprio(0);
             cur = nxt;
         }
         if (!b_here) break;

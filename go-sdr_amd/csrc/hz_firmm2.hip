@@ -26,8 +26,15 @@ static int launch_fmt(hipStream_t stream, int num_cus, unsigned D, const void *i
     (void)num_cus;
     unsigned long long *no_stamps = nullptr;
     // (the straight-line matrix loop exists for the 1024-tap window: 17 groups)
-    if (g.ks == 17 * 4)
+    static const int rolled = getenv("HZ_MM_ROLLED") ? atoi(getenv("HZ_MM_ROLLED")) : 0;  // (diagnostics)
+    if (g.ks == 17 * 4 && rolled == 0)
         return launch(fir_mm2_kernel<FMT, 8, 17>, dim3(grid), lds, stream, in, out, hist, new_hist, rhist, new_rhist, taps, n, g, L, P, F, no_stamps);
+    if (g.ks == 17 * 4 && rolled == 1)
+        return launch(fir_mm2_kernel<FMT, 8, 17, 0, 1>, dim3(grid), lds, stream, in, out, hist, new_hist, rhist, new_rhist, taps, n, g, L, P, F, no_stamps);
+    if (g.ks == 17 * 4 && rolled == 2)
+        return launch(fir_mm2_kernel<FMT, 8, 17, 0, 2>, dim3(grid), lds, stream, in, out, hist, new_hist, rhist, new_rhist, taps, n, g, L, P, F, no_stamps);
+    if (g.ks == 17 * 4 && rolled == 4)
+        return launch(fir_mm2_kernel<FMT, 8, 17, 0, 4>, dim3(grid), lds, stream, in, out, hist, new_hist, rhist, new_rhist, taps, n, g, L, P, F, no_stamps);
     return launch(fir_mm2_kernel<FMT, 8, 0>, dim3(grid), lds, stream, in, out, hist, new_hist, rhist, new_rhist, taps, n, g, L, P, F, no_stamps);
 }
 

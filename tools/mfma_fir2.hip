@@ -174,7 +174,7 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(tab, t.data(), t.size(), hipMemcpyHostToDevice));
     CK(hipMalloc(&g_stamps, 8 * 32 * 8 * 1024));
     CK(hipMemset(g_stamps, 0, 8 * 32 * 8 * 1024));
-    printf("fir_mm2_kernel<u8, 8>, 2^24 samples, %d taps; EXP 1 = no input loads, 2 = no matrix loop, 4 = no mixer, 8 = no stores, 32 = no priorities, 128 = no explicit vmcnt(0)\n", ntaps);
+    printf("fir_mm2_kernel<u8, 8>, 2^24 samples, %d taps; EXP 1 = no input loads, 2 = no matrix loop, 4 = no mixer, 8 = no stores, 32 = wave priorities, 128 = no explicit vmcnt(0)\n", ntaps);
     run<0, 0>(in, out, taps, tab, n, ntaps, true);
     run<128, 0>(in, out, taps, tab, n, ntaps, true);
     run<0, 0>(in, out, taps, tab, n, ntaps, true);
