@@ -102,9 +102,13 @@ static void launch_conv_n(hzsdr_ctx *ctx, const void *in, void *out, const void 
         constexpr int XPB = fv::xpb(N);
         const dim3 grid((unsigned)((nblocks + XPB - 1) / XPB)), block(fv::block(N));
         const size_t lds = (size_t)XPB * fv::lds_elems(N) * sizeof(cf);
-        if (direct)
-            launch_fv(conv_blocks_kernel16<N, FMT, false>, grid, block, lds, ctx->stream, in, (float2 *)out,
+        if (direct) {
+            // (a grid the chip holds at once: each workgroup walks its blocks with the next one's loads in flight)
+            const size_t resident = (size_t)ctx->num_cus * (size_t)(conv_occupancy(N, false) * 4 * 64 / fv::block(N));
+            const dim3 grid_p((unsigned)std::min<size_t>(grid.x, std::max<size_t>(resident, 1)));
+            launch_fv(conv_blocks_kernel16<N, FMT, false>, grid_p, block, lds, ctx->stream, in, (float2 *)out,
                       (const float2 *)filt, tabs, nblocks, dec, per, P);
+        }
         else
             launch_fv(conv_blocks_kernel16<N, FMT, true>, grid, block, lds, ctx->stream, in, (float2 *)out,
                       (const float2 *)filt, tabs, nblocks, dec, per, P);

@@ -586,44 +586,92 @@ __device__ __forceinline__ void stage_block16(float2 *lds, const void *in, const
 }
 
 // waves per SIMD the register allocator is asked to leave room for
-constexpr int conv_occupancy(int n) { return fv::block(n) >= 512 ? 2 : 4; }
+constexpr int conv_occupancy(int n, bool staged = true) { return fv::block(n) >= 512 ? 2 : 4; }
 
 template <int N, int FMT, bool STAGED>
-__global__ __launch_bounds__(fv::block(N), conv_occupancy(N)) void conv_blocks_kernel16(
+__global__ __launch_bounds__(fv::block(N), conv_occupancy(N, STAGED)) void conv_blocks_kernel16(
     const void *in, float2 *out, const float2 *__restrict__ filt, FvTabs tabs, size_t nblocks, unsigned dec,
     size_t per, EwProgram P) {
     constexpr int TPT = fv::tpt(N), XPB = fv::xpb(N), R0 = fv::first_radix(N);
-    const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
+    // (one block per workgroup: the block index is uniform, and the addresses are a scalar base plus a lane offset)
+    const int sub = XPB == 1 ? 0 : threadIdx.x / TPT, lane = XPB == 1 ? (int)threadIdx.x : threadIdx.x % TPT;
     cf *lds = fv_lds() + sub * fv::lds_elems(N);
-    const size_t b = (size_t)blockIdx.x * XPB + sub;
-    const bool live = b < nblocks;
     cf v[16];
+    auto tail = [&](size_t b, bool live, int lane) {
+        fv::backward<N>(v, lds, tabs.bwd, lane);
+        if (live) {
+            if (dec <= 1) {  // (uniform)
+                float2 *ob = out + b * N;
+#pragma unroll
+                for (int q = 0; q < 16; q++) ob[fv::edge_index<N, R0>(q, lane)] = fv::to2(v[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; q++) conv_store(out, b * N + fv::edge_index<N, R0>(q, lane), fv::to2(v[q]), dec, per);
+            }
+        }
+    };
+    auto finish = [&](size_t b, bool live, int lane) {
+        {
+            // freq1[i] = freq1[i] * freq[i] (fft/convolution.go:187-189).  Go forms this product in
+            // float64 and narrows once; between two float32 transforms that are themselves only
+            // error-bounded the extra half ulp buys nothing, and the float64 form cost 13 % of the
+            // kernel's vector instructions: a float32 product here (the closures of fft.Convolve,
+            // whose results ARE the reference's own arithmetic apart from the transforms, keep it)
+            // (the direct form in two halves: with the next block waiting in registers, sixteen bins in flight at
+            // once cost the fourth wave per SIMD its registers)
+            const cf *fl = (const cf *)filt + lane;
+            constexpr int HALF = STAGED ? 16 : 8;
+#pragma unroll
+            for (int q0 = 0; q0 < 16; q0 += HALF) {
+#pragma unroll
+                for (int q = q0; q < q0 + HALF; q++) v[q] = fv::cmul(v[q], fl[fv::edge_off<N, 16>(q)]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        tail(b, live, lane);
+    };
     if constexpr (STAGED) {
+        const size_t b = (size_t)blockIdx.x * XPB + sub;
+        const bool live = b < nblocks;
         stage_block16<N, FMT>((float2 *)lds, in, P, (int64_t)(b * N), ~(size_t)0, nullptr, 0, lane, live);
         __syncthreads();
         fv::load_lds<N, R0>(v, lds, lane);
         fv::forward<N, true>(v, lds, tabs.fwd, lane);
+        finish(b, live, lane);
     } else {
+        // c64 blocks straight from memory: the workgroup walks the blocks blockIdx.x, + gridDim.x, ... and has the
+        // NEXT block's sixteen loads per lane in flight while it transforms the current one -- load, transform and
+        // store phases of one block per workgroup left the memory pipes idle whenever the resident waves happened to
+        // compute (4.3 TB/s -> 4.7).  (Loads return in order: the filter's bins, read behind the forward transform, wait
+        // for the prefetch too -- it has the forward transform to arrive in.  Keeping the bins in registers across the
+        // blocks instead costs a wave per SIMD and was slower: 73 us against 57.)
+        using RT = typename Raw<FMT>::t;
+        const size_t stride = (size_t)gridDim.x * XPB;
+        size_t b = (size_t)blockIdx.x * XPB + sub;
+        RT nx[16];
+        {
+            const RT *pb = (const RT *)in + b * N;
 #pragma unroll
-        for (int q = 0; q < 16; q++)
-            v[q] = live ? fv::from2(Raw<FMT>::cvt(((const typename Raw<FMT>::t *)in)[b * N + fv::edge_index<N, R0>(q, lane)]))
-                        : cf{0.f, 0.f};
-        fv::forward<N>(v, lds, tabs.fwd, lane);
-    }
-    {
-        // freq1[i] = freq1[i] * freq[i] (fft/convolution.go:187-189).  Go forms this product in
-        // float64 and narrows once; between two float32 transforms that are themselves only
-        // error-bounded the extra half ulp buys nothing, and the float64 form cost 13 % of the
-        // kernel's vector instructions: a float32 product here (the closures of fft.Convolve,
-        // whose results ARE the reference's own arithmetic apart from the transforms, keep it)
-        const cf *fl = (const cf *)filt + lane;
+            for (int q = 0; q < 16; q++) nx[q] = b < nblocks ? pb[fv::edge_index<N, R0>(q, lane)] : RT{};
+        }
+#pragma unroll 1
+        for (size_t b0 = (size_t)blockIdx.x * XPB; b0 < nblocks; b0 += stride, b += stride) {  // (uniform trip count)
+            const bool live = b < nblocks;
+            // (the lane index as a value the compiler cannot prove loop-invariant: hoisted out of the loop, the
+            // trip's ~50 registers of addresses -- twiddle tables, filter, stores -- were spilled and reloaded)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
 #pragma unroll
-        for (int q = 0; q < 16; q++) v[q] = fv::cmul(v[q], fl[fv::edge_off<N, 16>(q)]);
-    }
-    fv::backward<N>(v, lds, tabs.bwd, lane);
-    if (live) {
+            for (int q = 0; q < 16; q++) v[q] = fv::from2(Raw<FMT>::cvt(nx[q]));
+            const size_t bn = b + stride;
+            if (bn < nblocks) {
+                const RT *pb = (const RT *)in + bn * N;
 #pragma unroll
-        for (int q = 0; q < 16; q++) conv_store(out, b * N + fv::edge_index<N, R0>(q, lane), fv::to2(v[q]), dec, per);
+                for (int q = 0; q < 16; q++) nx[q] = pb[fv::edge_index<N, R0>(q, ln)];
+            }
+            fv::forward<N>(v, lds, tabs.fwd, ln);
+            finish(b, live, ln);
+        }
     }
 }
 
