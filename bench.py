@@ -103,8 +103,11 @@ def self_launch(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=150)  # 20 periods of the clock (a 2*pi wrap every 7.5 steps)
-    ap.add_argument("--warmup", type=int, default=5)
+    # 60 periods of the clock (a 2*pi wrap every 7.5 steps).  The warm-up is 6 ms of the timed kernel: with 5 steps
+    # the chip was still ramping its clocks through the timed loop (41.2 .. 45.1 us per step run to run on one box;
+    # 40.0 .. 40.3 with these)
+    ap.add_argument("--steps", type=int, default=450)
+    ap.add_argument("--warmup", type=int, default=150)
     ap.add_argument("--log2n", type=int, default=24, help="samples per buffer = 2^log2n")
     ap.add_argument("--no-extra", action="store_true", help="skip the per-config side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle TIMING (the parity check still runs)")
