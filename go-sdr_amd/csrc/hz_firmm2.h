@@ -206,21 +206,21 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         if (wave < kWaves / 2 || fix_cnt == 0) return;
         const int ct = tid - 64 * (kWaves / 2);
         const int o = ct >> 4, sl = ct & 15;  // output, tap slice: sixteen lanes per output
-        double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
+        // a lane's 64 (ntaps / 16) taps as two packed float32 fma chains -- the reference's own arithmetic is float32
+        // throughout; a chain of 64 terms stays below 1e-7 here -- and the sixteen lanes' partial sums in float64:
+        // two vector instructions per tap instead of eight (the workgroup's first passes wait for this)
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f a0{0.f, 0.f}, a1{0.f, 0.f};
         if (o < fix_cnt) {
             const float2 *xo = xs + D * o + (G.ntaps - 1);
 #pragma unroll 8
             for (int kk = sl; kk < G.ntaps; kk += 16) {
                 const float2 hk = tl[kk], x = xo[-kk];
-                const double xr = x.x, xi = x.y, hr = hk.x, hi = hk.y;
-                ar = __fma_rn(xr, hr, ar);
-                br = __fma_rn(-xi, hi, br);
-                ai = __fma_rn(xr, hi, ai);
-                bi = __fma_rn(xi, hr, bi);
+                a0 = __builtin_elementwise_fma(v2f{x.x, x.x}, v2f{hk.x, hk.y}, a0);   // (xr hr, xr hi)
+                a1 = __builtin_elementwise_fma(v2f{-x.y, x.y}, v2f{hk.y, hk.x}, a1);  // (-xi hi, xi hr)
             }
         }
-        ar += br;
-        ai += bi;
+        double ar = (double)a0.x + (double)a1.x, ai = (double)a0.y + (double)a1.y;
 #pragma unroll
         for (int d = 1; d < 16; d <<= 1) {
             ar += __shfl_xor(ar, d);

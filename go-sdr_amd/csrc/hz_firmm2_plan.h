@@ -19,6 +19,7 @@ constexpr int kHistPer = 64; // samples per history task
 constexpr int kMaxRuns = 16;  // clock runs of a call that take the matrix path (more: the call keeps the transforms)
 constexpr int kMaxClockRuns = 32;  // hz_nco.h: kNcoMaxSegs, the runs of the clock that travel in the kernel arguments
 constexpr int kMaxFix = kMaxClockRuns + 2;
+constexpr uint64_t kShortRun = 2560;  // outputs: a clock run shorter than this is left to the fix-up tasks while they last
 constexpr int kU = 12;       // 16-byte pieces per lane of a pass image, any window (768 pieces = 12 KB at most)
 
 constexpr bool factor_ok(unsigned D) { return D == 8; }
@@ -181,6 +182,11 @@ inline bool plan_call(const PlanIn &in, const ClockRuns &cr, Plan *L, Fix *F, ui
         lo = (lo + tile - 1) / tile * tile;
         if (hi < n_out) hi = hi / tile * tile;
         if (!cr.tab[r] || hi < lo + 64) continue;  // a run without a table, or too short to bother
+        // A SHORT run -- the binades behind a 2*pi wrap of the clock double from a few samples up -- would put its
+        // table and one more multiplication of every pass it shares on ONE workgroup (the call's first: 24 items
+        // for its eight waves instead of 16, a whole pass time longer than the rest).  As fix-up tasks its outputs
+        // spread over the workgroups, one task each -- as long as there are workgroups left to take one.
+        if (hi - lo < kShortRun && (uint64_t)F->n_task + (hi - covered + kFixOut - 1) / kFixOut + 8 <= (uint64_t)in.max_grid) continue;
         if (L->n >= kMaxRuns) return false;
         Run &u = L->run[L->n];
         u.tab = cr.tab[r], u.m_lo = (uint32_t)lo, u.m_hi = (uint32_t)hi;
