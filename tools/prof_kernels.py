@@ -45,6 +45,9 @@ def main():
         elif w == "chain_c64":
             ch = ctx.chain(hz.FMT_C64, fs).fir_decimate(taps, D)
             fn = lambda: ch.run(xc, out[:n // D])
+        elif w == "fir_c64_d1":  # BASELINE config 3 in its north-star form: 1024 taps, no decimation
+            ch = ctx.chain(hz.FMT_C64, fs).fir_decimate(taps, 1)
+            fn = lambda: ch.run(xc, out)
         elif w == "conv":
             H = torch.from_numpy(np.fft.fft(np.asarray(taps, np.complex128) / 1024).astype(np.complex64)).cuda()
             fn = lambda: ctx.convolution_blocks(out, xc, H)
