@@ -74,7 +74,7 @@ template <int EXP, int MIXT = 1, int NGT = 17> static void run(void *const *in, 
     const int reps = 24;
     for (int r = 0; r < reps + 4; r++) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k, dim3(grid), dim3(mm2::kThreads), lds, 0, (const void *)in[r % 12], out, (const float2 *)nullptr,
+        hipLaunchKernelGGL(k, dim3(grid), dim3(mm2::kThreads), lds, 0, (const void *)in[getenv("ONEBUF") ? 0 : r % 12], out, (const float2 *)nullptr,
                            out + n_out, (const uint8_t *)taps, (uint8_t *)(out + n_out + 4096), taps, n, g, R, P, F, g_stamps);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
