@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""The north-star chain's two full-size calls (the second across the 2*pi wrap) R times over, every run
+compared bit for bit with a reference run: counts the runs that differ and says where (DESIGN.md section 4,
+"A hazard, and a known issue").  `python tools/repeat_check.py 150`; HZ_MM_ROLLED / HZ_MM_V1 select the kernel."""
+import importlib, sys, numpy as np
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+from util import rand_u8
+import torch
+hz = importlib.import_module("go-sdr_amd")
+TAU = 6.283185307179586476925286766559
+ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+n, fs, D = 1 << 24, 20_000_000, 8
+k = np.arange(1024) - 511.5
+taps = (2 / 16 * np.sinc(2 / 16 * k) * np.hamming(1024)).astype(np.complex64)
+dx = torch.from_numpy(rand_u8(9, 2 * n)).cuda()
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+outs = []
+for rep in range(R):
+    ch = ctx.chain(hz.FMT_U8, fs).shift(-fs / 8).fir_decimate(taps, D)
+    out = torch.zeros(2 * n // D, dtype=torch.complex64, device="cuda")
+    ch.run(dx[:n], out[:n // D]); ch.set_time(TAU - 0.4); ch.run(dx[n:], out[n // D:]); ctx.synchronize()
+    ch.close()
+    outs.append(torch.view_as_real(out).view(torch.int32).clone())
+# majority vote per element is costly; count pairwise differences against the modal run
+diffs = [[int((outs[i] != outs[j]).any(dim=1).sum().item()) for j in range(R)] for i in (0, 1, 2)]
+ref = min(range(3), key=lambda i: sorted(diffs[i])[R // 2])
+bad = [(j, diffs[ref][j]) for j in range(R) if diffs[ref][j]]
+print("reps", R, "glitchy runs:", len(bad), bad[:10])
+for j, _ in bad[:4]:
+    d = (outs[j] != outs[ref]).any(dim=1).nonzero().flatten().cpu().numpy()
+    a = outs[j].view(torch.float32)[d].cpu().numpy().astype(np.float64); b = outs[ref].view(torch.float32)[d].cpu().numpy().astype(np.float64)
+    m = d % (n // D)
+    print("  run", j, "outputs", len(d), "pass", sorted(set((m // 512).tolist()))[:3], "i", sorted(set((m % 8).tolist())), "tiles", ((m % 512) // 8).min(), ((m % 512) // 8).max(), "max |d|", np.abs(a - b).max())
