@@ -419,7 +419,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         auto pass_of = [&](uint32_t q) { return q < n_a ? a0 + q : b0 + (q - n_a); };
         auto prefetchable = [&](uint32_t q) { return q < seg_b && inside(pass_of(q)); };
         if (!first_seg) __syncthreads();  // every wave is done with the table that goes and with the queue
-        const int first_seg_prio = first_seg ? 1 : 0;
+        const bool first_group = first_seg;  // (the workgroup's first group: the small tasks ride on it)
         // Waves 0-3 (one per SIMD) take the queue's first items and put their bytes in flight at once;
         // waves 4-7 start behind the barrier: the first burst is half as large, and the two waves of a SIMD
         // start out of phase.
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         if (tid == 0) *ctr = kEarly;
         __syncthreads();
         if (first_stamp) stamp(11);
-        if (first_seg_prio) {  // (the first group of the workgroup: the small tasks)
+        if (first_group) {  // (the first group of the workgroup: the small tasks)
             if constexpr ((EXP & 32) != 0) __builtin_amdgcn_s_setprio(3);
             tasks_back();
             for (int round = 1; wb + round * L.grid < L.n_task; round++) {  // (uniform: calls with more tasks than workgroups)
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
             if constexpr ((EXP & 32) != 0) __builtin_amdgcn_s_setprio(1);
         }
         if constexpr ((EXP & 32) != 0) {
-            if (first_seg_prio) __builtin_amdgcn_s_setprio(1);
+            if (first_group) __builtin_amdgcn_s_setprio(1);
         }
         if (wave >= kEarly) {
             cur = grab();
