@@ -154,6 +154,36 @@ int main(int argc, char **argv) {
         }
         REQUIRE(at == NP);
     }
+    {
+        // directed: the benchmarked call in which the clock wraps (20 Msps, 2^24 samples, the wrap 0.4 s in).  The
+        // binades behind the wrap double from a few samples up: the short ones belong to the fix-up tasks (one per
+        // workgroup) and not, with a table each, to the call's first workgroup.
+        const uint64_t fs = 20000000, n = (uint64_t)1 << 24;
+        std::vector<hzsdr_nco_segment> segs(4096);
+        size_t need = 0;
+        double ts_end = 0;
+        REQUIRE(hzsdr_nco_segments(fs, tau - 0.4, n, segs.data(), segs.size(), &need, &ts_end) == HZSDR_OK);
+        REQUIRE(need <= (size_t)mm2::kMaxClockRuns);
+        std::vector<uint64_t> first(need);
+        std::vector<double> t0(need), step(need);
+        std::vector<const void *> tab(need);
+        static const char dummy2 = 0;
+        for (size_t k = 0; k < need; k++) first[k] = segs[k].first, t0[k] = segs[k].t0, step[k] = segs[k].step, tab[k] = segs[k].count >= 8 * 1024 ? &dummy2 : nullptr;
+        mm2::ClockRuns cr{(int)need, first.data(), t0.data(), step.data(), tab.data()};
+        mm2::PlanIn in{};
+        in.n_in = n, in.D = 8, in.ntaps = 1024, in.has_shift = true, in.cont = true, in.shift_op = 0, in.tau = -tau * 2.5e6, in.n_ops = 1, in.max_grid = 256;
+        mm2::Plan L;
+        mm2::Fix F;
+        REQUIRE(mm2::plan_call(in, cr, &L, &F, nullptr));
+        REQUIRE(F.n_task <= L.grid);
+        int with_table = 0;
+        for (size_t k = 0; k < need; k++) with_table += tab[k] != nullptr;
+        REQUIRE(L.n < with_table);  // some runs with a table went to the tasks ...
+        int short_planned = 0;  // (a short run stays on the matrix path only once the workgroups are used up)
+        for (int r = 0; r < L.n; r++) short_planned += L.run[r].m_hi - L.run[r].m_lo < mm2::kShortRun;
+        REQUIRE(short_planned <= 1);
+        printf("plan_fuzz wrap call: %zu clock runs, %d with a table, %d on the matrix path (%d of them short), %d fix-up tasks\n", need, with_table, L.n, short_planned, F.n_task);
+    }
     printf("plan_fuzz ok: %d cases, %ld planned, %ld kept the transforms\n", cases, planned, fell_back);
     return 0;
 }
