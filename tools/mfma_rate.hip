@@ -179,6 +179,65 @@ static void run8(int iters) {
            best * 1e3, best * 1e6 / (2.0 * iters * 8));
 }
 
+// VALU beside MFMA.  WAVES = 1: one wave per SIMD issues 4 MFMAs and NV independent float fmas per trip (its own
+// vector work in the shadow of its own matrix instructions).  WAVES = 2: the SIMD's first wave issues MFMAs only, its
+// second wave the fmas only (NV per 4 MFMA times, as long as the first wave runs): a partner's epilogue.
+template <int NV, int WAVES>
+__global__ __launch_bounds__(64 * 4 * WAVES) void mix_rate(int iters, float *fsink, int *sink, unsigned long long *cyc, int seed) {
+    const int wave = threadIdx.x >> 6;
+    v4i a = {seed + (int)threadIdx.x * 0x01020304, seed * 3, (int)threadIdx.x * 77, seed ^ 0x5a5a5a5a};
+    v4i b = {seed * 7 + (int)threadIdx.x * 0x11213141, seed * 5, (int)threadIdx.x * 91, seed ^ 0x3c3c3c3c};
+    float f[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) f[q] = 1.0f + (float)(threadIdx.x + q) * 1e-3f;
+    v16i acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[j][q] = 0;
+    const bool do_mfma = WAVES == 1 || wave < 4, do_valu = WAVES == 1 || wave >= 4;  // (uniform per wave)
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int i = 0; i < iters; i++) {
+        if (do_mfma) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[j], 0, 0, 0);
+        }
+        if (do_valu) {
+#pragma unroll
+            for (int q = 0; q < NV; q++) f[q & 7] = __fmaf_rn(f[q & 7], 1.0000001f, 1e-7f);
+        }
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + wave] = t1 - t0;
+    int r = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) r += acc[j][0] + acc[j][15];
+    float fs = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; q++) fs += f[q];
+    if (r == 0x7fffffff) sink[0] = r;
+    if (fs == 123.456f) fsink[0] = fs;
+}
+template <int NV, int WAVES> static void run_mix(int iters) {
+    int *sink;
+    float *fsink;
+    unsigned long long *cyc;
+    CK(hipMalloc(&sink, 4));
+    CK(hipMalloc(&fsink, 4));
+    CK(hipMalloc(&cyc, 8 * 8 * 256));
+    hipLaunchKernelGGL((mix_rate<NV, WAVES>), dim3(256), dim3(64 * 4 * WAVES), 0, 0, iters, fsink, sink, cyc, 777);
+    hipLaunchKernelGGL((mix_rate<NV, WAVES>), dim3(256), dim3(64 * 4 * WAVES), 0, 0, iters, fsink, sink, cyc, 778);
+    CK(hipDeviceSynchronize());
+    unsigned long long c[8];
+    CK(hipMemcpy(c, cyc, sizeof c, hipMemcpyDeviceToHost));
+    if (WAVES == 1)
+        printf("one wave per SIMD, 4 MFMAs + %2d fmas per trip: %.1f memtime ticks per trip (4 MFMAs alone: ~%d)\n", NV, (double)c[0] / iters, 4 * 8);
+    else
+        printf("two waves per SIMD, A: 4 MFMAs per trip, B: %2d fmas per trip: A %.1f ticks per trip, B %.1f ticks per trip = %.1f per fma\n", NV,
+               (double)c[0] / iters, (double)c[4] / iters, (double)c[4] / iters / NV);
+}
+
 template <int SHAPE> static void run(int wg_per_cu, int iters) {
     int *sink;
     unsigned long long *cyc;
@@ -209,6 +268,12 @@ template <int SHAPE> static void run(int wg_per_cu, int iters) {
 }
 
 int main() {
+    run_mix<0, 1>(4000);
+    run_mix<8, 1>(4000);
+    run_mix<16, 1>(4000);
+    run_mix<32, 1>(4000);
+    run_mix<8, 2>(4000);
+    run_mix<32, 2>(4000);
     run8(72);
     run8(720);
     run8m<0>(720);
