@@ -46,7 +46,10 @@ using mm::find_le;
 using mm::task_window;
 
 // EXP (tools/mfma_fir2.hip; 0 in the library): 1 = no input loads, 2 = no matrix loop, 4 = no mixer,
-// 8 = no stores, 16 = no stagger, 32 = wave priorities (see the pass loop's end), 64 = stamps, 128 = no explicit vmcnt(0).
+// 8 = no stores, 16 = no stagger, 32 = wave priorities (see the pass loop's end), 64 = stamps, 128 = no explicit vmcnt(0),
+// 256 = accumulator checksums per pass and lane, taken right behind the matrix loop and again behind the landing,
+// stored (first launch) or compared with the stored ones (tools/mm2_glitch.hip: which register, which lanes,
+// which compute unit, stale read or wrong sum).
 // NG: the window's groups (ks / GS) when the instantiation is for ONE tap count -- the matrix loop is then
 // straight-line code (a loop header drains the operand pipeline: the compiler cannot count outstanding
 // loads across a back edge); 0: any window, a loop over the groups.
@@ -633,10 +636,54 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                 }
             }
             stamp(2);
+            [[maybe_unused]] int cs_e1 = 0, cs_e2 = 0, cs_l1 = 0, cs_l2 = 0;
+            [[maybe_unused]] auto csum = [&](int &s1, int &s2) {
+#pragma unroll
+                for (int f = 0; f < 2; f++)
+#pragma unroll
+                    for (int b = 0; b < NB; b++) asm volatile("" : "+v"(acc[f][b]));
+                s1 = 0, s2 = 0;
+#pragma unroll
+                for (int f = 0; f < 2; f++)
+#pragma unroll
+                    for (int b = 0; b < NB; b++)
+#pragma unroll
+                        for (int q = 0; q < 16; q++) s1 += acc[f][b][q], s2 += (1 + q + 16 * (b + NB * f)) * acc[f][b][q];
+                asm volatile("" : "+v"(s1), "+v"(s2));
+            };
+            if constexpr ((EXP & 256) != 0) csum(cs_e1, cs_e2);
             if (in_next) land(x);
             else if (has_next) land_edge(pass_of(nxt));
             vm_clear();
             stamp(3);
+            if constexpr ((EXP & 256) != 0) {
+                // stamps[0]: 0 = store, 1 = compare; [1]: the stored checksums (int4 per pass and lane); [2]: records
+                // written; [8 + 8 r ...]: record r
+                csum(cs_l1, cs_l2);
+                v4i *ref = reinterpret_cast<v4i *>((uintptr_t)stamps[1]);
+                const size_t ci = (size_t)pass_of(cur) * 64 + l;
+                if (active) {
+                    if (stamps[0] == 0) {
+                        ref[ci] = v4i{cs_e1, cs_e2, cs_l1, cs_l2};
+                    } else {
+                        const v4i r = ref[ci];
+                        if (r[0] != cs_e1 || r[1] != cs_e2 || r[2] != cs_l1 || r[3] != cs_l2) {
+                            const unsigned long long slot_r = atomicAdd(&stamps[2], 1ull);
+                            if (slot_r < 4000) {
+                                unsigned long long *rec = stamps + 8 + 8 * slot_r;
+                                rec[0] = (unsigned long long)pass_of(cur) | ((unsigned long long)l << 32) | ((unsigned long long)wave << 40);
+                                rec[1] = (unsigned long long)(unsigned)wb | ((unsigned long long)(unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11)) << 32);
+                                rec[2] = (unsigned long long)(unsigned)cs_e1 | ((unsigned long long)(unsigned)cs_e2 << 32);
+                                rec[3] = (unsigned long long)(unsigned)cs_l1 | ((unsigned long long)(unsigned)cs_l2 << 32);
+                                rec[4] = (unsigned long long)(unsigned)r[0] | ((unsigned long long)(unsigned)r[1] << 32);
+                                rec[5] = (unsigned long long)(unsigned)r[2] | ((unsigned long long)(unsigned)r[3] << 32);
+                                rec[6] = __builtin_amdgcn_s_memrealtime();
+                                rec[7] = (unsigned long long)(unsigned)__builtin_amdgcn_s_getreg(20 | (31 << 11));
+                            }
+                        }
+                    }
+                }
+            }
             if (active) {
                 const double *dc = reinterpret_cast<const double *>(tabp + tab_off + (size_t)G.ne * 128);
                 float2 y[NB][4];
