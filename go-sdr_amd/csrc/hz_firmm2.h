@@ -35,6 +35,7 @@
 
 #include "hz_firmm.h"
 #include "hz_firmm2_plan.h"
+HZ_NO_PACKED_F32_BEGIN  // (hz_firmm.h says why)
 
 namespace hz {
 namespace mm2 {
@@ -49,7 +50,9 @@ using mm::task_window;
 // 8 = no stores, 16 = no stagger, 32 = wave priorities (see the pass loop's end), 64 = stamps, 128 = no explicit vmcnt(0),
 // 256 = accumulator checksums per pass and lane, taken right behind the matrix loop and again behind the landing,
 // stored (first launch) or compared with the stored ones (tools/mm2_glitch.hip: which register, which lanes,
-// which compute unit, stale read or wrong sum).
+// which compute unit, stale read or wrong sum), 512 = the mixer's step factors read from LDS in one batch, waited for
+// (lgkmcnt(0) and eight wait states) and pinned before their first use, 1024 = the first step factor formed a second
+// time from a second, fully waited read and compared with the one the mixer used (records as for 256).
 // NG: the window's groups (ks / GS) when the instantiation is for ONE tap count -- the matrix loop is then
 // straight-line code (a loop header drains the operand pipeline: the compiler cannot count outstanding
 // loads across a back edge); 0: any window, a loop over the groups.
@@ -341,18 +344,58 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                 const uint64_t ph0 = phi_r + (uint64_t)D * mb * dphi;
                 float s0, c0;
                 sincos_turns32((uint32_t)(ph0 >> 32), s0, c0);
+                [[maybe_unused]] float4 wpin[4 * NB];
+                [[maybe_unused]] float4 chk_w = make_float4(0.f, 0.f, 0.f, 0.f);
+                [[maybe_unused]] float chk_cs = 0.f, chk_sn = 0.f;
+                if constexpr ((EXP & 512) != 0) {
+#pragma unroll
+                    for (int i = 1; i < 4 * NB; i++) wpin[i] = wtab[i];
+                    asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 7" ::: "memory");
+#pragma unroll
+                    for (int i = 1; i < 4 * NB; i++) asm volatile("" : "+v"(wpin[i].x), "+v"(wpin[i].y), "+v"(wpin[i].z), "+v"(wpin[i].w));
+                }
 #pragma unroll
                 for (int b = 0; b < NB; b++)
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         float cs = c0, sn = s0;
                         if (b + q > 0) {
-                            const float4 w = wtab[4 * b + q];  // (cos hi, sin hi, cos lo, sin lo)
+                            float4 w;
+                            if constexpr ((EXP & 512) != 0) w = wpin[4 * b + q];
+                            else w = wtab[4 * b + q];  // (cos hi, sin hi, cos lo, sin lo)
                             cs = __fmaf_rn(c0, w.x, -(s0 * w.y)) + __fmaf_rn(c0, w.z, -(s0 * w.w));
                             sn = __fmaf_rn(c0, w.y, s0 * w.x) + __fmaf_rn(c0, w.w, s0 * w.z);
+                            if constexpr ((EXP & 1024) != 0) {
+                                if (b == 0 && q == 1) chk_w = w, chk_cs = cs, chk_sn = sn;
+                            }
                         }
                         y[b][q] = make_float2(__fmaf_rn(y[b][q].x, cs, -(y[b][q].y * sn)), __fmaf_rn(y[b][q].x, sn, y[b][q].y * cs));
                     }
+                if constexpr ((EXP & 1024) != 0) {
+                    float4 w2 = wtab[1];
+                    asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 7" : "+v"(w2.x), "+v"(w2.y), "+v"(w2.z), "+v"(w2.w));
+                    float c0b = c0, s0b = s0;
+                    asm volatile("" : "+v"(c0b), "+v"(s0b));
+                    float cs2 = __fmaf_rn(c0b, w2.x, -(s0b * w2.y)), csl = __fmaf_rn(c0b, w2.z, -(s0b * w2.w));
+                    float sn2 = __fmaf_rn(c0b, w2.y, s0b * w2.x), snl = __fmaf_rn(c0b, w2.w, s0b * w2.z);
+                    asm volatile("" : "+v"(cs2), "+v"(csl), "+v"(sn2), "+v"(snl));  // (no packed forms across these)
+                    cs2 += csl, sn2 += snl;
+                    if (__float_as_uint(cs2) != __float_as_uint(chk_cs) || __float_as_uint(sn2) != __float_as_uint(chk_sn)) {
+                        const unsigned long long slot_r = atomicAdd(&stamps[2], 1ull);
+                        if (slot_r < 4000) {
+                            unsigned long long *rec = stamps + 8 + 8 * slot_r;
+                            auto pk = [](float a, float bq) { return (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(bq) << 32); };
+                            rec[0] = (unsigned long long)(mb / kPassOut) | ((unsigned long long)l << 32) | ((unsigned long long)wave << 40);
+                            rec[1] = (unsigned long long)(unsigned)wb | ((unsigned long long)(unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11)) << 32);
+                            rec[2] = pk(c0, s0);
+                            rec[3] = pk(chk_cs, chk_sn);
+                            rec[4] = pk(cs2, sn2);
+                            rec[5] = pk(chk_w.x, chk_w.y);
+                            rec[6] = pk(chk_w.z, chk_w.w);
+                            rec[7] = pk(w2.z, w2.w);
+                        }
+                    }
+                }
             } else {
                 // (programs with several Shift stages: float64 phases, as hz_firmm.h)
                 const double step = P.segs.step[seg];
@@ -729,3 +772,4 @@ int launch_fir(hipStream_t stream, int num_cus, int fmt, unsigned D, const void 
 
 }  // namespace mm2
 }  // namespace hz
+HZ_NO_PACKED_F32_END

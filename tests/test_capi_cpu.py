@@ -224,3 +224,57 @@ def test_plain_c_walkthrough_compiles_as_c99_and_covers_the_header():
                                "-c", src, "-o", os.path.join(d, "t.o")])
     used = set(re.findall(r"\b(hzsdr_[a-z0-9_]+)\s*\(", open(src).read()))
     assert set(_header_symbols()) - used == set(), sorted(set(_header_symbols()) - used)
+
+
+def _device_code_objects(path):
+    """The gfx950 code objects bundled into a HIP shared library (clang offload bundles, uncompressed)."""
+    import struct
+    data = open(path, "rb").read()
+    magic, i, out = b"__CLANG_OFFLOAD_BUNDLE__", 0, []
+    while True:
+        i = data.find(magic, i)
+        if i < 0:
+            return out
+        (count,) = struct.unpack_from("<Q", data, i + 24)
+        off = i + 32
+        for _ in range(count):
+            o, size, tl = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + tl].decode()
+            off += tl
+            if "amdgcn" in triple and size:
+                out.append(data[i + o:i + o + size])
+        i += len(magic)
+
+
+def test_no_packed_float32_instruction_in_a_kernel_that_issues_mfmas(tmp_path):
+    """gfx950, measured (tools/pk_glitch.hip, profiles/r04_pk_glitch.txt): a v_pk_{mul,add,fma}_f32 whose op_sel
+    takes the high register of src1 for the low result reads that operand as zero in lanes 48-63 when the SIMD's
+    other wave issues an MFMA at the wrong cycle -- the cause of the matrix FIR's non-repeatable pass.  The
+    kernels that hold MFMAs (csrc/hz_firmm.h, hz_firmm2.h) are therefore compiled without packed float32
+    instructions; this test disassembles every kernel of the built library and holds them to it."""
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    lib = os.path.join(ROOT, "go-sdr_amd", "libhzsdr_hip.so")
+    objs = _device_code_objects(lib)
+    assert objs, "no gfx950 code object found in the library"
+    with_mfma, offenders = 0, {}
+    for k, blob in enumerate(objs):
+        f = tmp_path / f"co{k}.elf"
+        f.write_bytes(blob)
+        text = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(f)], capture_output=True, text=True, check=True).stdout
+        cur, mfma, packed = None, {}, {}
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                cur = m.group(1)
+                mfma[cur] = packed[cur] = 0
+            elif cur is not None:
+                mfma[cur] += "v_mfma" in line
+                packed[cur] += bool(re.search(r"v_pk_(mul|add|fma)_f32", line))
+        with_mfma += sum(1 for name in mfma if mfma[name])
+        offenders.update({name: packed[name] for name in mfma if mfma[name] and packed[name]})
+    assert with_mfma >= 10, with_mfma  # (the matrix FIR's instantiations are there at all)
+    assert not offenders, offenders

@@ -43,22 +43,17 @@ def lowpass(ntaps, cutoff):
 
 def test_north_star_is_repeatable(hz, dev):
     """The same two calls (the second across the 2*pi wrap: eleven runs on the matrix path) six times
-    over.  The integer sums are exact and nothing in the kernel is order-dependent, so the outputs
-    should be bit-identical from run to run -- and on most boxes they are, 59 runs of 59.  On some
-    boxes a run in ~20 has ONE pass whose last sixteen tiles differ in one output row by one or two
-    float32 ulp (<= 3e-8; DESIGN.md, known issues: the low digit plane's term of the last window
-    step is missing in a quarter of one accumulator; the cause is not found -- neither the loop's
-    form, wave priorities, extra wait states behind the loop nor zero-tap steps appended to it
-    change it).  The first straight-line build started its accumulators with the constant 0 as the C
-    operand and lost the two low planes there (3e-6: beyond the FIR bound) -- that is what this test
-    is for: it allows the ulp-sized event (a handful of outputs, 1e-7) and nothing larger; the
-    comparison with the oracle below holds either way."""
+    over: the integer sums are exact and nothing in the kernel is order-dependent, so the outputs are
+    bit-identical from run to run.  Round 3 had to allow an ulp-sized event here; its cause was a gfx950
+    instruction -- packed float32 with op_sel beside the other wave's MFMAs -- that the matrix kernels are
+    now compiled without (csrc/hz_firmm.h, tools/pk_glitch.hip), and the comparison is
+    bitwise again.  tools/repeat_check.py runs the same hundreds of times (profiles/r04_repeat_check.txt)."""
     ctx, torch = dev
     n, fs, D = 1 << 24, 20_000_000, 8
     shift, taps = -fs / 8, lowpass(1024, 1.0 / 16)
     dx = torch.from_numpy(rand_u8(9, 2 * n)).cuda()
     runs = []
-    for rep in range(6):
+    for rep in range(12):
         ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D)
         out = torch.zeros(2 * n // D, dtype=torch.complex64, device="cuda")
         ch.run(dx[:n], out[:n // D])
@@ -67,11 +62,10 @@ def test_north_star_is_repeatable(hz, dev):
         ctx.synchronize()
         assert ch.last_fir_kernel() == hz.FIR_KERNEL_MATRIX_PASSES
         ch.close()
-        runs.append(out)
-    for rep in range(1, 6):
-        d = torch.view_as_real(runs[rep]) - torch.view_as_real(runs[0])
-        differing = int((d != 0).any(dim=1).sum().item())
-        assert differing <= 64 and float(d.abs().max().item()) <= 1e-7, (rep, differing, float(d.abs().max().item()))
+        runs.append(torch.view_as_real(out).view(torch.int32))
+    for rep in range(1, len(runs)):
+        differing = int((runs[rep] != runs[0]).any(dim=1).sum().item())
+        assert differing == 0, (rep, differing)
 
 
 def test_north_star_full_size(hz, dev, orc):

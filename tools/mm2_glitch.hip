@@ -15,7 +15,9 @@
 // wherever it happens, not only where the real filter's taps are tiny).
 //   tools/bin/mm2_glitch [launches per leg = 20000] [taps = 1024]
 #include <stdio.h>
+#include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <map>
@@ -52,16 +54,84 @@ static long long model_acc(int b, uint32_t pass, int f, int blk, int reg, int la
     return sum;
 }
 
-__global__ void compare_kernel(const uint32_t *__restrict__ a, const uint32_t *__restrict__ ref, size_t nwords, unsigned long long *rec) {
+__global__ void compare_kernel(const uint32_t *__restrict__ a, const uint32_t *__restrict__ ref, size_t nwords, unsigned long long *rec, unsigned launch) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) {
         if (a[i] != ref[i]) {
             const unsigned long long s = atomicAdd(&rec[0], 1ull);
-            if (s < 4000) {
-                rec[8 + 2 * s] = i;
+            if (s < 100000) {
+                rec[8 + 2 * s] = i | ((unsigned long long)launch << 32);
                 rec[9 + 2 * s] = (unsigned long long)a[i] | ((unsigned long long)ref[i] << 32);
             }
         }
     }
+}
+
+
+// ---- leg 2: the kernel without instrumentation, outputs compared ---------------------------------------------
+template <int EXP>
+static void leg2(const char *name, int launches, void *const *in, float2 *out, const float2 *taps, size_t n, const mm2::Geom &g, const mm2::Plan &R,
+                 const EwProgram &P, const mm2::Fix &F, size_t lds) {
+    const uint32_t n_out = (uint32_t)(n / D);
+    auto k = mm2::fir_mm2_kernel<HZSDR_FMT_U8, D, 17, EXP>;
+    CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    uint32_t *refo[NBUF];
+    unsigned long long *rec;
+    const size_t rec_words = 8 + 2 * 100000;
+    CK(hipMalloc(&rec, rec_words * 8));
+    CK(hipMemset(rec, 0, rec_words * 8));
+    for (int b = 0; b < NBUF; b++) CK(hipMalloc(&refo[b], (size_t)n_out * 8));
+    unsigned long long *no_stamps = nullptr;
+    for (int r = 0; r < launches; r++) {
+        const int b = r % NBUF;
+        hipLaunchKernelGGL(k, dim3(R.grid), dim3(mm2::kThreads), lds, 0, (const void *)in[b], out, (const float2 *)nullptr, out + n_out,
+                           (const uint8_t *)taps, (uint8_t *)(out + n_out + 4096), taps, n, g, R, P, F, no_stamps);
+        if (r < NBUF) CK(hipMemcpyAsync(refo[b], out, (size_t)n_out * 8, hipMemcpyDeviceToDevice, 0));
+        else hipLaunchKernelGGL(compare_kernel, dim3(1024), dim3(256), 0, 0, (const uint32_t *)out, (const uint32_t *)refo[b], (size_t)n_out * 2, rec, (unsigned)r);
+    }
+    CK(hipDeviceSynchronize());
+    CK(hipGetLastError());
+    std::vector<unsigned long long> c(rec_words);
+    CK(hipMemcpy(c.data(), rec, rec_words * 8, hipMemcpyDeviceToHost));
+    // events = (launch, pass); per event: rows, tiles, words
+    struct Ev { int words = 0; unsigned rows = 0; unsigned long long tiles = 0; unsigned maxulp = 0; };
+    std::map<unsigned long long, Ev> ev;
+    const unsigned long long nrec = std::min<unsigned long long>(c[0], 100000);
+    for (unsigned long long r = 0; r < nrec; r++) {
+        const unsigned long long i = c[8 + 2 * r] & 0xffffffffull, launch = c[8 + 2 * r] >> 32, m = i / 2;
+        Ev &e = ev[(launch << 32) | (m / 512)];
+        e.words++;
+        e.rows |= 1u << (m % 8);
+        e.tiles |= 1ull << ((m % 512) / 8);
+        const unsigned a = (unsigned)c[9 + 2 * r], bq = (unsigned)(c[9 + 2 * r] >> 32);
+        e.maxulp = std::max(e.maxulp, a > bq ? a - bq : bq - a);
+    }
+    printf("leg 2, %s: %llu differing output words in %d compared launches: %zu events (launch, pass)\n", name, c[0], launches - NBUF, ev.size());
+    std::map<unsigned, int> by_wg, by_slot, by_rows;
+    std::map<unsigned long long, int> by_tiles;
+    for (auto &kv : ev) {
+        const unsigned pass = (unsigned)kv.first;
+        by_wg[pass / 16]++;
+        by_slot[pass % 16]++;
+        by_rows[kv.second.rows]++;
+        by_tiles[kv.second.tiles]++;
+    }
+    printf("    by pass %% 16 (a workgroup's k-th pass):");
+    for (auto &kv : by_slot) printf(" %u:%d", kv.first, kv.second);
+    printf("\n    by workgroup:");
+    for (auto &kv : by_wg) printf(" %u:%d", kv.first, kv.second);
+    printf("\n    by set of output rows (bit i = row i):");
+    for (auto &kv : by_rows) printf(" %02x:%d", kv.first, kv.second);
+    printf("\n    by set of tiles (bit t = tile t of 64):");
+    for (auto &kv : by_tiles) printf(" %016llx:%d", kv.first, kv.second);
+    printf("\n");
+    int shown = 0;
+    for (auto &kv : ev) {
+        if (shown++ >= 6) break;
+        printf("    launch %llu pass %u: %d words, rows %02x, tiles %016llx, largest difference %u ulp\n", kv.first >> 32, (unsigned)kv.first, kv.second.words,
+               kv.second.rows, kv.second.tiles, kv.second.maxulp);
+    }
+    for (int b = 0; b < NBUF; b++) CK(hipFree(refo[b]));
+    CK(hipFree(rec));
 }
 
 int main(int argc, char **argv) {
@@ -243,34 +313,38 @@ int main(int argc, char **argv) {
             CK(hipFree(ctl[b]));
         }
     }
-    // ---- leg 2: the unmodified kernel, outputs compared ---------------------------------------------------------
+    // ---- leg 3: the first step factor, formed twice (EXP 1024) ---------------------------------------------------
     {
-        auto k = mm2::fir_mm2_kernel<HZSDR_FMT_U8, D, 17, 0>;
+        auto k = mm2::fir_mm2_kernel<HZSDR_FMT_U8, D, 17, 1024>;
         CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        uint32_t *refo[NBUF];
-        unsigned long long *rec;
-        const size_t rec_words = 8 + 2 * 4000;
-        CK(hipMalloc(&rec, rec_words * 8));
-        CK(hipMemset(rec, 0, rec_words * 8));
-        for (int b = 0; b < NBUF; b++) CK(hipMalloc(&refo[b], (size_t)n_out * 8));
-        unsigned long long *no_stamps = nullptr;
-        for (int r = 0; r < launches; r++) {
-            const int b = r % NBUF;
-            hipLaunchKernelGGL(k, dim3(R.grid), dim3(mm2::kThreads), lds, 0, (const void *)in[b], out, (const float2 *)nullptr, out + n_out,
-                               (const uint8_t *)taps, (uint8_t *)(out + n_out + 4096), taps, n, g, R, P, F, no_stamps);
-            if (r < NBUF) CK(hipMemcpyAsync(refo[b], out, (size_t)n_out * 8, hipMemcpyDeviceToDevice, 0));
-            else hipLaunchKernelGGL(compare_kernel, dim3(1024), dim3(256), 0, 0, (const uint32_t *)out, (const uint32_t *)refo[b], (size_t)n_out * 2, rec);
-        }
+        const size_t ctl_words = 8 + 8 * 4000;
+        unsigned long long *ctl;
+        CK(hipMalloc(&ctl, ctl_words * 8));
+        CK(hipMemset(ctl, 0, ctl_words * 8));
+        for (int r = 0; r < launches; r++)
+            hipLaunchKernelGGL(k, dim3(R.grid), dim3(mm2::kThreads), lds, 0, (const void *)in[r % NBUF], out, (const float2 *)nullptr, out + n_out,
+                               (const uint8_t *)taps, (uint8_t *)(out + n_out + 4096), taps, n, g, R, P, F, ctl);
         CK(hipDeviceSynchronize());
         CK(hipGetLastError());
-        std::vector<unsigned long long> c(rec_words);
-        CK(hipMemcpy(c.data(), rec, rec_words * 8, hipMemcpyDeviceToHost));
-        printf("leg 2: %llu differing output words in %d compared launches of the unmodified kernel\n", c[0], launches - NBUF);
-        for (unsigned long long r = 0; r < std::min<unsigned long long>(c[0], 48); r++) {
-            const unsigned long long i = c[8 + 2 * r], m = i / 2;
-            printf("    output %llu (%s): pass %llu tile %llu row %llu: got %08x ref %08x\n", m, i & 1 ? "im" : "re", m / 512, (m % 512) / 8, m % 8,
-                   (unsigned)c[9 + 2 * r], (unsigned)(c[9 + 2 * r] >> 32));
+        std::vector<unsigned long long> c(ctl_words);
+        CK(hipMemcpy(c.data(), ctl, ctl_words * 8, hipMemcpyDeviceToHost));
+        printf("leg 3 (EXP 1024): %llu lanes whose first step factor differs from its second evaluation, %d launches\n", c[2], launches);
+        auto f = [](unsigned long long v, int hi) { unsigned u = hi ? (unsigned)(v >> 32) : (unsigned)v; float x; memcpy(&x, &u, 4); return x; };
+        for (unsigned long long r = 0; r < std::min<unsigned long long>(c[2], 24); r++) {
+            const unsigned long long *q = &c[8 + 8 * r];
+            const float c0 = f(q[2], 0), s0 = f(q[2], 1), cs1 = f(q[3], 0), sn1 = f(q[3], 1), cs2 = f(q[4], 0), sn2 = f(q[4], 1);
+            const float wx = f(q[5], 0), wy = f(q[5], 1), wz = f(q[6], 0), ww = f(q[6], 1);
+            const float cs_hi = fmaf(c0, wx, -(s0 * wy)), sn_hi = fmaf(c0, wy, s0 * wx), cs_lo = fmaf(c0, wz, -(s0 * ww)), sn_lo = fmaf(c0, ww, s0 * wz);
+            printf("    pass %u lane %d wave %d wg %u: c0 %.9g s0 %.9g | used cs %.9g sn %.9g | again cs %.9g sn %.9g | w %.9g %.9g %.9g %.9g (again lo %.9g %.9g)\n"
+                   "        hi parts %.9g %.9g, lo parts %.9g %.9g; used - hi = %.9g %.9g\n",
+                   (unsigned)q[0], (int)((q[0] >> 32) & 0xff), (int)(q[0] >> 40), (unsigned)q[1], c0, s0, cs1, sn1, cs2, sn2, wx, wy, wz, ww, f(q[7], 0),
+                   f(q[7], 1), cs_hi, sn_hi, cs_lo, sn_lo, cs1 - cs_hi, sn1 - sn_hi);
         }
+        CK(hipFree(ctl));
     }
+    leg2<0>("the unmodified kernel", launches, in, out, taps, n, g, R, P, F, lds);
+    leg2<4>("no mixer (EXP 4)", launches, in, out, taps, n, g, R, P, F, lds);
+    leg2<512>("the mixer's step factors waited for and pinned (EXP 512)", launches, in, out, taps, n, g, R, P, F, lds);
+    leg2<128>("no explicit vmcnt(0) (EXP 128)", launches, in, out, taps, n, g, R, P, F, lds);
     return 0;
 }
