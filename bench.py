@@ -222,7 +222,14 @@ def main():
         passes_form = kern == getattr(hz, "FIR_KERNEL_MATRIX_PASSES", -1)
         tile, steps = (8, 68) if passes_form else (16, 72)       # outputs per tile, 32-byte window steps (hz_firmm2.h / hz_firmm.h)
         alg_ops = 4 * 2 * ntaps * (n // D)                        # the direct form, no digit planes
-        exe_ops = 4 * (n // D // tile) * steps * 32 * 32 * 2      # planes x tiles x steps x (32 rows x 32 bytes) x 2
+        # MFMAs as issued x 65 536 (32 x 32 x 32 x 2).  A tile's 32 matrix rows are its outputs x (re, im) x the planes ONE
+        # A fragment holds: the passes form keeps TWO planes per fragment (8 outputs x 2 x 2), so its four planes
+        # are 2 fragments per tile and step; the chunk form one plane per fragment (16 outputs x 2), 4 per tile
+        frags = 2 if passes_form else 4
+        exe_ops = frags * (n // D // tile) * steps * 32 * 32 * 2    # (a 32-tile column block x a step x a fragment = one MFMA = 65 536)
+        if passes_form and ntaps == 1024:
+            # cross-check against the kernel's code: 272 v_mfma_i32_32x32x32_i8 per 512-output pass (4 per step x 68)
+            assert exe_ops == 272 * (n // D // 512) * 65536, (exe_ops, 272 * (n // D // 512) * 65536)
         roof = dict(hbm)
         roof.update({
             "kernel": ("hz::mm2::fir_mm2_kernel<u8, D = 8, 17 groups>" if passes_form else "hz::mm::fir_mm_kernel<u8, D = 8>"),
@@ -234,9 +241,10 @@ def main():
             "mfma_algorithmic_frac": round(alg_ops / t_s / 1e12 / I8_PEAK_TOPS, 4),
             "mfma_issue": {
                 "executed_int8_ops_per_launch": int(exe_ops),
-                "ops_are": "int8 multiply-adds x 2 as issued: 4 base-256 digit planes of the 32-bit fixed-point "
-                           "taps x tiles x window steps x 32 rows x 32 bytes (the tile windows' zero padding "
-                           "included) -- an implementation figure, not algorithmic work",
+                "ops_are": "int8 multiply-adds x 2 as issued: v_mfma_i32_32x32x32_i8 instructions x 65 536 -- the 4 "
+                           "base-256 digit planes of the 32-bit fixed-point taps (two planes share an A fragment "
+                           "in the passes form), tiles x window steps, the tile windows' zero padding included -- "
+                           "an implementation figure, not algorithmic work",
                 "achieved": round(exe_ops / t_s / 1e12, 1), "peak": I8_PEAK_TOPS, "unit": "Top/s",
                 "frac": round(exe_ops / t_s / 1e12 / I8_PEAK_TOPS, 4),
             },

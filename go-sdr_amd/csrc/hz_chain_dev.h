@@ -661,6 +661,11 @@ __global__ __launch_bounds__(fv::block(N), conv_occupancy(N, STAGED)) void conv_
             // trip's ~50 registers of addresses -- twiddle tables, filter, stores -- were spilled and reloaded)
             int ln = lane;
             asm volatile("" : "+v"(ln));
+            // The previous trip's backward transform ends in reads of the LDS (no barrier behind them) and this
+            // trip's forward transform starts with writes: where several waves share one transform's LDS a fast
+            // wave would overwrite what a slow one still reads.  (One wave per transform -- N <= 1024 -- orders
+            // its own LDS operations.)
+            if constexpr (fv::block(N) > 64) __syncthreads();
 #pragma unroll
             for (int q = 0; q < 16; q++) v[q] = fv::from2(Raw<FMT>::cvt(nx[q]));
             const size_t bn = b + stride;

@@ -143,9 +143,13 @@ func (mr *multiplyReader) Read(s sdr.Samples) (int, error) {
 type tableMultiplyReader struct {
 	t *MultiplyTable
 	r sdr.Reader
+	// SetMultiplier has no error in the reference's MultiplyReader interface (stream/multiply.go:27-35);
+	// a failed rebuild of the GPU table would leave the OLD weights in place without a word, so it is
+	// kept and returned by every Read until a later SetMultiplier succeeds.
+	setErr error
 }
 
-func (tr *tableMultiplyReader) SetMultiplier(m complex64)      { _ = tr.t.SetMultiplier(m) }
+func (tr *tableMultiplyReader) SetMultiplier(m complex64)      { tr.setErr = tr.t.SetMultiplier(m) }
 func (tr *tableMultiplyReader) SampleFormat() sdr.SampleFormat { return tr.r.SampleFormat() }
 func (tr *tableMultiplyReader) SampleRate() uint               { return tr.r.SampleRate() }
 func (tr *tableMultiplyReader) Close() error                   { return tr.t.Close() }
@@ -153,6 +157,9 @@ func (tr *tableMultiplyReader) Close() error                   { return tr.t.Clo
 func (tr *tableMultiplyReader) Read(s sdr.Samples) (int, error) {
 	if s.Format() != tr.r.SampleFormat() {
 		return 0, sdr.ErrSampleFormatMismatch
+	}
+	if tr.setErr != nil {
+		return 0, tr.setErr
 	}
 	i, err := tr.r.Read(s)
 	if err != nil {
@@ -297,6 +304,13 @@ func (s Readers) ConvolutionReader(r sdr.Reader, planner fft.Planner, filter []c
 		return nil, sdr.ErrSampleFormatUnknown
 	}
 	fftLength := len(filter)
+	// hzsdr_convolution_blocks takes power-of-two blocks of 4 ... 8192 bins; the reference fails at
+	// construction too when its planner refuses a length (fft.ConvolveFreq, fft/convolution.go:150-170),
+	// so an unsupported length is an error HERE, not at the first Read. (Other lengths: the reference's
+	// own stream.ConvolutionReader over ctx.Planner.)
+	if fftLength < 4 || fftLength > 8192 || fftLength&(fftLength-1) != 0 {
+		return nil, fmt.Errorf("hip.ConvolutionReader: filter length %d is not a power of two in 4..8192", fftLength)
+	}
 	return stream.ReadTransformer(r, stream.ReadTransformerConfig{
 		InputBufferLength:  fftLength,
 		OutputBufferLength: fftLength,
@@ -357,8 +371,8 @@ func (s Readers) ReadBeamform(rs sdr.Readers, cfg stream.BeamformConfig) (*Beamf
 		return nil, err
 	}
 	b := &Beamform{Reader: addReader, readers: multReaders, config: cfg}
-	if err := b.SetPhaseAngles(cfg.Angles); err != nil {
-		return nil, err
-	}
+	// stream/beamform.go:169 calls SetPhaseAngles and drops its error: a BeamformConfig whose Angles do
+	// not match the readers (the zero value, say) still yields a *Beamform with every weight 1.
+	_ = b.SetPhaseAngles(cfg.Angles)
 	return b, nil
 }

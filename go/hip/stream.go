@@ -6,6 +6,7 @@ package hip
 import "C"
 
 import (
+	"fmt"
 	"unsafe"
 
 	"hz.tools/rf"
@@ -153,6 +154,57 @@ func (x *Context) ConvertReader(in sdr.Reader, to sdr.SampleFormat) (sdr.Reader,
 		Proc:               x.ConvertBuffer,
 	})
 }
+
+// ConvertWriter is stream.ConvertWriter (stream/convert.go:58-118) on the GPU: a Writer of
+// inputFormat in front of `out`; every Write is converted in chunks of 32 Ki samples
+// (stream/convert.go:67) into a buffer of out's format and handed on. Same errors as the
+// reference: sdr.ErrSampleFormatMismatch for a Write of another format, the downstream
+// Writer's error with the count written so far, "Conversion mismatch" if a chunk came back short.
+func (x *Context) ConvertWriter(out sdr.Writer, inputFormat sdr.SampleFormat) (sdr.Writer, error) {
+	bufSize := 32 * 1024
+	buf, err := sdr.MakeSamples(out.SampleFormat(), bufSize)
+	if err != nil {
+		return nil, err
+	}
+	return &convWriter{x: x, out: out, inputFormat: inputFormat, buffer: buf}, nil
+}
+
+type convWriter struct {
+	x           *Context
+	out         sdr.Writer
+	inputFormat sdr.SampleFormat
+	buffer      sdr.Samples
+}
+
+func (cw *convWriter) Write(in sdr.Samples) (int, error) {
+	if in.Format() != cw.inputFormat {
+		return 0, sdr.ErrSampleFormatMismatch
+	}
+	bufSize := cw.buffer.Length()
+	n := 0
+	for i := 0; i < in.Length(); i += bufSize {
+		ie := i + bufSize
+		if ie > in.Length() {
+			ie = in.Length()
+		}
+		leng, err := cw.x.ConvertBuffer(cw.buffer, in.Slice(i, ie))
+		if err != nil {
+			return n, err
+		}
+		if ie-i != leng {
+			return n, fmt.Errorf("ConvertWriter: Conversion mismatch")
+		}
+		j, err := cw.out.Write(cw.buffer.Slice(0, leng))
+		n += j
+		if err != nil {
+			return n, err
+		}
+	}
+	return n, nil
+}
+
+func (cw *convWriter) SampleFormat() sdr.SampleFormat { return cw.inputFormat }
+func (cw *convWriter) SampleRate() uint               { return cw.out.SampleRate() }
 
 // Chain is nested stream.* Readers fused into one launch per buffer.
 type Chain struct {

@@ -351,6 +351,37 @@ static void readers(void) {
     OK(hzsdr_convolution_blocks(ctx, fout, 1024, blk, 1024, filt, 1024, &n));
     CHECK(n == 1024);
     for (int i = 0; i < 2048; i++) CHECK(fabsf(fout[i] - blk[i]) < 1e-4f);
+    /* the lengths hip.ConvolutionReader refuses at construction (go/hip/readers.go) are the ones the C call refuses */
+    CHECK(hzsdr_convolution_blocks(ctx, fout, 1000, blk, 1000, filt, 1000, &n) == HZSDR_ERR_INVALID_ARGUMENT);
+    /* ConvertWriter.Write (stream/convert.go:84-113, go/hip/stream.go): a Write of 2 B + 5 c64 samples into a u8
+     * Writer is three ConvertBuffer calls of at most 32 Ki samples into the writer's buffer, each handed on
+     * whole; a Write of another format is ErrSampleFormatMismatch before anything is converted */
+    {
+        enum { W = 2 * B + 5 };
+        static float wr[2 * W];
+        static uint8_t wbuf[2 * B], sink[2 * W];
+        size_t written = 0;
+        for (int i = 0; i < 2 * W; i++) wr[i] = (float)((i * 29) % 255 - 127) / 127.5f;
+        for (size_t i = 0; i < W; i += B) {
+            const size_t ie = i + B > W ? W : i + B;
+            OK(hzsdr_convert(ctx, HZSDR_FMT_U8, wbuf, B, HZSDR_FMT_C64, wr + 2 * i, ie - i, &n));
+            CHECK(n == ie - i); /* else: "ConvertWriter: Conversion mismatch" */
+            memcpy(sink + 2 * written, wbuf, 2 * n); /* out.Write(buffer.Slice(0, leng)) */
+            written += n;
+        }
+        CHECK(written == W);
+        CHECK(sink[0] == (uint8_t)(int)(wr[0] * 127.5f + 127.5f)); /* iq_c64.go:96-100: truncating */
+        CHECK(sink[2 * W - 1] == (uint8_t)(int)(wr[2 * W - 1] * 127.5f + 127.5f));
+    }
+    /* ReadBeamform with a BeamformConfig whose Angles do not match the readers (stream/beamform.go:169 drops
+     * SetPhaseAngles' error): every reader keeps the multiplier 1 the constructor gave it -- Multiply.Read skips
+     * m == 1 (stream/multiply.go:62-64) -- and the Beamform is the plain ordered sum */
+    OK(hzsdr_convert(ctx, HZSDR_FMT_C64, c64, B, HZSDR_FMT_U8, u8, B, &n));
+    {
+        const void *same[2] = {c64, c64};
+        OK(hzsdr_sum(ctx, HZSDR_FMT_C64, acc, same, 2, B));
+        CHECK(acc[0] == (0.0f + c64[0]) + c64[0]);
+    }
 }
 
 int main(void) {

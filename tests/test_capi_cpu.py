@@ -202,6 +202,12 @@ def test_go_package_has_the_reference_reader_constructors():
     }
     for name, pat in want.items():
         assert re.search(pat, src), name
+    # stream.ConvertWriter (stream/convert.go:58-118) lives beside ConvertReader in stream.go
+    stream_go = open(os.path.join(ROOT, "go", "hip", "stream.go")).read()
+    assert re.search(r"func \(x \*Context\) ConvertWriter\(out sdr\.Writer, inputFormat sdr\.SampleFormat\) \(sdr\.Writer, error\)", stream_go)
+    assert "sdr.ErrSampleFormatMismatch" in stream_go and "32 * 1024" in stream_go and "cw.x.ConvertBuffer(" in stream_go
+    # ReadBeamform drops SetPhaseAngles' error as stream/beamform.go:169 does; a failed table rebuild is not dropped
+    assert "_ = b.SetPhaseAngles(cfg.Angles)" in src and "tr.setErr = tr.t.SetMultiplier(m)" in src
     # the buffer-level calls the Readers stand on exist in the package and reach the C-ABI
     pkg = "".join(open(f).read() for f in sorted(__import__("glob").glob(os.path.join(ROOT, "go", "hip", "*.go"))))
     for method, cfn in (("ShiftBuffer", "hzsdr_nco_shift"), ("Scale", "hzsdr_scale"), ("Multiply", "hzsdr_rotate"),

@@ -73,7 +73,6 @@ def test_rccl_path_single_rank_and_duplicate_gpus(hz, orc):
         _run(hz, orc, torch, 2, 4, 1000, "c64", hz.MGPU_RCCL, 0)
 
 
-@pytest.mark.xfail(strict=False, reason="the multi-device paths have never run anywhere (no box with two GPUs so far): a first run reports, it does not gate")
 def test_distinct_gpus_ordered_and_rccl(hz, orc):
     """The real multi-device paths -- hipMemcpyPeerAsync over xGMI, cross-device event ordering,
     ncclCommInitAll / ncclReduce over distinct GPUs: runs only where the process sees two or more

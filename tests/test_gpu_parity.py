@@ -550,6 +550,30 @@ def test_convolution_blocks_reference_semantics(env, orc, flen):
     assert np.all(got[nblk * flen:] == 0)  # the partial block is never produced
 
 
+@pytest.mark.parametrize("flen", [2048, 4096, 8192])
+def test_convolution_blocks_walk_far_more_blocks_than_the_grid_holds(env, orc, flen):
+    """The direct c64 form walks its blocks in a loop (one workgroup, many blocks, the next one's loads in
+    flight) and from 2048 bins on several waves share one transform's LDS: every trip has to be fenced from the
+    previous trip's last reads.  8192 blocks are 4 ... 16 trips per workgroup on a 256-CU chip; blocks are
+    independent (block-circular), so the oracle is run on a sample of them -- the first, the last, and
+    every 97th -- and each is compared alone.  Tolerance as above: relative L2 <= 2e-6 per block."""
+    if env.kind != "device":
+        pytest.skip("one memory space is enough for a kernel-internal ordering")
+    nblk = 8192
+    rng = np.random.default_rng(flen)
+    x = (rng.standard_normal(nblk * flen, dtype=np.float32) + 1j * rng.standard_normal(nblk * flen, dtype=np.float32)).astype(np.complex64)
+    H = _lowpass_bins(flen)
+    out = env.zeros("c64", len(x))
+    assert env.ctx.convolution_blocks(out, env.put(x), env.put(H)) == nblk * flen
+    got = env.get(out)
+    pick = sorted(set(list(range(0, nblk, 97)) + [1, 2, nblk - 2, nblk - 1]))
+    xs = np.concatenate([x[b * flen:(b + 1) * flen] for b in pick])
+    want = zeros("c64", len(xs))
+    assert orc.convolution_reader(want, xs, H) == len(xs)
+    for i, b in enumerate(pick):
+        assert _rel_l2(got[b * flen:(b + 1) * flen], want[i * flen:(i + 1) * flen]) < 2e-6, (flen, b)
+
+
 @pytest.mark.parametrize("n", [8, 1024, 32768])
 def test_convolve_closures(env, orc, n):
     hz = env.hz
