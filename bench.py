@@ -407,6 +407,15 @@ def main():
         _, ms = timed(torch, lambda: ch.run(c, out), k, w)
         extra["shift_gain_c64_ulp1"] = rate(n, float(np.median(ms)), 16)
         ch.close()
+        # the Reader form of Shift (hzsdr_nco_shift: what ShiftReader / ShiftBuffer bind to), bit-exact and with
+        # hzsdr_nco_set_ulp1
+        nco = ctx.nco(fs)
+        _, ms = timed(torch, lambda: nco(2.5e6, c), k, w)
+        extra["shift_c64"] = rate(n, float(np.median(ms)), 16)
+        nco.set_ulp1()
+        _, ms = timed(torch, lambda: nco(2.5e6, c), k, w)
+        extra["shift_c64_ulp1"] = rate(n, float(np.median(ms)), 16)
+        nco.close()
         # cfg 3: reference ConvolutionReader semantics, 1024 bins (16 B/sample)
         H = torch.from_numpy(np.fft.fft(np.asarray(taps, np.complex128) / ntaps).astype(np.complex64)).cuda()
         _, ms = timed(torch, lambda: ctx.convolution_blocks(out, c, H), k, w)

@@ -456,6 +456,11 @@ class Nco:
     def ts(self, v):
         lib.hzsdr_nco_set_time(self._h, float(v))
 
+    def set_ulp1(self, on=True):
+        """Opt in to the <= 1-ulp rotation factor (include/hzsdr.h: hzsdr_nco_set_ulp1); the default is bit-exact."""
+        self.ctx._ck(lib.hzsdr_nco_set_ulp1(self._h, int(on)))
+        return self
+
     def close(self):
         if self._h:
             lib.hzsdr_nco_free(self._h)

@@ -107,6 +107,7 @@ SIGNATURES = {
     "hzsdr_nco_shift": (i32, [vp, f64, vp, sz]),
     "hzsdr_nco_get_time": (i32, [vp, C.POINTER(f64)]),
     "hzsdr_nco_set_time": (i32, [vp, f64]),
+    "hzsdr_nco_set_ulp1": (i32, [vp, i32]),
     "hzsdr_nco_free": (i32, [vp]),
     "hzsdr_nco_segments": (i32, [u64, f64, u64, C.POINTER(NcoSegment), sz, psz, C.POINTER(f64)]),
     "hzsdr_decimate": (i32, [vp, i32, vp, sz, i32, vp, sz, u32, i64, psz]),

@@ -139,7 +139,8 @@ __device__ __forceinline__ double nco_ts(const NcoSegs &sg, NcoWin w, uint64_t j
 // long for the inline form is uploaded to a context scratch slot.
 int nco_plan(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, size_t n, NcoSegs *sg);
 // In-place shift of n samples at device pointer buf, advancing *ts.
+// (ulp1: the float32 factor within one ulp of the reference's instead of bit-identical, hzsdr_nco_set_ulp1)
 int nco_shift_device(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, double shift_hz, void *buf,
-                     size_t n);
+                     size_t n, bool ulp1 = false);
 
 }  // namespace hz

@@ -12,11 +12,21 @@
 namespace hz {
 
 // buf[first + i] *= complex64(cos(ph), sin(ph)),  ph = (tau*shift) * ts_i
+// ULP1 (hzsdr_nco_set_ulp1): the factor from the phase in turns and float32 polynomials (sincos_turns32,
+// hz_device.h) -- within one float32 ulp of the reference's factor, a third of the vector instructions; the
+// default is math.Sincos operation for operation (bit-identical to the oracle).
+template <bool ULP1>
 __device__ __forceinline__ float2 nco_rotate(float2 v, double ts, double tau_shift) {
     double ph = __dmul_rn(tau_shift, ts);  // stream/shifter.go:81, (tau*shift)*ts left to right
-    double s, c;
-    go_sincos(ph, s, c);
-    return go_cmul(v, make_float2((float)c, (float)s));  // :82 complex64(complex(rl, im))
+    if constexpr (ULP1) {
+        float sf, cf;
+        sincos_turns32(turns32_wide(ph), sf, cf);  // (any phase: ts < 2 pi, but tau * shift is the caller's)
+        return go_cmul(v, make_float2(cf, sf));
+    } else {
+        double s, c;
+        go_sincos(ph, s, c);
+        return go_cmul(v, make_float2((float)c, (float)s));  // :82 complex64(complex(rl, im))
+    }
 }
 
 // Each workgroup owns a contiguous tile of kNcoTile vectors per trip; a lane
@@ -25,6 +35,7 @@ __device__ __forceinline__ float2 nco_rotate(float2 v, double ts, double tau_shi
 // sat at 4.4 TB/s, latency-bound, not f64-bound).
 constexpr int kNcoUnroll = 4;
 
+template <bool ULP1>
 __global__ __launch_bounds__(kThreads) void nco_shift_vec_kernel(float4 *buf, uint64_t base,
                                                                  size_t nvec, double tau_shift,
                                                                  NcoSegs sg) {
@@ -43,20 +54,21 @@ __global__ __launch_bounds__(kThreads) void nco_shift_vec_kernel(float4 *buf, ui
             const size_t i = t0 + (size_t)u * kThreads + threadIdx.x;
             if (i < nvec) {
                 const uint64_t j = base + 2 * i;
-                float2 l = nco_rotate(make_float2(a[u].x, a[u].y), nco_ts(sg, w, j), tau_shift);
-                float2 h = nco_rotate(make_float2(a[u].z, a[u].w), nco_ts(sg, w, j + 1), tau_shift);
+                float2 l = nco_rotate<ULP1>(make_float2(a[u].x, a[u].y), nco_ts(sg, w, j), tau_shift);
+                float2 h = nco_rotate<ULP1>(make_float2(a[u].z, a[u].w), nco_ts(sg, w, j + 1), tau_shift);
                 buf[i] = make_float4(l.x, l.y, h.x, h.y);
             }
         }
     }
 }
 
+template <bool ULP1>
 __global__ void nco_shift_scalar_kernel(float2 *buf, uint64_t base, size_t n, double tau_shift,
                                         NcoSegs sg) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const NcoWin w = nco_window_all(sg);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        buf[i] = nco_rotate(buf[i], nco_ts(sg, w, base + i), tau_shift);
+        buf[i] = nco_rotate<ULP1>(buf[i], nco_ts(sg, w, base + i), tau_shift);
 }
 
 // Plans the next n clock values from *ts into one table.
@@ -94,8 +106,8 @@ int nco_plan(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, size_t n, NcoSegs
 }
 
 // In-place shift of n samples at device pointer buf, advancing *ts.
-int nco_shift_device(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, double shift_hz, void *buf,
-                     size_t n) {
+template <bool ULP1>
+static int nco_shift_launch(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, double shift_hz, void *buf, size_t n) {
     if (n == 0) return HZSDR_OK;
     NcoSegs sg;
     HZ_TRY(nco_plan(ctx, sample_rate, ts, n, &sg));
@@ -104,14 +116,19 @@ int nco_shift_device(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, double sh
     size_t head = ((uintptr_t)q % 16) ? 1 : 0;
     size_t nvec = (n - head) / 2, tail = n - head - 2 * nvec;
     if (head)
-        hipLaunchKernelGGL(nco_shift_scalar_kernel, dim3(1), dim3(64), 0, ctx->stream, q, (uint64_t)0, head, tau_shift, sg);
+        hipLaunchKernelGGL(nco_shift_scalar_kernel<ULP1>, dim3(1), dim3(64), 0, ctx->stream, q, (uint64_t)0, head, tau_shift, sg);
     if (nvec)
-        hipLaunchKernelGGL(nco_shift_vec_kernel, dim3(blocks_for(ctx, (nvec + kNcoUnroll - 1) / kNcoUnroll)), dim3(kThreads), 0,
+        hipLaunchKernelGGL(nco_shift_vec_kernel<ULP1>, dim3(blocks_for(ctx, (nvec + kNcoUnroll - 1) / kNcoUnroll)), dim3(kThreads), 0,
                            ctx->stream, (float4 *)(q + head), (uint64_t)head, nvec, tau_shift, sg);
     if (tail)
-        hipLaunchKernelGGL(nco_shift_scalar_kernel, dim3(1), dim3(64), 0, ctx->stream,
+        hipLaunchKernelGGL(nco_shift_scalar_kernel<ULP1>, dim3(1), dim3(64), 0, ctx->stream,
                            q + head + 2 * nvec, (uint64_t)(head + 2 * nvec), tail, tau_shift, sg);
     return HZSDR_OK;
+}
+
+int nco_shift_device(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, double shift_hz, void *buf, size_t n, bool ulp1) {
+    return ulp1 ? nco_shift_launch<true>(ctx, sample_rate, ts, shift_hz, buf, n)
+                : nco_shift_launch<false>(ctx, sample_rate, ts, shift_hz, buf, n);
 }
 
 }  // namespace hz
@@ -120,6 +137,7 @@ struct hzsdr_nco {
     hzsdr_ctx *ctx;
     uint64_t sample_rate;
     double ts;
+    bool ulp1;
 };
 
 extern "C" {
@@ -128,7 +146,7 @@ int hzsdr_nco_create(hzsdr_ctx *ctx, uint64_t sample_rate, hzsdr_nco **out) {
     if (!ctx || !out) return HZSDR_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     if (sample_rate == 0) return hz::fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "nco: sample rate 0");
-    *out = new hzsdr_nco{ctx, sample_rate, 0.0};
+    *out = new hzsdr_nco{ctx, sample_rate, 0.0, false};
     return HZSDR_OK;
 }
 
@@ -142,7 +160,7 @@ int hzsdr_nco_shift(hzsdr_nco *nco, double shift_hz, void *buf, size_t n) {
     void *d;
     HZ_TRY(st.inout(0, buf, n * 8, &d));
     double ts = nco->ts;
-    HZ_TRY(nco_shift_device(ctx, nco->sample_rate, &ts, shift_hz, d, n));
+    HZ_TRY(nco_shift_device(ctx, nco->sample_rate, &ts, shift_hz, d, n, nco->ulp1));
     HZ_TRY(st.finish());
     nco->ts = ts;
     return HZSDR_OK;
@@ -157,6 +175,12 @@ int hzsdr_nco_get_time(const hzsdr_nco *nco, double *ts) {
 int hzsdr_nco_set_time(hzsdr_nco *nco, double ts) {
     if (!nco) return HZSDR_ERR_INVALID_ARGUMENT;
     nco->ts = ts;
+    return HZSDR_OK;
+}
+
+int hzsdr_nco_set_ulp1(hzsdr_nco *nco, int on) {
+    if (!nco) return HZSDR_ERR_INVALID_ARGUMENT;
+    nco->ulp1 = on != 0;
     return HZSDR_OK;
 }
 

@@ -96,6 +96,10 @@ func (s *Shifter) Time() float64 {
 }
 
 func (s *Shifter) SetTime(ts float64) error { return toErr(s.x.c, C.hzsdr_nco_set_time(s.n, C.double(ts))) }
+
+// SetULP1 opts this Shifter (and the ShiftReader built on it) in to the rotation factor within one float32
+// ulp of the reference's instead of bit-identical to it: HBM-bound instead of Sincos-bound. Off by default.
+func (s *Shifter) SetULP1(on bool) error { return toErr(s.x.c, C.hzsdr_nco_set_ulp1(s.n, cbool(on))) }
 func (s *Shifter) Close() error            { return toErr(s.x.c, C.hzsdr_nco_free(s.n)) }
 
 // ClockSegment is one exactly-linear run of the reference's serial clock recurrence

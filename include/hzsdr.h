@@ -171,6 +171,13 @@ int hzsdr_nco_create(hzsdr_ctx *ctx, uint64_t sample_rate, hzsdr_nco **out);
 int hzsdr_nco_shift(hzsdr_nco *nco, double shift_hz, void *buf_c64, size_t n);
 int hzsdr_nco_get_time(const hzsdr_nco *nco, double *ts);
 int hzsdr_nco_set_time(hzsdr_nco *nco, double ts);
+/* Opt-in, off by default: the rotation factor of stream/shifter.go:81-82 within ONE float32 ulp
+ * of the reference's complex64(complex(cos, sin)) instead of bit-identical to it -- the phase as a
+ * 32-bit fraction of a turn and float32 polynomials instead of math.Sincos in float64 (a third of
+ * the vector instructions: the kernel becomes HBM-bound, 0.59 -> 0.76 of the roofline).  The clock
+ * (ts, its wraps at 2 pi, its state across calls) is the reference's either way.  north_star:
+ * "within 1 ULP for c64 float ops".  The chain form is hzsdr_chain_shift_ulp1. */
+int hzsdr_nco_set_ulp1(hzsdr_nco *nco, int on);
 int hzsdr_nco_free(hzsdr_nco *nco);
 
 /* One run of the NCO time sequence that is exactly linear:

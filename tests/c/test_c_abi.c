@@ -101,6 +101,7 @@ static void vector_ops(void) { /* go/hip/stream.go */
     OK(hzsdr_nco_get_time(n1, &ts));
     CHECK(ts > 0 && ts < 1e-3);
     OK(hzsdr_nco_set_time(n1, 0.0));
+    OK(hzsdr_nco_set_ulp1(n1, 0)); /* (the default: bit-exact) */
     OK(hzsdr_nco_free(n1));
     OK(hzsdr_nco_free(n2));
     hzsdr_nco_segment segs[64];

@@ -384,6 +384,43 @@ def test_shift_bit_exact_at_volume(hz, orc):
     ctx.close()
 
 
+@pytest.mark.parametrize("rate,shift,t0", [(20_000_000, 2.5e6, 3.25), (20_000_000, -7.3e6, 2 * math.pi - 0.5),
+                                            (200_000_000, 95e6, 5.0)])
+def test_nco_shift_ulp1_is_within_one_ulp_of_the_factor_at_volume(hz, orc, rate, shift, t0):
+    """hzsdr_nco_set_ulp1 (opt-in; what ShiftReader / ShiftBuffer bind to): unit inputs over 2^25 samples, so the
+    output IS the rotation factor.  The reference's factor is the true value rounded once (half an ulp), the
+    opt-in's is within one ulp of the true value: components of size <= 1 are at most 1.5 x 2^-24 apart.  The
+    clock crosses 2*pi in the second case (1.6 s of samples from 2*pi - 0.5); in the third the phase is ~3e9
+    rad, math.Sincos' Payne-Hanek range, where the opt-in reduces with a double-double 1 / 2 pi.  The clock itself
+    (ts after the call) is the reference's bit for bit, and switching the option off again restores bit equality."""
+    import torch
+    n = 1 << 25
+    x = np.ones(n, np.complex64)
+    want = x.copy()
+    ref = orc.Shifter(rate)
+    ref.ts.value = t0
+    ref(shift, want)
+    ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+    nco = ctx.nco(rate).set_ulp1()
+    nco.ts = t0
+    d = torch.from_numpy(x).cuda()
+    nco(shift, d)
+    ctx.synchronize()
+    got = d.cpu().numpy()
+    assert nco.ts == ref.ts.value
+    dd = got.view(np.float32).astype(np.float64) - want.view(np.float32).astype(np.float64)
+    assert np.abs(dd).max() <= 1.5 * 2.0 ** -24, np.abs(dd).max() * 2.0 ** 24
+    assert not bits_equal(got, want)  # (it really is the other kernel)
+    nco.set_ulp1(False)
+    nco.ts = t0
+    d = torch.from_numpy(x).cuda()
+    nco(shift, d)
+    ctx.synchronize()
+    assert bits_equal(d.cpu().numpy(), want)
+    nco.close()
+    ctx.close()
+
+
 def test_shift_large_phase_uses_payne_hanek(env, orc):
     """2*pi*shift*ts beyond 2^29 rad takes trigReduce (src/math/trig_reduce.go)."""
     n, rate, shift = 100_000, 200_000_000, 95e6
