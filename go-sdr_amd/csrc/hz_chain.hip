@@ -480,6 +480,11 @@ static int mm_table_for(hzsdr_chain *c, double step, double omega, void **dev, b
         dc[1] = 0.5 * (double)(sr + si);
     }
     memcpy(tab.data() + (size_t)4 * g.ne * 32, dc, 16);
+    if (v2) {  // the mixer's step factors of this run (one Shift stage: omega is its tau; otherwise unused)
+        float wf[8][4];
+        mm2::step_factors(omega, step, (int)c->factor, wf);
+        memcpy(tab.data() + (size_t)4 * g.ne * 32 + 16, wf, sizeof wf);
+    }
     void *d = nullptr;
     HZ_HIP(ctx, hipMalloc(&d, tab.size()));
     hipError_t e = hipMemcpyAsync(d, tab.data(), tab.size(), hipMemcpyHostToDevice, ctx->stream);

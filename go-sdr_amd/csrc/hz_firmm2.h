@@ -35,7 +35,6 @@
 
 #include "hz_firmm.h"
 #include "hz_firmm2_plan.h"
-HZ_NO_PACKED_F32_BEGIN  // (hz_firmm.h says why)
 
 namespace hz {
 namespace mm2 {
@@ -52,7 +51,8 @@ using mm::task_window;
 // stored (first launch) or compared with the stored ones (tools/mm2_glitch.hip: which register, which lanes,
 // which compute unit, stale read or wrong sum), 512 = the mixer's step factors read from LDS in one batch, waited for
 // (lgkmcnt(0) and eight wait states) and pinned before their first use, 1024 = the first step factor formed a second
-// time from a second, fully waited read and compared with the one the mixer used (records as for 256).
+// time from a second, fully waited read and compared with the one the mixer used (records as for 256), 2048 = the
+// constant 0 as the first step's C operand instead of cleared accumulator registers.
 // NG: the window's groups (ks / GS) when the instantiation is for ONE tap count -- the matrix loop is then
 // straight-line code (a loop header drains the operand pipeline: the compiler cannot count outstanding
 // loads across a back edge); 0: any window, a loop over the groups.
@@ -76,7 +76,6 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     const size_t tab_lds = table_lds(G.ne), slot_sz = slot_bytes(D, G.ks);
     uint8_t *const tabp = mm_lds;
     unsigned *const ctr = reinterpret_cast<unsigned *>(mm_lds + 2 * tab_lds);
-    float4 *const wfac = reinterpret_cast<float4 *>(mm_lds + 2 * tab_lds + 16);  // [2 runs][8 outputs of a lane]
     uint8_t *const slot = mm_lds + 2 * tab_lds + kCtlBytes + (size_t)wave * slot_sz;
     const int64_t n_bytes = 2 * (int64_t)n_in;
     const uint8_t *src = (const uint8_t *)in;
@@ -514,17 +513,6 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                     if (tid + u * kThreads < tp) *reinterpret_cast<v4i *>(tabp + off_b + 16 * (size_t)(tid + u * kThreads)) = tq[u];
             }
         }
-        if (tid < 16 && L.shift_op >= 0) {
-            // the step factors of the group's runs (lane i of 0 .. 7: run A, 8 .. 15: run B), float64 once, kept as
-            // float pairs: (256 b + a) D dphi turns
-            const uint64_t dph = (tid & 8) ? rv.dphi : ru.dphi;
-            const uint64_t k = (uint64_t)(D * (32 * kT * ((tid & 7) >> 2) + (tid & 3)));
-            const double turns = (double)(k * dph) * 5.42101086242752217e-20;  // 2^-64
-            double sn, cs;
-            sincos_late(__dmul_rn(turns, 6.28318530717958647692), sn, cs);
-            const float ch = (float)cs, sh = (float)sn;
-            wfac[tid] = make_float4(ch, sh, (float)(cs - (double)ch), (float)(sn - (double)sh));
-        }
         first_seg = false;
         if (first_stamp) stamp(10);
         if (tid == 0) *ctr = kEarly;
@@ -581,8 +569,11 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
 #pragma unroll
                     for (int q = 0; q < 16; q++) acc[f][b][q] = 0;
             // (the accumulators as opaque registers: the straight-line form then starts them like every other
-            // step -- v_mfma acc, a, b, acc -- instead of with the constant 0 as the C operand)
-            if constexpr (STRAIGHT) {
+            // step -- v_mfma acc, a, b, acc -- instead of with the constant 0 as the C operand.  EXP & 2048 lets the
+            // compiler use the constant: 64 clears per pass less, exact sums all the same (tools/mm2_glitch.hip; what
+            // round 3 saw "lose terms" with the constant was the mixer's packed instruction, hz_firmm.h) -- and 1.8 us
+            // per call SLOWER, measured A/B on one box: the first step's destinations then overlap its sources)
+            if constexpr (STRAIGHT && (EXP & 2048) == 0) {
 #pragma unroll
                 for (int f = 0; f < 2; f++)
 #pragma unroll
@@ -734,7 +725,8 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                 stamp(4);
                 const uint32_t mb = m_start + (uint32_t)n * kT + 4 * h;
                 {
-                    program(y, mb, phi_r, dphi, sel ? rv.seg : ru.seg, wfac + (sel ? 8 : 0));
+                    // (the run's step factors: behind the constant term at the table's end, hz_firmm2_plan.h)
+                    program(y, mb, phi_r, dphi, sel ? rv.seg : ru.seg, reinterpret_cast<const float4 *>(dc + 2));
                     stamp(5);
 #pragma unroll
                     for (int b = 0; b < NB; b++) store_block(y[b], mb + (uint32_t)(32 * kT) * b, v_lo, v_hi);
@@ -772,4 +764,3 @@ int launch_fir(hipStream_t stream, int num_cus, int fmt, unsigned D, const void 
 
 }  // namespace mm2
 }  // namespace hz
-HZ_NO_PACKED_F32_END

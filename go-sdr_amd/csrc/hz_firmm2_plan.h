@@ -38,10 +38,11 @@ constexpr int tile_stride(int D) { return tile_bytes(D) + 16; }
 constexpr size_t slot_bytes(int D, int ks) {
     return ((image_bytes(D, ks) / tile_bytes(D) + 1) * tile_stride(D) + 255) / 256 * 256;
 }
-// table: T[f][E][part][pl] of 16 bytes (digit plane 2 f + pl, most significant first), then (dc_re, dc_im)
-constexpr size_t table_bytes(int ne) { return (size_t)ne * 128 + 16; }
+// table: T[f][E][part][pl] of 16 bytes (digit plane 2 f + pl, most significant first), then (dc_re, dc_im), then the
+// mixer's eight step factors of the run (step_factors below)
+constexpr size_t table_bytes(int ne) { return (size_t)ne * 128 + 16 + 128; }
 constexpr size_t table_lds(int ne) { return (table_bytes(ne) + 255) / 256 * 256; }
-constexpr size_t kCtlBytes = 512;  // the queue's counter; the mixer's step factors of the group's two runs
+constexpr size_t kCtlBytes = 512;  // the queue's counter
 // two tables, the queue's counter, a slot per wave, the fix-up task's window (ntaps + D (kFixOut - 1) samples) and taps
 constexpr size_t lds_bytes(int D, int ks, int ne, int ntaps) {
     return 2 * table_lds(ne) + kCtlBytes + kWaves * slot_bytes(D, ks) + ((size_t)(2 * ntaps + D * (kFixOut - 1)) * 8 + 255) / 256 * 256;
@@ -105,6 +106,24 @@ inline void phase_fix(double tau, double t0, double step, uint64_t first, uint64
     };
     *dphi = fix((long double)tau * (long double)step * inv2pi);
     *phi = fix((long double)tau * (long double)t0 * inv2pi) - first * *dphi;  // (mod 2^64: by the run's line at sample 0)
+}
+
+// The mixer's step factors of a clock run (chains with exactly one Shift stage): a lane forms ONE Sincos per pass, for
+// its first output, and turns it on to its other seven outputs -- (32 kT b + a) D samples further, b = 0, 1 the
+// column block, a = 0 .. 3 -- by exp(2 pi i k dphi), kept as float pairs (cos hi, sin hi, cos lo, sin lo).  They depend
+// on the run's phase increment alone, so they are a property of the run's table and travel at its end (the kernel
+// computed them in its first lines until round 4: two hundred float64 instructions in front of the first barrier).
+inline void step_factors(double tau, double step, int D, float out[8][4]) {
+    uint64_t phi, dphi;
+    phase_fix(tau, 0.0, step, 0, &phi, &dphi);
+    for (int i = 0; i < 8; i++) {
+        const uint64_t k = (uint64_t)(D * (32 * kT * (i >> 2) + (i & 3)));
+        const long double turns = (long double)(k * dphi) * 5.42101086242752217003726400434970855712890625e-20L;  // 2^-64 (k dphi mod 2^64)
+        const long double ang = turns * 6.283185307179586476925286766559005768L;
+        const long double cs = cosl(ang), sn = sinl(ang);
+        const float ch = (float)cs, sh = (float)sn;
+        out[i][0] = ch, out[i][1] = sh, out[i][2] = (float)(cs - (long double)ch), out[i][3] = (float)(sn - (long double)sh);
+    }
 }
 
 // geometry of a chain with `ntaps` taps at decimation D (host)

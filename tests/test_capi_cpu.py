@@ -232,55 +232,33 @@ def test_plain_c_walkthrough_compiles_as_c99_and_covers_the_header():
     assert set(_header_symbols()) - used == set(), sorted(set(_header_symbols()) - used)
 
 
-def _device_code_objects(path):
-    """The gfx950 code objects bundled into a HIP shared library (clang offload bundles, uncompressed)."""
-    import struct
-    data = open(path, "rb").read()
-    magic, i, out = b"__CLANG_OFFLOAD_BUNDLE__", 0, []
-    while True:
-        i = data.find(magic, i)
-        if i < 0:
-            return out
-        (count,) = struct.unpack_from("<Q", data, i + 24)
-        off = i + 32
-        for _ in range(count):
-            o, size, tl = struct.unpack_from("<QQQ", data, off)
-            off += 24
-            triple = data[off:off + tl].decode()
-            off += tl
-            if "amdgcn" in triple and size:
-                out.append(data[i + o:i + o + size])
-        i += len(magic)
-
-
-def test_no_packed_float32_instruction_in_a_kernel_that_issues_mfmas(tmp_path):
+def test_no_packed_float32_instruction_with_the_hazardous_operand_selection():
     """gfx950, measured (tools/pk_glitch.hip, profiles/r04_pk_glitch.txt): a v_pk_{mul,add,fma}_f32 whose op_sel
-    takes the high register of src1 for the low result reads that operand as zero in lanes 48-63 when the SIMD's
-    other wave issues an MFMA at the wrong cycle -- the cause of the matrix FIR's non-repeatable pass.  The
-    kernels that hold MFMAs (csrc/hz_firmm.h, hz_firmm2.h) are therefore compiled without packed float32
-    instructions; this test disassembles every kernel of the built library and holds them to it."""
+    takes the high register of src1 for the low result while src0 is taken straight (op_sel:[0,1]) reads that
+    operand as zero in lanes 48-63 when the SIMD's other wave issues an MFMA at the wrong cycle -- the cause of the
+    matrix FIR's non-repeatable pass.  The build rewrites every such instruction of the linked library with its
+    first two sources exchanged (tools/fix_pk_opsel.py, run by csrc/Makefile); this test disassembles the built
+    library and holds it to that, and checks that the kernels the hazard matters most to are in there at all."""
     import subprocess
-    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-    if not os.path.exists(objdump):
+    import sys
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fix_pk_opsel as fix
+    if not os.path.exists(fix.OBJDUMP):
         pytest.skip("no llvm-objdump")
     lib = os.path.join(ROOT, "go-sdr_amd", "libhzsdr_hip.so")
-    objs = _device_code_objects(lib)
-    assert objs, "no gfx950 code object found in the library"
-    with_mfma, offenders = 0, {}
-    for k, blob in enumerate(objs):
-        f = tmp_path / f"co{k}.elf"
-        f.write_bytes(blob)
-        text = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(f)], capture_output=True, text=True, check=True).stdout
-        cur, mfma, packed = None, {}, {}
-        for line in text.splitlines():
-            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
-            if m:
-                cur = m.group(1)
-                mfma[cur] = packed[cur] = 0
-            elif cur is not None:
-                mfma[cur] += "v_mfma" in line
-                packed[cur] += bool(re.search(r"v_pk_(mul|add|fma)_f32", line))
-        with_mfma += sum(1 for name in mfma if mfma[name])
-        offenders.update({name: packed[name] for name in mfma if mfma[name] and packed[name]})
-    assert with_mfma >= 10, with_mfma  # (the matrix FIR's instantiations are there at all)
-    assert not offenders, offenders
+    found, _ = fix.process(lib, check=True)
+    assert found == 0, "%d packed float32 instructions with op_sel:[0,1] in the library: run tools/fix_pk_opsel.py" % found
+    # the rewrite itself, on the instruction forms the compiler emits (encodings from llvm-mc)
+    assert fix.swap01(0xD3B1501A, 0x48021D1E) == (0xD3B1481A, 0x30023D0E)  # v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]
+    assert fix.swap01(0xD3B0521A, 0x0CA21D1E) == (0xD3B0491A, 0x14A23D0E)  # v_pk_fma_f32 ... op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]
+    assert fix.swap01(0xD3B25002, 0x18000D04) == (0xD3B24802, 0x18020806)  # v_pk_add_f32 v[2:3], v[4:5], s[6:7] op_sel:[0,1]
+    data = open(lib, "rb").read()
+    n_mfma = 0
+    for base, size in fix.code_objects(data):
+        with tempfile.NamedTemporaryFile(suffix=".elf") as f:
+            f.write(data[base:base + size])
+            f.flush()
+            text = subprocess.run([fix.OBJDUMP, "-d", "--mcpu=gfx950", f.name], capture_output=True, text=True, check=True).stdout
+        n_mfma += text.count("v_mfma_i32_32x32x32_i8")
+    assert n_mfma > 1000, n_mfma

@@ -71,7 +71,8 @@ template <int EXP, int MIXT = 1, int NGT = 17> static void run(void *const *in, 
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     float best = 1e9f, sum = 0;
-    const int reps = 24;
+    std::vector<float> all;
+    const int reps = getenv("AB") ? 96 : 24;
     for (int r = 0; r < reps + 4; r++) {
         CK(hipEventRecord(e0, 0));
         hipLaunchKernelGGL(k, dim3(grid), dim3(mm2::kThreads), lds, 0, (const void *)in[getenv("ONEBUF") ? 0 : r % 12], out, (const float2 *)nullptr,
@@ -80,11 +81,12 @@ template <int EXP, int MIXT = 1, int NGT = 17> static void run(void *const *in, 
         CK(hipEventSynchronize(e1));
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
-        if (r >= 4) { best = ms < best ? ms : best; sum += ms; }
+        if (r >= 4) { best = ms < best ? ms : best; sum += ms; all.push_back(ms); }
     }
     CK(hipGetLastError());
-    printf("MIX %d EXP %3d%s: grid %u, LDS %zu, ks %d, passes %d: min %.1f us  avg %.1f us\n", MIXT, EXP, shift ? " +Shift" : "       ", grid, lds,
-           g.ks, R.n_pass, best * 1e3f, sum / reps * 1e3f);
+    std::sort(all.begin(), all.end());
+    printf("MIX %d EXP %4d%s: grid %u, LDS %zu, ks %d, passes %d: min %.1f us  median %.1f us  avg %.1f us\n", MIXT, EXP, shift ? " +Shift" : "       ", grid, lds,
+           g.ks, R.n_pass, best * 1e3f, all[all.size() / 2] * 1e3f, sum / reps * 1e3f);
     if (EXP & 64) {
         const size_t nw = (size_t)grid * mm2::kWaves;
         std::vector<unsigned long long> st(nw * 32);
@@ -175,6 +177,14 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&g_stamps, 8 * 32 * 8 * 1024));
     CK(hipMemset(g_stamps, 0, 8 * 32 * 8 * 1024));
     printf("fir_mm2_kernel<u8, 8>, 2^24 samples, %d taps; EXP 1 = no input loads, 2 = no matrix loop, 4 = no mixer, 8 = no stores, 32 = wave priorities, 128 = no explicit vmcnt(0)\n", ntaps);
+    if (getenv("AB")) {  // A/B of the build's switches on one box, interleaved: EXP 0, 2048 (accumulator clears), 4 (no mixer)
+        for (int r = 0; r < 3; r++) {
+            run<0, 0>(in, out, taps, tab, n, ntaps, true);
+            run<2048, 0>(in, out, taps, tab, n, ntaps, true);
+            run<4, 0>(in, out, taps, tab, n, ntaps, true);
+        }
+        return 0;
+    }
     run<0, 0>(in, out, taps, tab, n, ntaps, true);
     run<128, 0>(in, out, taps, tab, n, ntaps, true);
     run<0, 0>(in, out, taps, tab, n, ntaps, true);
