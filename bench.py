@@ -108,6 +108,10 @@ def main():
     # 40.0 .. 40.3 with these)
     ap.add_argument("--steps", type=int, default=450)
     ap.add_argument("--warmup", type=int, default=150)
+    ap.add_argument("--ramp-ms", type=float, default=40.0,
+                    help="untimed: the same step repeated for this long BEFORE the W warm-up steps, so that the chip's clocks "
+                         "have settled whatever W is (with W = 5 the timed loop still ran through the ramp: 41.2 ... 45.1 us per "
+                         "step from run to run on one box, 40.0 ... 40.3 behind 150 steps); reported as clock_ramp_ms")
     ap.add_argument("--log2n", type=int, default=24, help="samples per buffer = 2^log2n")
     ap.add_argument("--no-extra", action="store_true", help="skip the per-config side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle TIMING (the parity check still runs)")
@@ -171,6 +175,14 @@ def main():
         it[0] = i + 1
         chain.run(xs[i % nbuf], ys[i % len(ys)])
 
+    ramp_steps = 0
+    if args.ramp_ms > 0:  # untimed clock ramp (see --ramp-ms), in bursts so the host does not run far ahead
+        t_r = time.perf_counter()
+        while time.perf_counter() - t_r < args.ramp_ms * 1e-3:
+            for _ in range(50):
+                step()
+            torch.cuda.synchronize()
+            ramp_steps += 50
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -271,6 +283,8 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "clock_ramp_ms": args.ramp_ms,
+        "clock_ramp_steps": ramp_steps,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
         "scaling": "weak",

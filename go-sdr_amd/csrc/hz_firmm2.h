@@ -362,8 +362,9 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                             float4 w;
                             if constexpr ((EXP & 512) != 0) w = wpin[4 * b + q];
                             else w = wtab[4 * b + q];  // (cos hi, sin hi, cos lo, sin lo)
-                            cs = __fmaf_rn(c0, w.x, -(s0 * w.y)) + __fmaf_rn(c0, w.z, -(s0 * w.w));
-                            sn = __fmaf_rn(c0, w.y, s0 * w.x) + __fmaf_rn(c0, w.w, s0 * w.z);
+                            // (the small terms first, the large ones chained on: four instructions per component)
+                            cs = __fmaf_rn(c0, w.x, __fmaf_rn(-s0, w.y, __fmaf_rn(c0, w.z, -(s0 * w.w))));
+                            sn = __fmaf_rn(c0, w.y, __fmaf_rn(s0, w.x, __fmaf_rn(c0, w.w, s0 * w.z)));
                             if constexpr ((EXP & 1024) != 0) {
                                 if (b == 0 && q == 1) chk_w = w, chk_cs = cs, chk_sn = sn;
                             }
@@ -375,10 +376,11 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                     asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 7" : "+v"(w2.x), "+v"(w2.y), "+v"(w2.z), "+v"(w2.w));
                     float c0b = c0, s0b = s0;
                     asm volatile("" : "+v"(c0b), "+v"(s0b));
-                    float cs2 = __fmaf_rn(c0b, w2.x, -(s0b * w2.y)), csl = __fmaf_rn(c0b, w2.z, -(s0b * w2.w));
-                    float sn2 = __fmaf_rn(c0b, w2.y, s0b * w2.x), snl = __fmaf_rn(c0b, w2.w, s0b * w2.z);
-                    asm volatile("" : "+v"(cs2), "+v"(csl), "+v"(sn2), "+v"(snl));  // (no packed forms across these)
-                    cs2 += csl, sn2 += snl;
+                    float csl = __fmaf_rn(c0b, w2.z, -(s0b * w2.w)), snl = __fmaf_rn(c0b, w2.w, s0b * w2.z);
+                    asm volatile("" : "+v"(csl), "+v"(snl));  // (no packed forms across these)
+                    float cs2 = __fmaf_rn(-s0b, w2.y, csl), sn2 = __fmaf_rn(s0b, w2.x, snl);
+                    asm volatile("" : "+v"(cs2), "+v"(sn2));
+                    cs2 = __fmaf_rn(c0b, w2.x, cs2), sn2 = __fmaf_rn(c0b, w2.y, sn2);
                     if (__float_as_uint(cs2) != __float_as_uint(chk_cs) || __float_as_uint(sn2) != __float_as_uint(chk_sn)) {
                         const unsigned long long slot_r = atomicAdd(&stamps[2], 1ull);
                         if (slot_r < 4000) {

@@ -140,6 +140,49 @@ template <int EXP, int MIXT = 1, int NGT = 17> static void run(void *const *in, 
                 }
                 printf(" end %.2f\n", (double)(s[7] - t0) / 100);
             }
+        {   // the workgroups that end last: where their time went
+            std::vector<std::pair<double, int>> ends;
+            for (unsigned wg = 0; wg < grid; wg++) {
+                double e = 0;
+                for (int w = 0; w < 8; w++) e = std::max(e, (double)(st[((size_t)wg * 8 + w) * 32 + 7] - t0));
+                ends.push_back({e, (int)wg});
+            }
+            std::sort(ends.begin(), ends.end());
+            printf("    workgroup ends: min %.2f median %.2f max %.2f us; the last twelve:\n", ends[0].first / 100, ends[grid / 2].first / 100, ends.back().first / 100);
+            for (unsigned q = grid >= 12 ? grid - 12 : 0; q < grid; q++) {
+                const int wg = ends[q].second;
+                double s0 = 1e18, l0 = 1e18, l4 = 1e18, bar = 0;
+                for (int w = 0; w < 8; w++) {
+                    const unsigned long long *sp = &st[((size_t)wg * 8 + w) * 32];
+                    s0 = std::min(s0, (double)(sp[0] - t0));
+                    bar = std::max(bar, (double)(sp[3] - t0));
+                    if (sp[8 + 1]) (w < 4 ? l0 : l4) = std::min(w < 4 ? l0 : l4, (double)(sp[8 + 1] - t0));
+                }
+                printf("      wg %3d: start %.2f barrier %.2f first loops %.2f / %.2f end %.2f\n", wg, s0 / 100, bar / 100, l0 / 100, l4 / 100, ends[q].first / 100);
+            }
+        }
+        {   // by XCD (workgroup index mod 8): the second pass's loop (nobody waits for memory there), the epilogue beside it, the end
+            printf("    by XCD:        ");
+            for (int x = 0; x < 8; x++) printf("%8d", x);
+            const char *rows[4] = {"first loop at ", "pass 2 loop   ", "pass 1 epilog.", "end           "};
+            for (int row = 0; row < 4; row++) {
+                printf("\n      %s", rows[row]);
+                for (int x = 0; x < 8; x++) {
+                    std::vector<double> v;
+                    for (size_t w = 0; w < nw; w++) {
+                        if ((int)((w / 8) % 8) != x) continue;
+                        const unsigned long long *sp = &st[w * 32];
+                        if (row == 0 && sp[8 + 1]) v.push_back((double)(sp[8 + 1] - t0));
+                        if (row == 1 && sp[16 + 1]) v.push_back((double)(sp[16 + 2] - sp[16 + 1]));
+                        if (row == 2 && sp[8 + 1]) v.push_back((double)(sp[8 + 6] - sp[8 + 2]));
+                        if (row == 3) v.push_back((double)(sp[7] - t0));
+                    }
+                    std::sort(v.begin(), v.end());
+                    printf("%8.2f", v.empty() ? 0.0 : v[v.size() / 2] / 100);
+                }
+            }
+            printf("\n");
+        }
         // waves 0-3 vs 4-7
         for (int half = 0; half < 2; half++) {
             std::vector<double> a, b;
