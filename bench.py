@@ -351,16 +351,12 @@ def main():
         ch.close()
         del xa
         # the same chain on the overlap-save transform kernels (round 2's first implementation)
-        os.environ["HZ_FIR_FFT"] = "1"
-        ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D)
-        del os.environ["HZ_FIR_FFT"]
+        ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_options(hz.FIR_IMPL_TRANSFORMS).fir_decimate(taps, D)
         _, ms = timed(torch, lambda: ch.run(x, y), k, w)
         extra["chain_transform_kernels"] = rate(n, float(np.median(ms)), 2 + 8 / D)
         ch.close()
         # the same chain on the first int8 matrix kernel (round 2: one round of 2048-output chunk workgroups)
-        os.environ["HZ_MM_V1"] = "1"
-        ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D)
-        del os.environ["HZ_MM_V1"]
+        ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_options(hz.FIR_IMPL_MATRIX_CHUNKS).fir_decimate(taps, D)
         ch.set_time(1.0)
         _, ms = timed(torch, lambda: ch.run(x, y), k, w)
         extra["chain_matrix_chunks_kernel"] = dict(rate(n, float(np.median(ms)), 2 + 8 / D), kernel=ch.last_fir_kernel())
@@ -384,11 +380,8 @@ def main():
             tt = lowpass_taps(nt, 0.5 / dd)
             yy = y[:n // dd]
             row = {}
-            for name, env in (("matrix", None), ("transform", "1")):
-                if env:
-                    os.environ["HZ_FIR_FFT"] = env
-                ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(tt, dd)
-                os.environ.pop("HZ_FIR_FFT", None)
+            for name, impl in (("matrix", hz.FIR_IMPL_AUTO), ("transform", hz.FIR_IMPL_TRANSFORMS)):
+                ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_options(impl).fir_decimate(tt, dd)
                 ch.set_time(1.0)
                 _, ms = timed(torch, lambda: ch.run(x, yy), 12, 2)
                 row[name + "_ms"] = round(float(np.median(ms)), 4)

@@ -21,7 +21,8 @@ import ctypes as C
 import numpy as np
 
 from . import _capi
-from ._capi import (CONV_CONVOLVE, CONV_CROSS_CORRELATE, FFT_BACKWARD, FFT_FORWARD, FIR_KERNEL_MATRIX_CHUNKS,
+from ._capi import (CONV_CONVOLVE, CONV_CROSS_CORRELATE, FFT_BACKWARD, FFT_FORWARD, FIR_IMPL_AUTO,
+                    FIR_IMPL_MATRIX_CHUNKS, FIR_IMPL_TRANSFORMS, FIR_KERNEL_MATRIX_CHUNKS,
                     FIR_KERNEL_MATRIX_PASSES, FIR_KERNEL_NONE, FIR_KERNEL_TRANSFORM, FIR_PATH_MATRIX,
                     FIR_PATH_NONE, FIR_PATH_TRANSFORM, FMT_C64, FMT_I8, FMT_I16, FMT_U8, MEM_DEVICE,
                     MEM_HOST, lib)
@@ -564,6 +565,13 @@ class Chain:
 
     def mix_in_order(self, in_order=True):
         self.ctx._ck(lib.hzsdr_chain_mix_in_order(self._h, int(in_order)))
+        return self
+
+    def fir_options(self, impl=0, nfft_min=0, loop_form=0):
+        """In front of fir_decimate: which implementation the terminal takes (FIR_IMPL_AUTO / _TRANSFORMS /
+        _MATRIX_CHUNKS), the smallest overlap-save block, the matrix loop's form -- include/hzsdr.h:
+        hzsdr_chain_fir_options (measurements and tests; AUTO is the library's choice)."""
+        self.ctx._ck(lib.hzsdr_chain_fir_options(self._h, int(impl), int(nfft_min), int(loop_form)))
         return self
 
     def shift_ulp1(self, on=True):

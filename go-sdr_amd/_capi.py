@@ -52,6 +52,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 FFT_BACKWARD, FFT_FORWARD = 0, 1
 FIR_PATH_NONE, FIR_PATH_TRANSFORM, FIR_PATH_MATRIX = 0, 1, 2
 FIR_KERNEL_NONE, FIR_KERNEL_TRANSFORM, FIR_KERNEL_MATRIX_CHUNKS, FIR_KERNEL_MATRIX_PASSES = 0, 1, 2, 3
+FIR_IMPL_AUTO, FIR_IMPL_TRANSFORMS, FIR_IMPL_MATRIX_CHUNKS = 0, 1, 2  # hzsdr_chain_fir_options
 CONV_CONVOLVE, CONV_CROSS_CORRELATE = 0, 1
 
 (OK, ERR_FORMAT_MISMATCH, ERR_FORMAT_UNKNOWN, ERR_DST_TOO_SMALL, ERR_CONVERSION_NOT_IMPLEMENTED,
@@ -143,6 +144,7 @@ SIGNATURES = {
     "hzsdr_chain_fir_decimate": (i32, [vp, C.POINTER(f32), sz, u32]),
     "hzsdr_chain_mix_in_order": (i32, [vp, i32]),
     "hzsdr_chain_shift_ulp1": (i32, [vp, i32]),
+    "hzsdr_chain_fir_options": (i32, [vp, i32, u32, i32]),
     "hzsdr_chain_plan": (i32, [vp, sz, psz, psz]),
     "hzsdr_chain_run": (i32, [vp, vp, sz, vp, sz, psz, psz]),
     "hzsdr_mgpu_open": (i32, [C.POINTER(C.c_int), i32, pvp]),

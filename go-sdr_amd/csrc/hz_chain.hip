@@ -70,7 +70,12 @@ struct hzsdr_chain {
     bool rh_valid = false;
     double rh_step = 0.0, rh_next = 0.0;
     uint64_t rh_len = 0;
-    bool debug_mm = false;  // HZ_DEBUG_MM, read once at creation
+    bool debug_mm = false;  // HZ_DEBUG_MM (diag_env)
+    // hzsdr_chain_fir_options: which implementation the FIR-decimate terminal takes (0: the library chooses),
+    // the smallest overlap-save block, the matrix loop's form -- A/B measurements and tests
+    int fir_impl = HZSDR_FIR_IMPL_AUTO;
+    unsigned fir_nfft_min = 0;
+    int fir_loop_form = 0;
     int last_path = HZSDR_FIR_PATH_NONE;
 };
 
@@ -84,6 +89,32 @@ struct hzsdr_conv {
 };
 
 namespace hz {
+
+// The diagnostic environment switches (README.md), read ONCE per process -- getenv is not safe against a
+// concurrent setenv, and a chain's behaviour must not depend on what the environment holds at the moment a stage is
+// added -- and only in a library built with -DHZSDR_DIAG (csrc/Makefile: DIAG=1).  Programs select an
+// implementation per chain with hzsdr_chain_fir_options instead.
+struct DiagEnv {
+    bool fir_fft = false, mm_v1 = false, no_slow_first = false, debug_late = false, debug_mm = false;
+    unsigned nfft_min = 0;
+    int rolled = 0;
+};
+static const DiagEnv &diag_env() {
+    static const DiagEnv e = [] {
+        DiagEnv d;
+#ifdef HZSDR_DIAG
+        d.fir_fft = getenv("HZ_FIR_FFT") != nullptr;
+        d.mm_v1 = getenv("HZ_MM_V1") != nullptr;
+        d.no_slow_first = getenv("HZ_NO_SLOW_FIRST") != nullptr;
+        d.debug_late = getenv("HZ_DEBUG_LATE") != nullptr;
+        d.debug_mm = getenv("HZ_DEBUG_MM") != nullptr;
+        if (const char *v = getenv("HZ_FIR_NFFT_MIN")) d.nfft_min = (unsigned)atoi(v);
+        if (const char *v = getenv("HZ_MM_ROLLED")) d.rolled = atoi(v);
+#endif
+        return d;
+    }();
+    return e;
+}
 
 // Launch with `lds` bytes of dynamic LDS; above the 64 KiB default a kernel needs its limit
 // raised once (160 KiB per CU on gfx950).
@@ -378,18 +409,19 @@ static double mm_scale(const hzsdr_chain *c) { return c->src_fmt == HZSDR_FMT_U8
 // 1536: 70 / 70, 2048: 87 / 73; D = 16 (chunks of 1024 outputs): 256: 24 / 70, 512: 28 / 78, 1024: 36 / 48,
 // 1536: 46 / 67, 2047: 54 / 69, 3000: 85 / 82; D = 32: 256: 31 / 71, 1024: 41 / 80, 4096: 99 / 151; D = 64: 1024:
 // 39 / 79, 4096: 77 / 152; the D = 8 / 16 transform figures from before N_fft started at 256 D).
-// Environment HZ_FIR_FFT=1 keeps every chain on the transform kernels (A/B measurements, tests).
+// hzsdr_chain_fir_options(HZSDR_FIR_IMPL_TRANSFORMS) keeps a chain on the transform kernels (A/B measurements, tests).
 static bool mm_eligible(const hzsdr_chain *c) {
-    if (getenv("HZ_FIR_FFT")) return false;
+    if (c->fir_impl == HZSDR_FIR_IMPL_TRANSFORMS || (c->fir_impl == HZSDR_FIR_IMPL_AUTO && diag_env().fir_fft)) return false;
     if (c->src_fmt != HZSDR_FMT_U8 && c->src_fmt != HZSDR_FMT_I8) return false;
     if (!mm::factor_ok(c->factor)) return false;
     return c->ntaps >= 16 && c->ntaps <= (c->factor == 8 ? 1536u : c->factor <= 24 ? 2560u : 4096u);
 }
 
 // hz_firmm2.h (the persistent-pass form): D = 8, and a pass image / table that fit its fixed register counts.
-// HZ_MM_V1=1 keeps the first form (A/B measurements).
+// hzsdr_chain_fir_options(HZSDR_FIR_IMPL_MATRIX_CHUNKS) keeps the first form (A/B measurements).
 static bool mm2_eligible(const hzsdr_chain *c) {
-    if (getenv("HZ_MM_V1") || !mm2::factor_ok(c->factor)) return false;
+    if (c->fir_impl == HZSDR_FIR_IMPL_MATRIX_CHUNKS || (c->fir_impl == HZSDR_FIR_IMPL_AUTO && diag_env().mm_v1)) return false;
+    if (!mm2::factor_ok(c->factor)) return false;
     const mm2::Geom g = mm2::make_geom((int)c->ntaps, (int)c->factor, c->off, 0);
     const int D = (int)c->factor;
     return mm2::image_bytes(D, g.ks) <= (size_t)mm2::kU * 64 * 16 && mm2::table_bytes(g.ne) <= (size_t)4 * mm2::kThreads * 16 &&
@@ -397,34 +429,17 @@ static bool mm2_eligible(const hzsdr_chain *c) {
 }
 
 static void mm_geometry(hzsdr_chain *c) {
-    mm::Geom &g = c->mmg;
     const int D = (int)c->factor;
     c->mm_ver = mm2_eligible(c) ? 2 : 1;
+    // q = round(h' 2^S) with |q| <= 2^30 (hz_firmm_plan.h: digit_shift)
+    const int S = mm::digit_shift(c->taps_host.data(), c->ntaps, mm_scale(c));
     if (c->mm_ver == 2) {
-        const mm2::Geom g2 = mm2::make_geom((int)c->ntaps, D, c->off, 0);
-        g.ntaps = g2.ntaps, g.w0 = g2.w0, g.ks = g2.ks, g.ne = g2.ne, g.e0 = g2.e0, g.off = g2.off;
+        const mm2::Geom g2 = mm2::make_geom((int)c->ntaps, D, c->off, S);
+        mm::Geom &g = c->mmg;
+        g.ntaps = g2.ntaps, g.w0 = g2.w0, g.ks = g2.ks, g.ne = g2.ne, g.e0 = g2.e0, g.shift = g2.shift, g.off = g2.off;
+    } else {
+        c->mmg = mm::make_geom((int)c->ntaps, D, c->off, S);
     }
-    g.ntaps = (int)c->ntaps;
-    if (c->mm_ver == 1) {
-        g.w0 = (g.ntaps - 1 + 7) / 8 * 8;
-        const int window = g.w0 + D * (mm::kT - 1) + 1;  // samples a tile's outputs reach back over
-        g.ks = (2 * window + 31) / 32;
-        g.ks = (g.ks + D - 1) / D * D;  // whole groups of PPT / 2 = D steps (hz_firmm.h)
-        g.e0 = 2 * (g.ks + 4);
-        g.ne = g.e0 + (D / 8) * (mm::kT - 1) + 1;
-    }
-    g.off = c->off;
-    // q = round(h' 2^S) with |q| <= 2^30: |h'[k]| <= |h[k]| * scale for every modulation
-    double hmax = 0.0;
-    for (size_t k = 0; k < c->ntaps; k++) hmax = std::max(hmax, hypot(c->taps_host[2 * k], c->taps_host[2 * k + 1]));
-    hmax *= mm_scale(c);
-    int S = 0;
-    if (hmax > 0.0) {
-        int e;
-        frexp(hmax, &e);  // hmax < 2^e
-        S = 30 - e;
-    }
-    g.shift = S < -900 ? -900 : S > 900 ? 900 : S;
 }
 
 // The digit table of taps[k] * exp(-i omega k step) * scale (hz_firmm.h: F[digit][E][part][16],
@@ -441,50 +456,9 @@ static int mm_table_for(hzsdr_chain *c, double step, double omega, void **dev, b
         return HZSDR_OK;
     }
     if (!make || c->mm_cache.size() >= kLateCacheMax) return HZSDR_OK;
-    const mm::Geom &g = c->mmg;
-    const double sc = mm_scale(c);
-    std::vector<int64_t> qr(c->ntaps), qi(c->ntaps);
-    int64_t sr = 0, si = 0;
-    for (size_t k = 0; k < c->ntaps; k++) {
-        const double ph = -omega * ((double)k * step);
-        const double cr = cos(ph), ci = sin(ph);
-        const double hr = c->taps_host[2 * k], hi = c->taps_host[2 * k + 1];
-        qr[k] = llround(ldexp((hr * cr - hi * ci) * sc, g.shift));
-        qi[k] = llround(ldexp((hr * ci + hi * cr) * sc, g.shift));
-        sr += qr[k];
-        si += qi[k];
-    }
-    // (both forms keep 4 digits x ne x 2 parts x 16 bytes + the constant term; hz_firmm2.h orders them
-    // T[f][E][part][pl] with digit = 2 f + pl: a fragment row holds two digit planes)
-    const bool v2 = c->mm_ver == 2;
-    std::vector<uint8_t> tab(mm::table_bytes(g.ne), 0);
-    static_assert(mm::table_bytes(100) == mm2::table_bytes(100), "one size for both layouts");
-    for (int E = 0; E < g.ne; E++)
-        for (int pout = 0; pout < 2; pout++)
-            for (int e = 0; e < 16; e++) {
-                const int kap = 8 * (E - g.e0) + g.w0 - (e >> 1), pin = e & 1;
-                if (kap < 0 || kap >= g.ntaps) continue;
-                // y_re = h_re x_re - h_im x_im ; y_im = h_im x_re + h_re x_im
-                int64_t q = pout == 0 ? (pin == 0 ? qr[kap] : -qi[kap]) : (pin == 0 ? qi[kap] : qr[kap]);
-                for (int d = 3; d >= 0; d--) {  // balanced base-256 digits, d = 0 most significant
-                    const int64_t r = ((q + 128) & 255) - 128;
-                    const size_t at = v2 ? ((((size_t)(d >> 1) * g.ne + E) * 2 + pout) * 2 + (d & 1)) : (((size_t)d * g.ne + E) * 2 + pout);
-                    tab[at * 16 + e] = (uint8_t)(int8_t)r;
-                    q = (q - r) >> 8;
-                }
-            }
-    // u8: x = (b - 128) + 0.5 (1 + i): the constant part of every output, in units of 2^-S
-    double dc[2] = {0.0, 0.0};
-    if (c->src_fmt == HZSDR_FMT_U8) {
-        dc[0] = 0.5 * (double)(sr - si);
-        dc[1] = 0.5 * (double)(sr + si);
-    }
-    memcpy(tab.data() + (size_t)4 * g.ne * 32, dc, 16);
-    if (v2) {  // the mixer's step factors of this run (one Shift stage: omega is its tau; otherwise unused)
-        float wf[8][4];
-        mm2::step_factors(omega, step, (int)c->factor, wf);
-        memcpy(tab.data() + (size_t)4 * g.ne * 32 + 16, wf, sizeof wf);
-    }
+    // (the table's contents: hz_firmm_plan.h, HIP-free and fuzzed on the host)
+    const std::vector<uint8_t> tab = mm::digit_table(c->mmg, (int)c->factor, c->taps_host.data(), mm_scale(c), step, omega,
+                                                     c->src_fmt == HZSDR_FMT_U8, c->mm_ver == 2);
     void *d = nullptr;
     HZ_HIP(ctx, hipMalloc(&d, tab.size()));
     hipError_t e = hipMemcpyAsync(d, tab.data(), tab.size(), hipMemcpyHostToDevice, ctx->stream);
@@ -528,94 +502,26 @@ static bool mm_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in
     memset(R, 0, sizeof *R);
     memset(F, 0, sizeof *F);
     if (!c->mm_ok || c->mix_in_order || P.segs.big_n != 0 || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) return false;
-    const uint64_t D = c->factor, n_out = n / D, nt = c->ntaps;
-    const uint64_t chunk_out = mm::chunk_out(mm::blocks_for((int)D));  // 2048 outputs at D = 8, 1024 at D = 16
-    const uint64_t tile = mm::kT;
-    if (n_out < 4096 || n_out >= (1ull << 31)) return false;  // (a call this short is launch-bound either way)
     for (int i = 0; i < P.n; i++)
         if (P.op[i].kind == EW_SHIFT && !(fabs(P.op[i].tau_shift) * 6.2832 < 1073741824.0)) return false;
     const int nr = c->has_shift ? P.segs.n : 1;
     if (nr < 1 || nr > mm::kMaxRuns) return false;
-    R->n = nr;
     // does run 0 continue the run the previous call ended in (same step, no reset in between)?  Then
     // the clock is exactly linear across the call boundary and the first windows may reach back
     // into the raw history instead of going to the fix-up tasks.
-    R->cont = c->rh_valid && (!c->has_shift || (P.segs.step[0] == c->rh_step && c->rh_len >= nt && c->rh_next == P.segs.t0[0])) ? 1 : 0;
-    // outputs whose whole window lies in run r (and that has a table): [lo, hi), on the tile grid
-    bool any = false;
+    const bool cont = c->rh_valid && (!c->has_shift || (P.segs.step[0] == c->rh_step && c->rh_len >= c->ntaps && c->rh_next == P.segs.t0[0]));
+    const void *tabs[mm::kMaxRuns];
     for (int r = 0; r < nr; r++) {
-        const uint64_t a = c->has_shift ? P.segs.first[r] : 0;
-        const uint64_t b = (c->has_shift && r + 1 < nr) ? P.segs.first[r + 1] : (uint64_t)n;
         void *dev = nullptr;
         (void)mm_table_for(c, c->has_shift ? P.segs.step[r] : 0.0, 0.0, &dev, false);
-        uint64_t lo = (r == 0 && R->cont) ? 0 : (a + nt - 1 + D - 1) / D, hi = std::min((b + D - 1) / D, n_out);
-        lo = (lo + tile - 1) / tile * tile;
-        if (hi < n_out) hi = hi / tile * tile;
-        R->m_lo[r] = R->m_hi[r] = 0;
-        R->tab[r] = dev;
-        if (!dev || hi < lo + 64) continue;  // a run without a table, or too short to bother
-        R->m_lo[r] = (uint32_t)lo;
-        R->m_hi[r] = (uint32_t)hi;
-        any = true;
+        tabs[r] = dev;
     }
-    if (!any) return false;
-    // The call's outputs in chunks of 2048 (D = 16: 1024); a chunk goes to the run that holds most of it (none: the
-    // run of the chunk before), what that run does not hold goes to the fix-up tasks.
-    const uint64_t n_chunks = (n_out + chunk_out - 1) / chunk_out;
-    uint64_t fix_total = 0, fix_a = 0, fix_b = 0;  // the open fix interval [fix_a, fix_b)
-    auto flush_fix = [&]() {
-        if (fix_b > fix_a && F->n < mm::kMaxFix) {
-            F->m_a[F->n] = (uint32_t)fix_a;
-            F->m_b[F->n] = (uint32_t)fix_b;
-            F->wg_first[F->n] = F->n_wg;
-            F->n_wg += (int)((fix_b - fix_a + mm::kFixOut - 1) / mm::kFixOut);
-            F->n++;
-        } else if (fix_b > fix_a) {
-            fix_total = ~0ull >> 1;  // too many intervals: the call stays on the transform kernels
-        }
-        fix_a = fix_b = 0;
-    };
-    auto add_fix = [&](uint64_t a, uint64_t b) {
-        if (b <= a) return;
-        fix_total += b - a;
-        if (fix_b == a && fix_b > fix_a) {
-            fix_b = b;
-        } else {
-            flush_fix();
-            fix_a = a;
-            fix_b = b;
-        }
-    };
-    int owner = 0, prev_owner = -1;
-    for (int r = 0; r < nr; r++) R->wg_first[r] = (int)n_chunks;
-    for (uint64_t ch = 0; ch < n_chunks; ch++) {
-        const uint64_t cs = ch * chunk_out, ce = std::min(cs + chunk_out, n_out);
-        // the valid ranges ascend with r, so the owner never goes back and the scan stops at the first
-        // run that starts behind the chunk (runs without a range are [0, 0)): linear in chunks + runs
-        uint64_t best = 0;
-        for (int r = owner; r < nr; r++) {
-            if (R->m_hi[r] == 0) continue;
-            if (R->m_lo[r] >= ce) break;
-            const uint64_t lo = std::max<uint64_t>(R->m_lo[r], cs), hi = std::min<uint64_t>(R->m_hi[r], ce);
-            if (hi > lo && hi - lo > best) {
-                best = hi - lo;
-                owner = r;
-            }
-        }
-        if (owner != prev_owner) {
-            for (int r = prev_owner + 1; r <= owner; r++) R->wg_first[r] = (int)ch;  // (runs skipped over own nothing)
-            prev_owner = owner;
-        }
-        const uint64_t vlo = std::max<uint64_t>(R->m_lo[owner], cs), vhi = std::min<uint64_t>(R->m_hi[owner], ce);
-        if (vlo < vhi) {
-            add_fix(cs, vlo);
-            add_fix(vhi, ce);
-        } else {
-            add_fix(cs, ce);
-        }
-    }
-    flush_fix();
-    R->n_wg = (int)n_chunks;
+    const uint64_t zero_first = 0;
+    // the planner itself is host-only code (hz_firmm_plan.h: sanitizer-built and fuzzed in tests/host/)
+    const mm::ChunkPlanIn pin{n, c->factor, (int)c->ntaps, cont, nr, c->has_shift ? P.segs.first : &zero_first, tabs};
+    uint64_t fix_total = 0;
+    const bool ok = mm::plan_chunks(pin, R, F, &fix_total);
+    const uint64_t n_chunks = (uint64_t)R->n_wg;
     if (c->debug_mm) {
         fprintf(stderr, "hzsdr mm: %d runs, cont %d, %llu chunks, %d fix intervals (%d tasks, %llu outputs)\n", nr, R->cont,
                 (unsigned long long)n_chunks, F->n, F->n_wg, (unsigned long long)fix_total);
@@ -624,8 +530,7 @@ static bool mm_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in
                     (unsigned long long)(c->has_shift ? P.segs.first[r] : 0), R->m_lo[r], R->m_hi[r], R->wg_first[r], R->tab[r]);
         for (int k = 0; k < F->n; k++) fprintf(stderr, "   fix [%u, %u) first task %d\n", F->m_a[k], F->m_b[k], F->wg_first[k]);
     }
-    // the fix-up tasks are the slow way: a call that is mostly boundaries keeps the transforms
-    return fix_total <= 16384 && fix_total * 8 <= n_out;
+    return ok;
 }
 
 static int mm_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const EwProgram &P, const mm::Runs &R,
@@ -695,7 +600,7 @@ static int mm2_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const
     return mm2::launch_fir(c->ctx->stream, c->ctx->num_cus, c->src_fmt, c->factor, in, (float2 *)out,
                            (const float2 *)c->hist[c->hist_cur], (float2 *)c->hist[c->hist_cur ^ 1],
                            (const uint8_t *)c->rhist[c->hist_cur], (uint8_t *)c->rhist[c->hist_cur ^ 1],
-                           (const float2 *)c->taps_dev, n, g2, L, P, F);
+                           (const float2 *)c->taps_dev, n, g2, L, P, F, c->fir_loop_form);
 }
 
 // The modulated filter of every clock run long enough to hold a whole block (lookups only).
@@ -732,7 +637,7 @@ static int late_filters(hzsdr_chain *c, const EwProgram &P, size_t n, LateFilter
 static void slow_blocks(const hzsdr_chain *c, const EwProgram &P, const LateFilters &late, size_t n,
                         size_t nblocks, SlowBlocks *out) {
     out->n = 0;
-    if (getenv("HZ_NO_SLOW_FIRST")) return;  // measurement aid (tools/wrap_probe.py): stream order
+    if (diag_env().no_slow_first) return;  // measurement aid (tools/wrap_probe.py): stream order
     const int64_t N = c->nfft, hop = c->hop, off = c->off;
     std::vector<unsigned> v;
     auto add_range = [&](int64_t lo, int64_t hi) {  // blocks lo .. hi inclusive, clipped
@@ -762,7 +667,7 @@ static void slow_blocks(const hzsdr_chain *c, const EwProgram &P, const LateFilt
     if (v.size() > (size_t)kMaxSlowBlocks) return;
     out->n = (int)v.size();
     for (size_t i = 0; i < v.size(); i++) out->idx[i] = v[i];
-    if (getenv("HZ_DEBUG_LATE")) {
+    if (diag_env().debug_late) {
         int nh = 0;
         for (int r = 0; r < nr; r++) nh += late.h[r] != nullptr;
         fprintf(stderr, "hzsdr: %d runs, %d with a late filter, %d of %zu blocks listed as reference-order:", nr, nh, out->n, nblocks);
@@ -989,7 +894,9 @@ int hzsdr_chain_create(hzsdr_ctx *ctx, int src_format, uint64_t sample_rate, hzs
     c->ctx = ctx;
     c->src_fmt = src_format;
     c->sample_rate = sample_rate;
-    c->debug_mm = getenv("HZ_DEBUG_MM") != nullptr;
+    c->debug_mm = hz::diag_env().debug_mm;
+    c->fir_nfft_min = hz::diag_env().nfft_min;
+    c->fir_loop_form = hz::diag_env().rolled;
     *out = c;
     return HZSDR_OK;
 }
@@ -1063,6 +970,17 @@ int hzsdr_chain_convolution(hzsdr_chain *c, const void *filter_freq, size_t filt
     return HZSDR_OK;
 }
 
+int hzsdr_chain_fir_options(hzsdr_chain *c, int impl, unsigned nfft_min, int loop_form) {
+    if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
+    if (c->term != TERM_NONE) return hz::fail(c->ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: fir options go in front of the terminal stage");
+    if (impl < HZSDR_FIR_IMPL_AUTO || impl > HZSDR_FIR_IMPL_MATRIX_CHUNKS || (nfft_min && (nfft_min < 256 || nfft_min > 8192 || (nfft_min & (nfft_min - 1)))))
+        return hz::fail(c->ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: fir options");
+    c->fir_impl = impl;
+    c->fir_nfft_min = nfft_min;
+    c->fir_loop_form = loop_form;
+    return HZSDR_OK;
+}
+
 int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps, size_t n_taps, unsigned factor) {
     using namespace hz;
     HZ_TRY(chain_terminal_set(c));
@@ -1073,10 +991,10 @@ int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps, size_t n_taps, u
     // the polyphase analysis N / D >= 256 for D = 2, 4, 8, 16.  Measured on 2^24 u8 samples (us per
     // chain_run, N_min = 256 as in round 1 -> now): D = 8, 64 taps 152 -> 43, 256 taps 71 -> 45;
     // D = 16, 256 taps 69 -> 41; D = 4, 128 taps 167 -> 54; D = 2, 64 taps 157 -> 78.
-    // (HZ_FIR_NFFT_MIN overrides N_min: the measurement aid those numbers come from.)
+    // (hzsdr_chain_fir_options' nfft_min overrides N_min: the measurement aid those numbers come from.)
     unsigned nfft = 1024;
     if (factor == 2 || factor == 4 || factor == 8 || factor == 16) nfft = std::max(1024u, 256u * factor);
-    if (getenv("HZ_FIR_NFFT_MIN")) nfft = (unsigned)atoi(getenv("HZ_FIR_NFFT_MIN"));
+    if (c->fir_nfft_min) nfft = c->fir_nfft_min;
     if (nfft < 256 || nfft > 8192 || (nfft & (nfft - 1))) nfft = 1024;
     while (nfft < 4 * n_taps && nfft < 8192) nfft <<= 1;
     unsigned off = (unsigned)(n_taps - 1);

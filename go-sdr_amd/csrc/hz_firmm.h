@@ -55,6 +55,7 @@
 // (tools/fix_pk_opsel.py, run by the Makefile behind the link: same arithmetic, same size, same schedule; compiling
 // the kernels without packed float32 altogether cost 2 us of 38), and tests/test_capi_cpu.py holds the library to it.
 #include "hz_chain_dev.h"
+#include "hz_firmm_plan.h"
 
 namespace hz {
 namespace mm {
@@ -63,18 +64,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 
-constexpr int kT = 16;                        // outputs per tile
-// NB 32-tile column blocks per workgroup: 4 at D = 8 (2048 outputs, 34 KB of input: four workgroups per
-// CU), 2 at D = 16 (1024 outputs, the same 34 KB: with 4 a chunk was 67 KB, two workgroups per CU --
-// one wave per SIMD -- and the matrix form no faster than the transforms at 1024 taps), 1 at D = 32 (512
-// outputs, 34 KB: the table loads are no longer shared between blocks, but the matrix work is a quarter)
-constexpr int blocks_for(int D) { return D >= 32 ? 1 : D >= 16 ? 2 : 4; }  // (D = 24: 48 KB, 40 / 48 / 64: 40 / 48 / 64 KB)
-constexpr int chunk_tiles(int nb) { return 32 * nb; }
-constexpr int chunk_out(int nb) { return chunk_tiles(nb) * kT; }
-constexpr int kThreads = 128;                 // two waves
-constexpr int kFixOut = 16;                   // outputs per fix-up task
-constexpr int kMaxRuns = kNcoMaxSegs;
-constexpr int kMaxFix = kMaxRuns + 2;
+static_assert(kMaxRuns == kNcoMaxSegs, "one run per clock-table entry");
 // How the two waves of a workgroup share the chunk's 4 digit planes x 4 column blocks:
 // HZ_MM_SPLIT_BLOCKS = 0: by digits (wave 0: planes 0-1, wave 1: planes 2-3, all four blocks; the halves
 // meet through LDS); 1: by blocks (each wave all four planes of two blocks: no exchange, twice the
@@ -84,46 +74,6 @@ constexpr int kMaxFix = kMaxRuns + 2;
 #endif
 constexpr bool kSplitBlocks = HZ_MM_SPLIT_BLOCKS != 0;
 constexpr int kND = kSplitBlocks ? 4 : 2;       // digit planes per wave
-
-// geometry of one chain (host: mm_geometry)
-struct Geom {
-    int ntaps;
-    int w0;      // window start before the tile's first output sample: ntaps-1 rounded up to 8
-    int ks;      // 32-byte steps over a tile's window (a multiple of D: whole groups of the matrix loop)
-    int ne;      // entries E of one digit of the table
-    int e0;      // E of (i = 0, h = 0, s = 0): 2 (ks + 4), the prefetch runs four steps past the end
-    int shift;   // S: taps are q = round(h' 2^S)
-    unsigned off;  // history length (the chain's `off`)
-};
-
-// per clock run: the table, the outputs that take the matrix path (tile-aligned inside the call) and
-// the first chunk (2048 outputs of the call's grid) the host gave to the run
-struct Runs {
-    int n;
-    int n_wg;                 // chunk workgroups in total
-    int cont;                 // run 0 continues the previous call's last run: windows may reach into the raw history
-    const void *tab[kMaxRuns];
-    uint32_t m_lo[kMaxRuns], m_hi[kMaxRuns];
-    int wg_first[kMaxRuns];
-};
-// the output ranges computed in reference order, and the first fix-up workgroup of each
-struct Fix {
-    int n;
-    int n_wg;
-    uint32_t m_a[kMaxFix], m_b[kMaxFix];
-    int wg_first[kMaxFix];
-};
-
-constexpr int tile_bytes(int D) { return 2 * D * kT; }
-constexpr int pieces_per_tile(int D) { return tile_bytes(D) / 16; }
-constexpr size_t chunk_bytes(int D, int ks) {
-    return (size_t)(chunk_tiles(blocks_for(D)) - 1) * tile_bytes(D) + 32 * (size_t)ks;
-}
-// the matrix loop's look-ahead reads two steps past the last window: LDS allocated behind the image
-// (a conditional in the unrolled loop instead cost 1.8 us of the kernel)
-constexpr size_t kLookAhead = 1024;
-// table bytes: 4 digits x ne x 2 parts x 16, then (dc_re, dc_im) as two doubles
-constexpr size_t table_bytes(int ne) { return (size_t)4 * ne * 32 + 16 + 128; }  // (+ 128: hz_firmm2.h's step factors)
 
 // LDS image of a chunk: 16-byte piece p of tile t at TB t + 16 (p ^ (t & 15)).  A fragment read
 // (same piece, 32 consecutive tiles; ds_read_b128 serves 16 lanes per cycle) then touches 16

@@ -762,7 +762,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
 // hz_firmm2.hip
 int launch_fir(hipStream_t stream, int num_cus, int fmt, unsigned D, const void *in, float2 *out, const float2 *hist,
                float2 *new_hist, const uint8_t *rhist, uint8_t *new_rhist, const float2 *taps, size_t n, const Geom &g,
-               const Plan &L, const EwProgram &P, const Fix &F);
+               const Plan &L, const EwProgram &P, const Fix &F, int loop_form = 0);
 
 }  // namespace mm2
 }  // namespace hz

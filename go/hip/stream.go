@@ -255,6 +255,13 @@ func (ch *Chain) FIRDecimate(taps []complex64, factor uint) error {
 
 func (ch *Chain) MixInOrder(inOrder bool) error { return toErr(ch.x.c, C.hzsdr_chain_mix_in_order(ch.c, cbool(inOrder))) }
 
+// FIROptions selects, in front of FIRDecimate, which implementation the terminal takes (0: the library's choice,
+// 1: the overlap-save transform kernels, 2: the int8 matrix form as chunk workgroups), the smallest overlap-save
+// block and the matrix loop's form: a measurement and test aid (include/hzsdr.h: hzsdr_chain_fir_options).
+func (ch *Chain) FIROptions(impl int, nfftMin uint, loopForm int) error {
+	return toErr(ch.x.c, C.hzsdr_chain_fir_options(ch.c, C.int(impl), C.uint(nfftMin), C.int(loopForm)))
+}
+
 // ShiftULP1 opts a terminal-less chain (ShiftReader, ShiftReader -> Gain) in to the Shift whose rotation
 // factor is within one float32 ulp of the reference's instead of bit-identical to it (include/hzsdr.h).
 func (ch *Chain) ShiftULP1(on bool) error { return toErr(ch.x.c, C.hzsdr_chain_shift_ulp1(ch.c, cbool(on))) }

@@ -364,6 +364,18 @@ int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps_c64, size_t n_tap
  * bound, not to bits).  in_order = 1: every block mixes each input sample before the
  * filter, exactly as nested stream.ShiftReader -> filter Readers would. */
 int hzsdr_chain_mix_in_order(hzsdr_chain *c, int in_order);
+/* Measurement and test aid, in front of hzsdr_chain_fir_decimate: WHICH implementation the FIR-decimate
+ * terminal takes -- all of them compute the same filter (stream/downsample.go:47-64 / a Reader that
+ * convolves and decimates) within the bound of DESIGN.md section 2; AUTO is the library's choice by
+ * format, factor and tap count and is what every ordinary caller wants.  nfft_min (0: the default):
+ * the smallest overlap-save block (a power of two in 256 ... 8192); loop_form (0: the default): the
+ * persistent-pass matrix kernel's loop form (1, 2, 4 groups per trip, 99 the any-window instantiation).
+ * Replaces the round-2/3 environment switches HZ_FIR_FFT / HZ_MM_V1 / HZ_FIR_NFFT_MIN / HZ_MM_ROLLED,
+ * which a library built with -DHZSDR_DIAG still reads, once, as the process-wide default. */
+#define HZSDR_FIR_IMPL_AUTO 0
+#define HZSDR_FIR_IMPL_TRANSFORMS 1     /* the overlap-save transform kernels */
+#define HZSDR_FIR_IMPL_MATRIX_CHUNKS 2  /* the int8 matrix form as chunk workgroups (hz_firmm.h), where eligible */
+int hzsdr_chain_fir_options(hzsdr_chain *c, int impl, unsigned nfft_min, int loop_form);
 /* OPT-IN, off by default: a chain WITHOUT a terminal (ShiftReader, or ShiftReader -> Gain: BASELINE config 2)
  * whose buffers allow four samples per lane forms the Shift's rotation factor from the phase in turns with
  * float32 polynomials instead of an operation-for-operation math.Sincos in float64.  The float64 product

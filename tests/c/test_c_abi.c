@@ -236,8 +236,10 @@ static void chain_and_ring(void) { /* go/hip/stream.go Chain, go/hip/ring.go */
     OK(hzsdr_chain_shift(c, -2.5e6));
     OK(hzsdr_chain_gain(c, 0.5f));
     OK(hzsdr_chain_rotate(c, 0.0f, 1.0f));
+    OK(hzsdr_chain_fir_options(c, HZSDR_FIR_IMPL_AUTO, 0, 0)); /* (the library's choice: what every caller wants) */
     OK(hzsdr_chain_fir_decimate(c, taps, T, D));
     CHECK(hzsdr_chain_decimate(c, 2) == HZSDR_ERR_INVALID_ARGUMENT); /* one terminal stage */
+    CHECK(hzsdr_chain_fir_options(c, HZSDR_FIR_IMPL_TRANSFORMS, 0, 0) == HZSDR_ERR_INVALID_ARGUMENT); /* in front of it */
     OK(hzsdr_chain_mix_in_order(c, 0));
     OK(hzsdr_chain_shift_ulp1(c, 0));
     size_t cons = 0, outn = 0;

@@ -9,15 +9,22 @@
 //     serial recurrence of stream/shifter.go:76-79 (ts += 1/fs; if ts > 2 pi { ts -= 2 pi }) sample for sample;
 //   * mm2::plan_call (hz_firmm2_plan.h): every output lies in EXACTLY one run's valid range or one fix-up
 //     interval; ranges and intervals ascend; a run's passes hold its outputs; tile alignment; task counts;
-//     windows of valid outputs lie inside their run (or the raw history when the call continues a run).
+//     windows of valid outputs lie inside their run (or the raw history when the call continues a run);
+//   * mm::plan_chunks (hz_firmm_plan.h, the chunk form's planner, factors 8 ... 64): every output lies in EXACTLY
+//     one place -- its chunk's owner run's valid range or one fix-up interval --, the owners ascend with the chunks,
+//     a run's first chunk is where its ownership starts, task counts add up;
+//   * mm::digit_table (hz_firmm_plan.h): the four balanced base-256 digits of every table entry recombine to the
+//     quantised tap they were cut from, |q| <= 2^30, in both kernels' layouts; the constant term; step factors of
+//     unit modulus to 2^-23.
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <vector>
 
-#include "hz_firmm2_plan.h"
+#include "hz_firmm_plan.h"
 #include "hzsdr.h"
 
 using namespace hz;
@@ -44,7 +51,7 @@ int main(int argc, char **argv) {
     const int cases = argc > 1 ? atoi(argv[1]) : 3000;
     const double tau = 6.283185307179586476925286766559;
     const uint64_t rates[] = {250000, 1000000, 1048576, 1800000, 2048000, 2097152, 2400000, 8000000, 20000000, 200000000};
-    long planned = 0, fell_back = 0;
+    long planned = 0, fell_back = 0, chunks_planned = 0, tables = 0;
     for (g_case = 0; g_case < cases; g_case++) {
         const uint64_t fs = rates[rnd() % (sizeof rates / sizeof rates[0])];
         double ts0;
@@ -82,6 +89,126 @@ int main(int argc, char **argv) {
                 REQUIRE(planned_ts == ts);
             }
             REQUIRE(ts == ts_end);
+        }
+        // ---- the chunk planner (hz_firmm.h's form) over these runs, any of its factors
+        if (need <= (size_t)mm::kMaxRuns) {
+            static const unsigned factors[] = {8, 16, 24, 32, 40, 48, 64};
+            const unsigned Dc = factors[rnd() % 7];
+            const int nt = 16 + (int)(rnd() % (Dc == 8 ? 1500 : 4000));
+            std::vector<uint64_t> first(need);
+            std::vector<const void *> tab(need);
+            static const char dummy_c = 0;
+            for (size_t k = 0; k < need; k++) {
+                first[k] = segs[k].first;
+                tab[k] = (segs[k].count >= 8ull * (uint64_t)nt && rnd() % 16 != 0) ? &dummy_c : nullptr;
+            }
+            const mm::ChunkPlanIn cin{n / Dc * Dc, Dc, nt, rnd() % 2 == 0, (int)need, first.data(), tab.data()};
+            mm::Runs R;
+            mm::Fix F;
+            uint64_t fix_outputs = 0;
+            if (mm::plan_chunks(cin, &R, &F, &fix_outputs)) {
+                chunks_planned++;
+                const uint64_t n_out = cin.n_in / Dc, chunk = (uint64_t)mm::chunk_out(mm::blocks_for((int)Dc));
+                REQUIRE(R.n == (int)need && (uint64_t)R.n_wg == (n_out + chunk - 1) / chunk && F.n <= mm::kMaxFix);
+                REQUIRE(fix_outputs <= 16384 && fix_outputs * 8 <= n_out);
+                std::vector<uint8_t> cover(n_out, 0);
+                uint64_t prev_hi = 0;
+                for (int r = 0; r < R.n; r++) {
+                    if (R.m_hi[r] == 0) continue;
+                    REQUIRE(R.tab[r] != nullptr && R.m_lo[r] < R.m_hi[r] && R.m_hi[r] <= n_out && R.m_lo[r] >= prev_hi);
+                    REQUIRE(R.m_lo[r] % mm::kT == 0 && (R.m_hi[r] % mm::kT == 0 || R.m_hi[r] == n_out));
+                    const uint64_t run_end = (size_t)r + 1 < need ? first[r + 1] : cin.n_in;
+                    const int64_t w_lo = (int64_t)Dc * R.m_lo[r] - (nt - 1);
+                    REQUIRE(w_lo >= (int64_t)first[r] || (r == 0 && cin.cont));
+                    REQUIRE((uint64_t)Dc * (R.m_hi[r] - 1) < run_end);
+                    prev_hi = R.m_hi[r];
+                }
+                // a chunk's owner: the last run whose first chunk is at or before it (the kernel's lookup)
+                int prev_owner = 0;
+                for (uint64_t ch = 0; ch < (uint64_t)R.n_wg; ch++) {
+                    int owner = -1;
+                    for (int r = 0; r < R.n; r++)
+                        if ((uint64_t)R.wg_first[r] <= ch) owner = r;
+                    REQUIRE(owner >= prev_owner);
+                    prev_owner = owner;
+                    const uint64_t cs = ch * chunk, ce = cs + chunk < n_out ? cs + chunk : n_out;
+                    const uint64_t vlo = R.m_lo[owner] > cs ? R.m_lo[owner] : cs, vhi = R.m_hi[owner] < ce ? R.m_hi[owner] : ce;
+                    for (uint64_t m = vlo; m < vhi; m++) cover[m]++;
+                }
+                int tasks = 0;
+                uint64_t fixed = 0;
+                uint32_t prev_b = 0;
+                for (int k = 0; k < F.n; k++) {
+                    REQUIRE(F.m_a[k] < F.m_b[k] && F.m_b[k] <= n_out && F.m_a[k] >= prev_b && F.wg_first[k] == tasks);
+                    tasks += (int)((F.m_b[k] - F.m_a[k] + mm::kFixOut - 1) / mm::kFixOut);
+                    for (uint64_t m = F.m_a[k]; m < F.m_b[k]; m++) cover[m]++;
+                    fixed += F.m_b[k] - F.m_a[k];
+                    prev_b = F.m_b[k];
+                }
+                REQUIRE(tasks == F.n_wg && fixed == fix_outputs);
+                for (uint64_t m = 0; m < n_out; m++) REQUIRE(cover[m] == 1);
+            }
+        }
+        // ---- a digit table (every eighth case: the tables are 20 ... 70 KB)
+        if (g_case % 8 == 0) {
+            static const unsigned factors[] = {8, 16, 32, 64};
+            const bool v2 = rnd() % 2 == 0;
+            const int Dt = v2 ? 8 : (int)factors[rnd() % 4];
+            const int nt = 16 + (int)(rnd() % (v2 ? 1100 : 2000));
+            std::vector<double> taps(2 * (size_t)nt);
+            const double amp = ldexp(1.0, (int)(rnd() % 40) - 30);
+            for (auto &t : taps) t = (double)(float)((urand() - 0.5) * amp);
+            const double scale = rnd() % 2 ? 1.0 / 127.5 : 1.0 / 128.0;
+            const int S = mm::digit_shift(taps.data(), (size_t)nt, scale);
+            const unsigned off = (unsigned)((nt - 1 + Dt - 1) / Dt * Dt);
+            mm::Geom g;
+            if (v2) {
+                const mm2::Geom g2 = mm2::make_geom(nt, Dt, off, S);
+                g.ntaps = g2.ntaps, g.w0 = g2.w0, g.ks = g2.ks, g.ne = g2.ne, g.e0 = g2.e0, g.shift = g2.shift, g.off = g2.off;
+            } else {
+                g = mm::make_geom(nt, Dt, off, S);
+            }
+            const double stepv = 1.0 / (double)fs, omega = tau * 1e6 * (urand() - 0.5);
+            std::vector<int64_t> q;
+            const std::vector<uint8_t> tab = mm::digit_table(g, Dt, taps.data(), scale, stepv, omega, scale != 1.0 / 128.0, v2, &q);
+            REQUIRE(tab.size() == mm::table_bytes(g.ne));
+            int64_t sr = 0, si = 0;
+            for (int k = 0; k < nt; k++) {
+                REQUIRE(llabs(q[2 * k]) <= (1ll << 30) && llabs(q[2 * k + 1]) <= (1ll << 30));
+                sr += q[2 * k], si += q[2 * k + 1];
+            }
+            size_t seen = 0;
+            for (int E = 0; E < g.ne; E++)
+                for (int pout = 0; pout < 2; pout++)
+                    for (int e = 0; e < 16; e++) {
+                        const int kap = 8 * (E - g.e0) + g.w0 - (e >> 1), pin = e & 1;
+                        int64_t v = 0;
+                        for (int d = 0; d < 4; d++) {
+                            const size_t at = v2 ? ((((size_t)(d >> 1) * g.ne + E) * 2 + pout) * 2 + (d & 1)) : (((size_t)d * g.ne + E) * 2 + pout);
+                            v = v * 256 + (int8_t)tab[at * 16 + e];
+                        }
+                        if (kap < 0 || kap >= nt) {
+                            REQUIRE(v == 0);
+                            continue;
+                        }
+                        const int64_t want = pout == 0 ? (pin == 0 ? q[2 * kap] : -q[2 * kap + 1]) : (pin == 0 ? q[2 * kap + 1] : q[2 * kap]);
+                        REQUIRE(v == want);
+                        seen++;
+                    }
+            REQUIRE(seen == 4 * (size_t)nt);  // every tap, (re, im) x (I, Q), exactly once
+            double dc[2];
+            memcpy(dc, tab.data() + (size_t)4 * g.ne * 32, 16);
+            REQUIRE(scale == 1.0 / 128.0 ? (dc[0] == 0.0 && dc[1] == 0.0) : (dc[0] == 0.5 * (double)(sr - si) && dc[1] == 0.5 * (double)(sr + si)));
+            if (v2) {
+                float wf[8][4];
+                memcpy(wf, tab.data() + (size_t)4 * g.ne * 32 + 16, sizeof wf);
+                REQUIRE(wf[0][0] == 1.0f && wf[0][1] == 0.0f);  // (k = 0)
+                for (int i = 0; i < 8; i++) {
+                    const double c = (double)wf[i][0] + (double)wf[i][2], s = (double)wf[i][1] + (double)wf[i][3];
+                    REQUIRE(fabs(c * c + s * s - 1.0) < 1e-12);
+                }
+            }
+            tables++;
         }
         // ---- the pass planner over these runs
         if (need > (size_t)mm2::kMaxClockRuns) continue;
@@ -184,6 +311,6 @@ int main(int argc, char **argv) {
         REQUIRE(short_planned <= 1);
         printf("plan_fuzz wrap call: %zu clock runs, %d with a table, %d on the matrix path (%d of them short), %d fix-up tasks\n", need, with_table, L.n, short_planned, F.n_task);
     }
-    printf("plan_fuzz ok: %d cases, %ld planned, %ld kept the transforms\n", cases, planned, fell_back);
+    printf("plan_fuzz ok: %d cases, %ld planned, %ld kept the transforms; %ld chunk plans, %ld digit tables\n", cases, planned, fell_back, chunks_planned, tables);
     return 0;
 }

@@ -65,10 +65,12 @@ def oracle(orc, x, rate, ops, taps, D, ts0=0.0, cuts=None, ts_at=None):
     return want, float(np.abs(xc).max())
 
 
-def build(hz, ctx, fmt, rate, ops, taps, D):
+def build(hz, ctx, fmt, rate, ops, taps, D, impl=0):
     ch = ctx.chain(fmt, rate)
     for kind, arg in ops:
         ch = ch.shift(arg) if kind == "shift" else ch.gain(arg) if kind == "gain" else ch.rotate(arg)
+    if impl:
+        ch.fir_options(impl)
     return ch.fir_decimate(taps, D)
 
 
@@ -115,8 +117,7 @@ def test_matrix_form_against_the_oracle(hz, ctx, orc, name):
         assert ch.run(x[a:b], out[a // D:b // D]) == (b - a, (b - a) // D)
         assert ch.last_fir_path() == hz.FIR_PATH_MATRIX, (name, a)
         # factor 8 up to ~1150 taps: the persistent-pass kernel (csrc/hz_firmm2.h); the rest: chunk workgroups
-        want_kernel = hz.FIR_KERNEL_MATRIX_PASSES if D == 8 and c["ntaps"] <= 1100 and not os.environ.get("HZ_MM_V1") \
-            else hz.FIR_KERNEL_MATRIX_CHUNKS
+        want_kernel = hz.FIR_KERNEL_MATRIX_PASSES if D == 8 and c["ntaps"] <= 1100 else hz.FIR_KERNEL_MATRIX_CHUNKS
         assert ch.last_fir_kernel() == want_kernel, (name, a, ch.last_fir_kernel())
     assert_fir_close(out, want, taps, xmax, name)
     # exact integer filter sums: what is left is one float32 rounding of the filter output and one per
@@ -175,14 +176,14 @@ def test_clock_boundaries_and_wrap(hz, ctx, orc):
     ch.close()
 
 
-def test_where_the_matrix_form_must_not_run(hz, ctx, orc, monkeypatch):
+def test_where_the_matrix_form_must_not_run(hz, ctx, orc):
     rate, taps = 20_000_000, taps_for(1024)
     n = 1 << 19
     x = rand_u8(8, n)
     ops = [("shift", -2.5e6)]
 
-    def run(D, in_order=False, fmt=None, data=None):
-        ch = build(hz, ctx, fmt or hz.FMT_U8, rate, ops, taps, D)
+    def run(D, in_order=False, fmt=None, data=None, impl=0):
+        ch = build(hz, ctx, fmt or hz.FMT_U8, rate, ops, taps, D, impl)
         ch.mix_in_order(in_order)
         ch.set_time(1.0)
         out = zeros("c64", n // D)
@@ -206,11 +207,17 @@ def test_where_the_matrix_form_must_not_run(hz, ctx, orc, monkeypatch):
     ch.run(x, zeros("c64", n // 8))
     assert ch.last_fir_path() == hz.FIR_PATH_TRANSFORM
     ch.close()
-    monkeypatch.setenv("HZ_FIR_FFT", "1")  # read when the terminal is created
-    p, out_fft = run(8)
+    p, out_fft = run(8, impl=hz.FIR_IMPL_TRANSFORMS)  # hzsdr_chain_fir_options, in front of the terminal
     assert p == hz.FIR_PATH_TRANSFORM
-    assert_fir_close(out_fft, want8, taps, xmax, "HZ_FIR_FFT")
-    monkeypatch.delenv("HZ_FIR_FFT")
+    assert_fir_close(out_fft, want8, taps, xmax, "FIR_IMPL_TRANSFORMS")
+    # ... and the chunk form of the matrix path where the persistent passes are the default
+    ch = build(hz, ctx, hz.FMT_U8, rate, ops, taps, 8, hz.FIR_IMPL_MATRIX_CHUNKS)
+    ch.set_time(1.0)
+    out_chunks = zeros("c64", n // 8)
+    ch.run(x, out_chunks)
+    assert ch.last_fir_kernel() == hz.FIR_KERNEL_MATRIX_CHUNKS
+    ch.close()
+    assert_fir_close(out_chunks, want8, taps, xmax, "FIR_IMPL_MATRIX_CHUNKS")
     # the two implementations agree far inside their common bound
     d = out.astype(np.complex128) - out_fft
     assert np.linalg.norm(d) <= 3e-7 * np.linalg.norm(want8.astype(np.complex128))

@@ -55,10 +55,12 @@ def oracle_chain(orc, x, rate, ops, taps, D, ts0=0.0):
     return want, xc
 
 
-def build(hz, ctx, fmt, rate, ops, taps, D, in_order):
+def build(hz, ctx, fmt, rate, ops, taps, D, in_order, fir_opts=None):
     ch = ctx.chain(fmt, rate)
     for kind, arg in ops:
         ch = ch.shift(arg) if kind == "shift" else ch.gain(arg) if kind == "gain" else ch.rotate(arg)
+    if fir_opts:
+        ch.fir_options(**fir_opts)
     ch.fir_decimate(taps, D)
     ch.mix_in_order(in_order)
     return ch
@@ -150,21 +152,20 @@ def test_chains_without_a_shift(hz, ctx, orc):
 
 
 @pytest.mark.parametrize("nmin,ntaps,D,fmt", [(256, 50, 3, "c64"), (256, 64, 8, "u8"), (512, 100, 2, "i16"), (512, 120, 5, "c64")])
-def test_small_overlap_save_blocks(hz, ctx, orc, monkeypatch, nmin, ntaps, D, fmt):
+def test_small_overlap_save_blocks(hz, ctx, orc, nmin, ntaps, D, fmt):
     """The library picks N_fft >= 1024 (>= 256 D for the polyphase factors) because the fast forms of
-    the kernels need it; the 256- and 512-point instantiations stay correct (HZ_FIR_NFFT_MIN, read
-    when the terminal is created, and HZ_FIR_FFT for the byte source that would otherwise take the
+    the kernels need it; the 256- and 512-point instantiations stay correct (hzsdr_chain_fir_options:
+    the smallest block, and the transform kernels for the byte source that would otherwise take the
     matrix form)."""
     from util import rand_i16
-    monkeypatch.setenv("HZ_FIR_NFFT_MIN", str(nmin))
-    monkeypatch.setenv("HZ_FIR_FFT", "1")
+    fir_opts = dict(impl=hz.FIR_IMPL_TRANSFORMS, nfft_min=nmin)
     n, rate, taps = 1 << 18, 2_400_000, taps_for(ntaps)
     ops = [("shift", 2.5e5), ("gain", 0.5)]
     x = {"u8": rand_u8, "i16": rand_i16, "c64": rand_c64}[fmt](3, n)
     f = {"u8": hz.FMT_U8, "i16": hz.FMT_I16, "c64": hz.FMT_C64}[fmt]
     want, xc = oracle_chain(orc, x, rate, ops, taps, D)
     for in_order in (False, True):
-        ch = build(hz, ctx, f, rate, ops, taps, D, in_order)
+        ch = build(hz, ctx, f, rate, ops, taps, D, in_order, fir_opts)
         out = zeros("c64", n // D)
         cons, outn = ch.run(x, out)
         assert (cons, outn) == (n // D * D, n // D)

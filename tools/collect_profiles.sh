@@ -27,8 +27,8 @@ tools/bin/mfma_fir > $out/mfma_fir.txt 2>&1
 tools/bin/mfma_fir2 > $out/mfma_fir2.txt 2>&1
 tools/bin/mfma_rate > $out/mfma_rate.txt 2>&1
 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" > $out/firmm_probe.txt
-HZ_MM_V1=1 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" >> $out/firmm_probe.txt
-HZ_FIR_FFT=1 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" >> $out/firmm_probe.txt
+PROBE_IMPL=2 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" >> $out/firmm_probe.txt
+PROBE_IMPL=1 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" >> $out/firmm_probe.txt
 for f in $out/bench_trace/*/*kernel_stats.csv $out/fft_trace/*/*kernel_stats.csv $out/kern_trace/*/*kernel_stats.csv; do echo "== $f"; cut -d, -f1-4 $f | cut -c1-160 | head -14; done
 cat $out/sq_counters.txt | head -60
 tail -3 $out/bench.err

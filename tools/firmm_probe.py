@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-call device time of the north-star chain on 12 rotating 2^24-sample buffers (the bench's
-timed loop), for the int8 matrix form and -- HZ_FIR_FFT=1 -- the transform kernels; the second
+timed loop), for the int8 matrix form and -- PROBE_IMPL=1: the transform kernels, 2: the chunk form -- ; the second
 half of the calls is printed one by one (a clock wrap shows as a slower call)."""
 import importlib
 import os
@@ -23,7 +23,7 @@ def main():
     taps = B.lowpass_taps(ntaps, 0.5 / D)
     xs = [torch.from_numpy(B.synth_u8(9 + i, n)).cuda() for i in range(12)]
     y = torch.zeros(n // D, dtype=torch.complex64, device="cuda")
-    ch = ctx.chain(hz.FMT_U8, fs).shift(-fs / 8).fir_decimate(taps, D)
+    ch = ctx.chain(hz.FMT_U8, fs).shift(-fs / 8).fir_options(int(os.environ.get("PROBE_IMPL", "0"))).fir_decimate(taps, D)
     for i in range(6):
         ch.run(xs[i % 12], y)
     torch.cuda.synchronize()

@@ -35,9 +35,7 @@ def main():
             ch = ctx.chain(hz.FMT_U8, fs).shift(-fs / 8).fir_decimate(taps, D)
             fn = lambda: ch.run(xu8, out[:n // D])
         elif w == "chain_fft":  # the same chain on the overlap-save transform kernels
-            os.environ["HZ_FIR_FFT"] = "1"
-            ch = ctx.chain(hz.FMT_U8, fs).shift(-fs / 8).fir_decimate(taps, D)
-            del os.environ["HZ_FIR_FFT"]
+            ch = ctx.chain(hz.FMT_U8, fs).shift(-fs / 8).fir_options(hz.FIR_IMPL_TRANSFORMS).fir_decimate(taps, D)
             fn = lambda: ch.run(xu8, out[:n // D])
         elif w == "chain_noshift":
             ch = ctx.chain(hz.FMT_U8, fs).fir_decimate(taps, D)

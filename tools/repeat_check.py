@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The north-star chain's two full-size calls (the second across the 2*pi wrap) R times over, every run
 compared bit for bit with a reference run: counts the runs that differ and says where (DESIGN.md section 4,
-"A hazard, and a known issue").  `python tools/repeat_check.py 150`; HZ_MM_ROLLED / HZ_MM_V1 select the kernel."""
+"A hazard, and a known issue").  `python tools/repeat_check.py 150`."""
 import importlib, sys, numpy as np
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
