@@ -762,7 +762,10 @@ constexpr int fir_occupancy(int n, int fold, bool late) {
 
 // EXP: ablation switches for tools/fir_ablate.hip (0 in the library): 1 = no input loads,
 // 2 = no filter loads, 4 = no output store, 8 = no pass-3 LDS reads, 16 = no pass-1/2 LDS
-// traffic.  Results are wrong by construction with any of them set.
+// traffic.  Results are wrong by construction with any of them set.  (Round 4, config 3's form -- c64, full backward
+// transform, D = 1 -- in that tool: 66 us of which input loads 7, filter loads 5, stores 9, the transforms alone 50;
+// tried and dropped, no gain either: the filter's bins asked for in front of the forward transform, and persistent
+// workgroups that keep the bins in registers from block to block -- 150 registers, one wave per SIMD less.)
 template <int N, int FMT, int FOLD, bool LATE, int EXP = 0>
 __global__ __launch_bounds__(fv::block(N), fir_occupancy(N, FOLD, LATE)) void fir_decimate_kernel16(
     const void *in, float2 *out, const float2 *__restrict__ hist, float2 *__restrict__ new_hist,
@@ -930,7 +933,7 @@ __global__ __launch_bounds__(fv::block(N), fir_occupancy(N, FOLD, LATE)) void fi
     {
         const cf *hl = (const cf *)hf + lane;
 #pragma unroll
-        for (int q = 0; q < 16; q++) v[q] = fv::cmul(v[q], hl[fv::edge_off<N, 16>(q)]);
+        for (int q = 0; q < 16; q++) v[q] = fv::cmul(v[q], (EXP & 2) ? cf{0.5f, 0.25f} : hl[fv::edge_off<N, 16>(q)]);
     }
     if constexpr (FOLD == 0) {
         fv::backward<N>(v, lds, tabs.bwd, lane);
@@ -944,6 +947,15 @@ __global__ __launch_bounds__(fv::block(N), fir_occupancy(N, FOLD, LATE)) void fi
                         if (p < n_in) out[p / D] = fv::to2(v[q]);
                     }
                 }
+            }
+        } else if (LATE && P.n == 0 && D == 1) {
+            // a late block of a chain WITHOUT elementwise stages at D = 1 (BASELINE config 3 as a FIR): nothing to
+            // mix and nothing to drop -- the kept outputs go from the backward transform's registers straight to
+            // memory (a wave stores 64 consecutive outputs per instruction), no fifth trip through the LDS
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const unsigned idx = fv::edge_index<N, R0>(q, lane);
+                if (idx >= off && idx < off + hop && !((EXP & 4) && v[q].x != 1234.5f)) out[b * hop + (idx - off)] = fv::to2(v[q]);
             }
         } else if constexpr (LATE) {
             // late block: the filtered block back to LDS, then the elementwise program over
