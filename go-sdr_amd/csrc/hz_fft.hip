@@ -311,6 +311,9 @@ __device__ __forceinline__ float2 big_twiddle(const BigTw &t, uint32_t m, bool i
     return w;
 }
 
+// (Round 4, tried: the forward pass's sixteen twiddles per lane from SEVEN table twiddles -- k1 = lane + q T, so
+// W^(n2 k1) = W^(n2 lane) (W^(4 n2 T))^a (W^(n2 T))^b, q = 4 a + b: 14 gathers instead of 32 -- 74.5 us against 72.9:
+// the gathers are not what the pass waits for; its 128-byte pieces at a power-of-two stride are.)
 template <int N1, bool FWD>
 __global__ __launch_bounds__(256) void fft2_cols_kernel(const float2 *__restrict__ in, float2 *__restrict__ a_out,
                                                         fv::FvTabs tabs, BigTw bt, uint32_t n2_total) {
