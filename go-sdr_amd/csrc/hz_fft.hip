@@ -313,7 +313,12 @@ __device__ __forceinline__ float2 big_twiddle(const BigTw &t, uint32_t m, bool i
 
 // (Round 4, tried: the forward pass's sixteen twiddles per lane from SEVEN table twiddles -- k1 = lane + q T, so
 // W^(n2 k1) = W^(n2 lane) (W^(4 n2 T))^a (W^(n2 T))^b, q = 4 a + b: 14 gathers instead of 32 -- 74.5 us against 72.9:
-// the gathers are not what the pass waits for; its 128-byte pieces at a power-of-two stride are.)
+// the gathers are not what the pass waits for; its 128-byte pieces at a power-of-two stride are.  Also tried, each
+// measured per 2^24 points at N = 2^16 (tools/fft_pairs.py over a rocprofv3 kernel trace): N1 = 16 with a lane per
+// column and no LDS (fully coalesced: the column pass 56.8 us -- but the row pass at N2 = 4096 then writes single
+// 8-byte elements at a 128-byte stride: 244 us); the scratch between the passes in tiles of 16 k1 x 16 n2 so that
+// both passes move 2 KB pieces (the column pass 84.5 us instead of 72.9: worse -- every workgroup's tiles of one
+// register slot then sit 32 KB apart and the slots of all workgroups hit the same channels together).)
 template <int N1, bool FWD>
 __global__ __launch_bounds__(256) void fft2_cols_kernel(const float2 *__restrict__ in, float2 *__restrict__ a_out,
                                                         fv::FvTabs tabs, BigTw bt, uint32_t n2_total) {
