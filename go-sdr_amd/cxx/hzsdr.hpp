@@ -107,6 +107,15 @@ struct Reader {
 };
 using ReaderPtr = std::shared_ptr<Reader>;
 
+// sdr.Writer (writer.go)
+struct Writer {
+    virtual ~Writer() = default;
+    virtual size_t Write(Samples s) = 0;
+    virtual int SampleFormat() const = 0;
+    virtual unsigned SampleRate() const = 0;
+};
+using WriterPtr = std::shared_ptr<Writer>;
+
 // sdr.ReadFull (reader.go:72-117).  Throws Eof with nothing read, Error(short) after a partial read.
 inline size_t ReadFull(Reader &r, Samples buf, size_t *partial = nullptr) {
     size_t n = 0;
@@ -191,6 +200,37 @@ inline ReaderPtr ConvertReader(const Context &x, ReaderPtr in, int to) {
     unsigned rate = in->SampleRate();
     return std::make_shared<ReadTransformer>(std::move(in), kBlock, kBlock, to, rate,
                                              [&x](Samples i, Samples o) { return x.ConvertBuffer(o, i); });
+}
+
+// stream.ConvertWriter (stream/convert.go:58-118): a Writer of `input_format` in front of `out`; every Write is
+// converted in chunks of 32 Ki samples into a buffer of out's format and handed on whole.  A Write of another format
+// throws ErrSampleFormatMismatch before anything is converted; "Conversion mismatch" if a chunk comes back short.
+class ConvWriter : public Writer {
+public:
+    ConvWriter(const Context &x, WriterPtr out, int input_format)
+        : x_(x), out_(std::move(out)), fmt_(input_format), buf_(out_->SampleFormat(), kBlock) {}
+    size_t Write(Samples in) override {
+        if (in.format != fmt_) throw Error(HZSDR_ERR_FORMAT_MISMATCH, hzsdr_strerror(HZSDR_ERR_FORMAT_MISMATCH));
+        size_t n = 0;
+        for (size_t i = 0; i < in.length; i += kBlock) {
+            const size_t ie = i + kBlock > in.length ? in.length : i + kBlock;
+            const size_t leng = x_.ConvertBuffer(buf_.view, in.slice(i, ie));
+            if (ie - i != leng) throw Error(-1, "ConvertWriter: Conversion mismatch");
+            n += out_->Write(buf_.view.slice(0, leng));
+        }
+        return n;
+    }
+    int SampleFormat() const override { return fmt_; }
+    unsigned SampleRate() const override { return out_->SampleRate(); }
+
+private:
+    const Context &x_;
+    WriterPtr out_;
+    int fmt_;
+    Buffer buf_;
+};
+inline WriterPtr ConvertWriter(const Context &x, WriterPtr out, int input_format) {
+    return std::make_shared<ConvWriter>(x, std::move(out), input_format);
 }
 
 // stream.DownsampleReader (stream/downsample.go:47-64)

@@ -82,6 +82,39 @@ int main() {
             EXPECT(!"no error");
         } catch (const Error &e) { EXPECT(e.status == HZSDR_ERR_FORMAT_MISMATCH); }
     }
+    {  // stream.ConvertWriter (stream/convert.go:58-118): c64 written in front of a u8 sink, 2 x 32 Ki + 5 samples
+       // (three chunks); every byte is the reference's truncating conversion (iq_c64.go:96-100)
+        struct Sink : Writer {
+            std::vector<uint8_t> got;
+            size_t calls = 0;
+            size_t Write(Samples s) override {
+                EXPECT(s.format == HZSDR_FMT_U8 && s.length <= 32 * 1024);
+                const uint8_t *p = (const uint8_t *)s.data;
+                got.insert(got.end(), p, p + 2 * s.length);
+                calls++;
+                return s.length;
+            }
+            int SampleFormat() const override { return HZSDR_FMT_U8; }
+            unsigned SampleRate() const override { return 1800000u; }
+        };
+        auto sink = std::make_shared<Sink>();
+        auto w = stream::ConvertWriter(ctx, sink, HZSDR_FMT_C64);
+        EXPECT(w->SampleFormat() == HZSDR_FMT_C64 && w->SampleRate() == 1800000u);
+        const size_t n = 2 * 32 * 1024 + 5;
+        std::vector<c64> in(n);
+        for (size_t i = 0; i < n; i++) in[i] = c64((float)((int)(i * 29 % 255) - 127) / 127.5f, (float)((int)(i * 31 % 255) - 127) / 127.5f);
+        EXPECT(w->Write(view(HZSDR_FMT_C64, in, 1)) == n);
+        EXPECT(sink->calls == 3 && sink->got.size() == 2 * n);
+        bool ok = true;
+        for (size_t i = 0; i < n && ok; i++)
+            ok = sink->got[2 * i] == (uint8_t)(int)(in[i].real() * 127.5f + 127.5f) && sink->got[2 * i + 1] == (uint8_t)(int)(in[i].imag() * 127.5f + 127.5f);
+        EXPECT(ok);
+        std::vector<int16_t> wrong(32);
+        try {
+            w->Write(view(HZSDR_FMT_I16, wrong, 2));
+            EXPECT(!"no error");
+        } catch (const Error &e) { EXPECT(e.status == HZSDR_ERR_FORMAT_MISMATCH); }
+    }
     {  // stream/downsample_test.go:59-93: i % 4 pattern, factor 4 -> exactly 1.5+1.5i
         const size_t n = 32 * 1024;
         std::vector<c64> in(n), out(n);
