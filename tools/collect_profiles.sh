@@ -4,7 +4,7 @@
 # (FETCH_SIZE / WRITE_SIZE in separate passes), SQ wave-state counters, big-FFT timings.
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02'
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/prof_$tag
 export TMPDIR=/tmp
 mkdir -p $out
@@ -26,6 +26,12 @@ python3 tools/pmc_sq.py $out/sq3 >> $out/sq_counters.txt
 tools/bin/mfma_fir > $out/mfma_fir.txt 2>&1
 tools/bin/mfma_fir2 > $out/mfma_fir2.txt 2>&1
 tools/bin/mfma_rate > $out/mfma_rate.txt 2>&1
+# round 4: the packed-float32 hazard (the instruction alone; the kernel patched and as the compiler left it), the MFMA's own wait states
+tools/bin/pk_glitch 200000 > $out/pk_glitch.txt 2>&1
+tools/bin/mm2_glitch 60000 2>&1 | cut -c1-600 > $out/mm2_glitch.txt
+tools/bin/mm2_glitch_unpatched 60000 2>&1 | cut -c1-600 > $out/mm2_glitch_unpatched_build.txt
+tools/bin/mfma_hazard 2000 > $out/mfma_hazard.txt 2>&1
+timeout 900 python3 tools/repeat_check.py 500 > $out/repeat_check.txt 2>&1
 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" > $out/firmm_probe.txt
 PROBE_IMPL=2 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" >> $out/firmm_probe.txt
 PROBE_IMPL=1 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" >> $out/firmm_probe.txt

@@ -153,9 +153,24 @@ __global__ __launch_bounds__(512) void glitch_kernel(Res *res, int iters, int pa
         } else if constexpr (T == 14) {
             asm volatile(PRE "v_pk_mul_f32 v[26:27], v[30:31], v[14:15] op_sel_hi:[1,0]\n" POST OPSX);
             wlo = s0 * f0, whi = s1 * f0;
-        } else {
+        } else if constexpr (T == 15) {
             asm volatile(PRE "v_pk_mul_f32 v[26:27], v[30:31], v[14:15] op_sel:[0,1]\n" POST OPSX);
             wlo = s0 * f1, whi = s1 * f1;
+        } else if constexpr (T == 16) {  // the packed MOVE: lo <- src0 half op_sel[0], hi <- src1 half op_sel[1]
+            asm volatile(PRE "v_pk_mov_b32 v[26:27], v[30:31], v[14:15] op_sel:[0,1]\n" POST OPSX);
+            wlo = s0, whi = f1;
+        } else if constexpr (T == 17) {  // packed float16 (VOP3P too): lo result from the HIGH half of src1's register
+            asm volatile(PRE "v_pk_add_f16 v26, v30, v14 op_sel:[0,1] op_sel_hi:[1,0]\n v_mov_b32 v27, v26\n" POST OPSX);
+            const unsigned a = __float_as_uint(s0), b = __float_as_uint(f0);
+            const _Float16 alo = __builtin_bit_cast(_Float16, (unsigned short)(a & 0xffff)), ahi = __builtin_bit_cast(_Float16, (unsigned short)(a >> 16));
+            const _Float16 blo = __builtin_bit_cast(_Float16, (unsigned short)(b & 0xffff)), bhi = __builtin_bit_cast(_Float16, (unsigned short)(b >> 16));
+            const _Float16 rlo = alo + bhi, rhi = ahi + blo;
+            const unsigned r = (unsigned)__builtin_bit_cast(unsigned short, rlo) | ((unsigned)__builtin_bit_cast(unsigned short, rhi) << 16);
+            wlo = whi = __uint_as_float(r);
+        } else {  // a 64-bit shift: a 64-bit VALU operand pair that is not a packed instruction
+            asm volatile(PRE "v_lshlrev_b64 v[26:27], 1, v[14:15]\n" POST OPSX);
+            const unsigned long long xx = ((unsigned long long)__float_as_uint(f1) << 32) | __float_as_uint(f0), yy = xx << 1;
+            wlo = __uint_as_float((unsigned)yy), whi = __uint_as_float((unsigned)(yy >> 32));
         }
         const unsigned ulo = __float_as_uint(lo), uhi = __float_as_uint(hi), up = __float_as_uint(poison);
         if (ulo != __float_as_uint(wlo)) {
@@ -189,9 +204,10 @@ __global__ __launch_bounds__(512) void glitch_kernel(Res *res, int iters, int pa
 static Res *g_res;
 
 template <int T> static void run_one(int partner, int iters) {
-    static const char *tn[16] = {"v_pk_mul_f32 op_sel", "v_pk_mul_f32", "v_pk_fma_f32", "v_pk_add_f32", "2 x v_mul_f32", "v_fma_f64", "v_pk_mul_f32 op_sel neg_lo",
+    static const char *tn[19] = {"v_pk_mul_f32 op_sel", "v_pk_mul_f32", "v_pk_fma_f32", "v_pk_add_f32", "2 x v_mul_f32", "v_fma_f64", "v_pk_mul_f32 op_sel neg_lo",
                                  "pk_mul op_sel:[1,0] hi:[0,1]", "pk_mul op_sel:[1,1] hi:[0,0]", "pk_mul op_sel:[0,0] hi:[0,0]", "pk_mul op_sel:[1,1] hi:[1,1]",
-                                 "pk_fma op_sel:[0,1,0] hi:[1,0,1]", "pk_add op_sel:[0,1] hi:[1,0]", "pk_fma op_sel:[0,0,1] hi:[1,1,0]", "pk_mul op_sel_hi:[1,0]", "pk_mul op_sel:[0,1]"};
+                                 "pk_fma op_sel:[0,1,0] hi:[1,0,1]", "pk_add op_sel:[0,1] hi:[1,0]", "pk_fma op_sel:[0,0,1] hi:[1,1,0]", "pk_mul op_sel_hi:[1,0]", "pk_mul op_sel:[0,1]",
+                                 "v_pk_mov_b32 op_sel:[0,1]", "v_pk_add_f16 op_sel:[0,1]", "v_lshlrev_b64"};
     static const char *pn[8] = {"idle", "MFMAs back to back", "sleep + 16 MFMAs", "sleep + 4 MFMAs", "sleep + landing + 16 MFMAs", "sleep + 1 MFMA", "sleep + 64 v_fma_f32", "sleep + 4 MFMA 16x16x64"};
     CK(hipMemset(g_res, 0, sizeof(Res)));
     auto k = glitch_kernel<T>;
@@ -237,5 +253,9 @@ int main(int argc, char **argv) {
     run_one<13>(3, iters);
     run_one<14>(3, iters);
     run_one<15>(3, iters);
+    // neighbours of the three instructions: the packed move, packed float16, a 64-bit operand that is not packed
+    run_one<16>(3, iters);
+    run_one<17>(3, iters);
+    run_one<18>(3, iters);
     return 0;
 }
