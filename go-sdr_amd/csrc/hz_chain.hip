@@ -212,6 +212,16 @@ static int conv_generic_device(hzsdr_ctx *ctx, void *dst, const void *src1, cons
     return fft_device(ctx, f1, dst, n, 1, false);
 }
 
+void nco_shift_ulp1_map4(hzsdr_ctx *ctx, void *buf, size_t nvec4, uint64_t base, double tau_shift, const NcoSegs &sg) {
+    EwProgram P{};
+    P.n = 1;
+    P.op[0].kind = EW_SHIFT;
+    P.op[0].tau_shift = tau_shift;
+    P.segs = sg;
+    hipLaunchKernelGGL((chain_map_kernel<HZSDR_FMT_C64, 4, SHAPE_SHIFT_ULP1>), dim3(blocks_for(ctx, nvec4)), dim3(kThreads), 0, ctx->stream,
+                       (const void *)buf, (float2 *)buf, nvec4, base, P);
+}
+
 template <int FMT>
 static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, const EwProgram &P, bool ulp1) {
     using R = typename Raw<FMT>::t;

@@ -143,4 +143,9 @@ int nco_plan(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, size_t n, NcoSegs
 int nco_shift_device(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, double shift_hz, void *buf,
                      size_t n, bool ulp1 = false);
 
+// hz_chain.hip: the <= 1-ulp Shift over four samples per lane (chain_map_kernel<c64, 4, SHAPE_SHIFT_ULP1>: four
+// interleaved factor chains, 32-byte loads) on `nvec4` groups of four samples at a 32-byte aligned `buf`, the
+// clock table `sg` counted from sample `base` of the call
+void nco_shift_ulp1_map4(hzsdr_ctx *ctx, void *buf, size_t nvec4, uint64_t base, double tau_shift, const NcoSegs &sg);
+
 }  // namespace hz

@@ -15,12 +15,14 @@ namespace hz {
 // ULP1 (hzsdr_nco_set_ulp1): the factor from the phase in turns and float32 polynomials (sincos_turns32,
 // hz_device.h) -- within one float32 ulp of the reference's factor, a third of the vector instructions; the
 // default is math.Sincos operation for operation (bit-identical to the oracle).
-template <bool ULP1>
+template <int ULP1>
 __device__ __forceinline__ float2 nco_rotate(float2 v, double ts, double tau_shift) {
     double ph = __dmul_rn(tau_shift, ts);  // stream/shifter.go:81, (tau*shift)*ts left to right
     if constexpr (ULP1) {
         float sf, cf;
-        sincos_turns32(turns32_wide(ph), sf, cf);  // (any phase: ts < 2 pi, but tau * shift is the caller's)
+        // (ULP1 = 1: |tau shift| 2 pi < 1e8 rad, where the plain product is good to a thirtieth of an ulp; 2: any
+        // phase the reference can form, by a double-double 1 / 2 pi -- three float64 instructions more)
+        sincos_turns32(ULP1 == 1 ? turns32(ph) : turns32_wide(ph), sf, cf);
         return go_cmul(v, make_float2(cf, sf));
     } else {
         double s, c;
@@ -35,7 +37,7 @@ __device__ __forceinline__ float2 nco_rotate(float2 v, double ts, double tau_shi
 // sat at 4.4 TB/s, latency-bound, not f64-bound).
 constexpr int kNcoUnroll = 4;
 
-template <bool ULP1>
+template <int ULP1>
 __global__ __launch_bounds__(kThreads) void nco_shift_vec_kernel(float4 *buf, uint64_t base,
                                                                  size_t nvec, double tau_shift,
                                                                  NcoSegs sg) {
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(kThreads) void nco_shift_vec_kernel(float4 *buf, ui
     }
 }
 
-template <bool ULP1>
+template <int ULP1>
 __global__ void nco_shift_scalar_kernel(float2 *buf, uint64_t base, size_t n, double tau_shift,
                                         NcoSegs sg) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -106,13 +108,25 @@ int nco_plan(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, size_t n, NcoSegs
 }
 
 // In-place shift of n samples at device pointer buf, advancing *ts.
-template <bool ULP1>
+template <int ULP1>
 static int nco_shift_launch(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, double shift_hz, void *buf, size_t n) {
     if (n == 0) return HZSDR_OK;
     NcoSegs sg;
     HZ_TRY(nco_plan(ctx, sample_rate, ts, n, &sg));
     const double tau_shift = (M_PI * 2) * shift_hz;  // tau * shift, one rounding (stream/shifter.go:81)
     float2 *q = (float2 *)buf;
+    if constexpr (ULP1 == 1) {
+        // the opt-in factor where the plain range reduction holds: four samples per lane on the chain's kernel
+        // (44-46 us per 2^24 samples against 51 with two per lane); what does not fit 32-byte groups one at a time
+        const size_t lead = std::min<size_t>(n, (32 - (uintptr_t)q % 32) % 32 / 8), nvec4 = (n - lead) / 4, rest = n - lead - 4 * nvec4;
+        if (lead)
+            hipLaunchKernelGGL(nco_shift_scalar_kernel<1>, dim3(1), dim3(64), 0, ctx->stream, q, (uint64_t)0, lead, tau_shift, sg);
+        if (nvec4) nco_shift_ulp1_map4(ctx, q + lead, nvec4, (uint64_t)lead, tau_shift, sg);
+        if (rest)
+            hipLaunchKernelGGL(nco_shift_scalar_kernel<1>, dim3(1), dim3(64), 0, ctx->stream, q + lead + 4 * nvec4, (uint64_t)(lead + 4 * nvec4), rest,
+                               tau_shift, sg);
+        return HZSDR_OK;
+    }
     size_t head = ((uintptr_t)q % 16) ? 1 : 0;
     size_t nvec = (n - head) / 2, tail = n - head - 2 * nvec;
     if (head)
@@ -127,8 +141,10 @@ static int nco_shift_launch(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, do
 }
 
 int nco_shift_device(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, double shift_hz, void *buf, size_t n, bool ulp1) {
-    return ulp1 ? nco_shift_launch<true>(ctx, sample_rate, ts, shift_hz, buf, n)
-                : nco_shift_launch<false>(ctx, sample_rate, ts, shift_hz, buf, n);
+    if (!ulp1) return nco_shift_launch<0>(ctx, sample_rate, ts, shift_hz, buf, n);
+    // (ts < 2 pi: the largest phase of the call is |2 pi shift| 2 pi)
+    return fabs((M_PI * 2) * shift_hz) * 6.2832 < 1.0e8 ? nco_shift_launch<1>(ctx, sample_rate, ts, shift_hz, buf, n)
+                                                         : nco_shift_launch<2>(ctx, sample_rate, ts, shift_hz, buf, n);
 }
 
 }  // namespace hz

@@ -411,6 +411,19 @@ def test_nco_shift_ulp1_is_within_one_ulp_of_the_factor_at_volume(hz, orc, rate,
     dd = got.view(np.float32).astype(np.float64) - want.view(np.float32).astype(np.float64)
     assert np.abs(dd).max() <= 1.5 * 2.0 ** -24, np.abs(dd).max() * 2.0 ** 24
     assert not bits_equal(got, want)  # (it really is the other kernel)
+    # a sample-aligned sub-slice (8-byte, not 32-byte aligned; a length that is not a multiple of four)
+    m = 100_003
+    want_s = np.ones(m, np.complex64)
+    ref.ts.value = t0
+    ref(shift, want_s)
+    nco.ts = t0
+    d = torch.from_numpy(x[:m + 1].copy()).cuda()
+    nco(shift, d[1:])
+    ctx.synchronize()
+    got_s = d.cpu().numpy()
+    assert got_s[0] == 1.0  # (the sample in front of the slice is not touched)
+    dd = got_s[1:].view(np.float32).astype(np.float64) - want_s.view(np.float32).astype(np.float64)
+    assert np.abs(dd).max() <= 1.5 * 2.0 ** -24
     nco.set_ulp1(False)
     nco.ts = t0
     d = torch.from_numpy(x).cuda()
