@@ -45,6 +45,82 @@ using mm::v4i;
 using mm::find_le;
 using mm::task_window;
 
+// The kernel's arguments as ONE struct (the kernarg segment's layout: the explicit arguments in order, each at its
+// natural alignment), for the RARE paths -- fix-up and history tasks, edge landings, the elementwise stages other
+// than the one Shift the planner marks.  Left to read the arguments the ordinary way, everything those paths derive
+// from them (pointers, comparisons, table addresses) is loop-invariant and the compiler hoists it to the kernel's
+// head and parks it in spilled scalar registers: 138 of the 621 instructions in front of the first barrier were
+// v_writelane, executed by every wave of every launch at the cold instruction cache's ~7 ns per instruction, for
+// paths most launches never take.  A rare path starts with HZ_COLD_ARGS instead: the kernarg pointer through an
+// empty asm (nothing derived from it can move above that line) and its own names for the arguments.
+struct KernArgs {
+    const void *in;
+    float2 *out;
+    const float2 *hist;
+    float2 *new_hist;
+    const uint8_t *rhist;
+    uint8_t *new_rhist;
+    const float2 *taps;
+    size_t n_in;
+    Geom G;
+    Plan L;
+    EwProgram P;
+    Fix F;
+    unsigned long long *stamps;
+};
+typedef const KernArgs __attribute__((address_space(4))) *KernArgsP;
+#define HZ_COLD_ARGS                                                                                                   \
+    KernArgsP ca_ = (KernArgsP)__builtin_amdgcn_kernarg_segment_ptr();                                                 \
+    asm volatile("" : "+s"(ca_));                                                                                      \
+    [[maybe_unused]] const void *const in = ca_->in;                                                                   \
+    [[maybe_unused]] float2 *const out = ca_->out;                                                                     \
+    [[maybe_unused]] const float2 *const hist = ca_->hist;                                                             \
+    [[maybe_unused]] float2 *const new_hist = ca_->new_hist;                                                           \
+    [[maybe_unused]] const uint8_t *const rhist = ca_->rhist;                                                          \
+    [[maybe_unused]] uint8_t *const new_rhist = ca_->new_rhist;                                                        \
+    [[maybe_unused]] const float2 *const taps = ca_->taps;                                                             \
+    [[maybe_unused]] const size_t n_in = ca_->n_in;                                                                    \
+    [[maybe_unused]] const Geom &G = *(const Geom *)&ca_->G;                                                           \
+    [[maybe_unused]] const Plan &L = *(const Plan *)&ca_->L;                                                           \
+    [[maybe_unused]] const EwProgram &P = *(const EwProgram *)&ca_->P;                                                 \
+    [[maybe_unused]] const Fix &F = *(const Fix *)&ca_->F
+
+// A Shift stage of a program with SEVERAL Shift stages (float64 phases, as hz_firmm.h), over a lane's outputs
+// m = mb + 32 kT b + a of a pass: OUT OF LINE.  Inlined, its two float64 Sincos put twenty-two polynomial constants
+// into vector registers at the kernel's head -- loop-invariant, so hoisted, for every wave of every launch -- for a
+// path that a chain with one Shift never takes.  `y` travels through memory (the caller copies: its own outputs
+// stay in registers).
+template <int D, int NB>
+__device__ __attribute__((noinline)) void other_shift_stage(float2 *y, double tau_shift, double step, double ts0, int l) {
+    double cs0, cc0, fs, fc;
+    sincos_late(__dmul_rn(tau_shift, ts0), cs0, cc0);
+    const double mult = l == 0 ? (double)D : (double)(32 * kT * D);
+    sincos_late(__dmul_rn(tau_shift, __dmul_rn(mult, step)), fs, fc);
+    const double e_s = __shfl(fs, 0), e_c = __shfl(fc, 0), b_s = __shfl(fs, 1), b_c = __shfl(fc, 1);
+    auto mul32 = [](float2 v, double c, double sn) {
+        const float cr = (float)c, ci = (float)sn;
+        return make_float2(__fmaf_rn(v.x, cr, -(v.y * ci)), __fmaf_rn(v.x, ci, v.y * cr));
+    };
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        double zc = cc0, zs = cs0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            y[4 * b + q] = mul32(y[4 * b + q], zc, zs);
+            if (q < 3) {
+                const double nc = __fma_rn(zc, e_c, -(zs * e_s)), ns = __fma_rn(zc, e_s, zs * e_c);
+                zc = nc;
+                zs = ns;
+            }
+        }
+        if (b + 1 < NB) {
+            const double nc = __fma_rn(cc0, b_c, -(cs0 * b_s)), ns = __fma_rn(cc0, b_s, cs0 * b_c);
+            cc0 = nc;
+            cs0 = ns;
+        }
+    }
+}
+
 // EXP (tools/mfma_fir2.hip; 0 in the library): 1 = no input loads, 2 = no matrix loop, 4 = no mixer,
 // 8 = no stores, 16 = no stagger, 32 = wave priorities (see the pass loop's end), 64 = stamps, 128 = no explicit vmcnt(0),
 // 256 = accumulator checksums per pass and lane, taken right behind the matrix loop and again behind the landing,
@@ -52,7 +128,8 @@ using mm::task_window;
 // which compute unit, stale read or wrong sum), 512 = the mixer's step factors read from LDS in one batch, waited for
 // (lgkmcnt(0) and eight wait states) and pinned before their first use, 1024 = the first step factor formed a second
 // time from a second, fully waited read and compared with the one the mixer used (records as for 256), 2048 = the
-// constant 0 as the first step's C operand instead of cleared accumulator registers.
+// constant 0 as the first step's C operand instead of cleared accumulator registers, 4096 = the rare paths read the
+// kernel arguments as the common path does (HZ_COLD_ARGS below switched off: round 3's code shape, for A/B).
 // NG: the window's groups (ks / GS) when the instantiation is for ONE tap count -- the matrix loop is then
 // straight-line code (a loop header drains the operand pipeline: the compiler cannot count outstanding
 // loads across a back edge); 0: any window, a loop over the groups.
@@ -150,18 +227,15 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     // call with more fix-up tasks than workgroups keeps the transform kernels (the host).
     // A HISTORY TASK = 64 samples of the next call's history, one wave (4-7) each.
     using RWT = typename Raw<FMT>::t;
-    const int n_hist_tasks = new_hist ? (int)((G.off + kHistPer - 1) / kHistPer) : 0;
-    float2 *const xs = reinterpret_cast<float2 *>(mm_lds + 2 * tab_lds + kCtlBytes + (size_t)kWaves * slot_sz);
-    float2 *const tl = xs + (G.ntaps + D * (kFixOut - 1));  // the taps, beside the window
     uint32_t fix_m0 = 0;
     int fix_cnt = 0;
-    bool tasks_done = false;
-    auto tasks_front = [&](int round) {  // round r: fix-up task wb + r grid
-        if (round == 0) {
-            if (tasks_done) return;
-            tasks_done = true;
-        }
-        if (wave < kWaves / 2) return;
+    bool tasks_backed = false;
+    // (the tasks' scratch in LDS behind the slots: the window's samples, the taps beside them)
+    auto task_xs = [&](const Geom &G) { return reinterpret_cast<float2 *>(mm_lds + 2 * table_lds(G.ne) + kCtlBytes + (size_t)kWaves * slot_bytes(D, G.ks)); };
+    auto tasks_front_cold = [&](int round, const void *in, const float2 *hist, float2 *new_hist, const uint8_t *rhist, uint8_t *new_rhist,
+                                const float2 *taps, size_t n_in, const Geom &G, const Plan &L, const EwProgram &P, const Fix &F) {
+        float2 *const xs = task_xs(G);
+        float2 *const tl = xs + (G.ntaps + D * (kFixOut - 1));
         const int ftask = wb + round * L.grid;
         if (ftask < L.n_task) {
             const int ct = tid - 64 * (kWaves / 2);  // 0 .. 255
@@ -192,11 +266,17 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                 }
             }
         }
-        if (round > 0) return;
-        // history tasks: behind the fix-up tasks in the workgroup order, young waves last to first
-        for (int t = wb + L.grid * (kWaves - 1 - wave); t < L.n_task + n_hist_tasks; t += (kWaves / 2) * L.grid) {  // (uniform per wave)
-            const int j = t - L.n_task;
-            if (j < 0) continue;
+    };
+    // A HISTORY TASK = 64 samples of the next call's history (the stages in reference order, and the raw samples): task
+    // j goes to workgroup j mod grid, one wave each, and it is the OLD waves that take them, BEHIND their last pass:
+    // waves 0-3 are through with their passes ~5 us before waves 4-7, who run the workgroup's last pass alone.  (Round
+    // 3 had wave 7 of the first sixteen workgroups do them in front of its first pass -- 5 us of exact Sincos that
+    // made those waves, and with them the launch, end 2 us late: tools/mfma_fir2.hip lists the workgroups that end
+    // last, and they were workgroups 3 and 11 on every box.)
+    auto history_tasks_cold = [&](const void *in, const float2 *hist, float2 *new_hist, const uint8_t *rhist, uint8_t *new_rhist, size_t n_in,
+                                  const Geom &G, const Plan &L, const EwProgram &P) {
+        const int n_hist_tasks = new_hist ? (int)((G.off + kHistPer - 1) / kHistPer) : 0;
+        for (int j = wb + L.grid * wave; j < n_hist_tasks; j += (kWaves / 2) * L.grid) {  // (uniform per wave)
             const unsigned idx = (unsigned)j * kHistPer + l;
             const int64_t h_lo = (int64_t)n_in - (int64_t)G.off + (int64_t)j * kHistPer;
             const NcoWin tw = task_window(P, h_lo, h_lo + kHistPer - 1);
@@ -207,8 +287,33 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
             }
         }
     };
-    auto tasks_back = [&]() {  // behind the barrier that follows tasks_front
-        if (wave < kWaves / 2 || fix_cnt == 0) return;
+    auto history_tasks = [&]() {
+        if (wave >= kWaves / 2 || new_hist == nullptr || wb + L.grid * wave >= (int)((G.off + kHistPer - 1) / kHistPer)) return;
+        if constexpr ((EXP & 4096) != 0) {
+            history_tasks_cold(in, hist, new_hist, rhist, new_rhist, n_in, G, L, P);
+        } else {
+            HZ_COLD_ARGS;
+            history_tasks_cold(in, hist, new_hist, rhist, new_rhist, n_in, G, L, P);
+        }
+    };
+    // Round r: workgroup wb takes fix-up task wb + r grid.  Round 0 is called ONCE, in front of the run groups, the
+    // further rounds of a call with more tasks than workgroups (short calls across many clock boundaries) BEHIND them
+    // -- never inside the groups' loop: what a call site inside a loop derives from loop-invariant values (the exact
+    // Sincos' twenty-two polynomial constants, for one) is hoisted to the loop's head, i.e. into every launch's first
+    // microseconds.
+    auto tasks_front = [&](int round) {
+        if (wave < kWaves / 2) return;
+        if (wb + round * L.grid >= L.n_task) return;  // (what most workgroups of most calls find)
+        if constexpr ((EXP & 4096) != 0) {
+            tasks_front_cold(round, in, hist, new_hist, rhist, new_rhist, taps, n_in, G, L, P, F);
+        } else {
+            HZ_COLD_ARGS;
+            tasks_front_cold(round, in, hist, new_hist, rhist, new_rhist, taps, n_in, G, L, P, F);
+        }
+    };
+    auto tasks_back_cold = [&](float2 *out, const Geom &G) {
+        float2 *const xs = task_xs(G);
+        float2 *const tl = xs + (G.ntaps + D * (kFixOut - 1));
         const int ct = tid - 64 * (kWaves / 2);
         const int o = ct >> 4, sl = ct & 15;  // output, tap slice: sixteen lanes per output
         // a lane's 64 (ntaps / 16) taps as two packed float32 fma chains -- the reference's own arithmetic is float32
@@ -233,6 +338,15 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         }
         if (o < fix_cnt && sl == 0) out[fix_m0 + o] = make_float2((float)ar, (float)ai);
         fix_cnt = 0;
+    };
+    auto tasks_back = [&]() {  // behind the barrier that follows tasks_front
+        if (wave < kWaves / 2 || fix_cnt == 0) return;
+        if constexpr ((EXP & 4096) != 0) {
+            tasks_back_cold(out, G);
+        } else {
+            HZ_COLD_ARGS;
+            tasks_back_cold(out, G);
+        }
     };
     stamp(9);
     auto put = [&](int q, v4i v) {
@@ -260,8 +374,9 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    auto land_edge = [&](uint32_t pass) {
-        const int64_t p0 = pass_p0(pass);
+    auto land_edge_cold = [&](uint32_t pass, const uint8_t *src, const uint8_t *rhist, int64_t n_bytes, const Geom &G, const Plan &L) {
+        const int64_t p0 = 2 * ((int64_t)D * ((int64_t)pass * kPassOut) - G.w0);
+        const int pieces = (int)(image_bytes(D, G.ks) / 16);
 #pragma unroll 1
         for (int q = l; q < pieces; q += 64) {
             const int64_t p = p0 + (int64_t)q * 16;
@@ -285,6 +400,14 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    };
+    auto land_edge = [&](uint32_t pass) {  // (the call's first and last passes)
+        if constexpr ((EXP & 4096) != 0) {
+            land_edge_cold(pass, src, rhist, n_bytes, G, L);
+        } else {
+            HZ_COLD_ARGS;
+            land_edge_cold(pass, (const uint8_t *)in, rhist, 2 * (int64_t)n_in, G, L);
+        }
     };
 
     // A fragments: lane n is row (a = n >> 3, c = (n >> 2) & 1, part = (n >> 1) & 1, pl = n & 1) = output
@@ -321,8 +444,10 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     // the elementwise program over a lane's outputs m = mb + 256 b + a of a pass in the run with phase line
     // (phi_r, dphi) / clock-table entry seg: equally spaced in two directions inside one exactly-linear clock run
     auto program = [&](float2(&y)[NB][4], uint32_t mb, uint64_t phi_r, uint64_t dphi, int seg, const float4 *wtab) {
-#pragma unroll 1
-        for (int oi = 0; oi < ((EXP & 4) ? 0 : L.n_ops); oi++) {  // uniform
+        // The other stages of a program -- Gain, Multiply, the Shifts of a program with several -- through the cold
+        // arguments (HZ_COLD_ARGS above): the stage's kind and parameters are read where they are used.  (Read the
+        // ordinary way they were five dependent scalar loads per pass in front of the marked Shift.)
+        auto other_stage = [&](int oi, int seg, const EwProgram &P) {
             const EwOp &o = P.op[oi];
             if (o.kind == EW_SCALE) {
 #pragma unroll
@@ -334,7 +459,33 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                 for (int b = 0; b < NB; b++)
 #pragma unroll
                     for (int q = 0; q < 4; q++) y[b][q] = go_cmul(y[b][q], make_float2(o.a, o.b));
-            } else if (L.shift_op == oi) {
+            } else {
+                // (programs with several Shift stages: out of line, other_shift_stage above)
+                const double step = P.segs.step[seg];
+                const int64_t dj = (int64_t)((uint64_t)D * mb) - (int64_t)P.segs.first[seg];
+                const double ts0 = __fma_rn((double)dj, step, P.segs.t0[seg]);
+                float2 t[4 * NB];
+#pragma unroll
+                for (int b = 0; b < NB; b++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) t[4 * b + q] = y[b][q];
+                other_shift_stage<D, NB>(t, o.tau_shift, step, ts0, l);
+#pragma unroll
+                for (int b = 0; b < NB; b++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) y[b][q] = t[4 * b + q];
+            }
+        };
+#pragma unroll 1
+        for (int oi = 0; oi < ((EXP & 4) ? 0 : L.n_ops); oi++) {  // uniform
+            if (L.shift_op != oi) {
+                if constexpr ((EXP & 4096) != 0) {
+                    other_stage(oi, seg, P);
+                } else {
+                    HZ_COLD_ARGS;
+                    other_stage(oi, seg, P);
+                }
+            } else {
                 // The stage's phase is a 64-bit accumulator in turns (exact increments, no float64).  ONE Sincos per
                 // lane, for its first output; the other seven are that factor turned on by the group's step factors
                 // exp(2 pi i (256 b + a) D dphi) -- double-float constants in LDS, two fma pairs and an add per
@@ -397,38 +548,6 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                         }
                     }
                 }
-            } else {
-                // (programs with several Shift stages: float64 phases, as hz_firmm.h)
-                const double step = P.segs.step[seg];
-                const int64_t dj = (int64_t)((uint64_t)D * mb) - (int64_t)P.segs.first[seg];
-                const double ts0 = __fma_rn((double)dj, step, P.segs.t0[seg]);
-                double cs0, cc0, fs, fc;
-                sincos_late(__dmul_rn(o.tau_shift, ts0), cs0, cc0);
-                const double mult = l == 0 ? (double)D : (double)(32 * kT * D);
-                sincos_late(__dmul_rn(o.tau_shift, __dmul_rn(mult, step)), fs, fc);
-                const double e_s = __shfl(fs, 0), e_c = __shfl(fc, 0), b_s = __shfl(fs, 1), b_c = __shfl(fc, 1);
-                auto mul32 = [](float2 v, double c, double sn) {
-                    const float cr = (float)c, ci = (float)sn;
-                    return make_float2(__fmaf_rn(v.x, cr, -(v.y * ci)), __fmaf_rn(v.x, ci, v.y * cr));
-                };
-#pragma unroll
-                for (int b = 0; b < NB; b++) {
-                    double zc = cc0, zs = cs0;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        y[b][q] = mul32(y[b][q], zc, zs);
-                        if (q < 3) {
-                            const double nc = __fma_rn(zc, e_c, -(zs * e_s)), ns = __fma_rn(zc, e_s, zs * e_c);
-                            zc = nc;
-                            zs = ns;
-                        }
-                    }
-                    if (b + 1 < NB) {
-                        const double nc = __fma_rn(cc0, b_c, -(cs0 * b_s)), ns = __fma_rn(cc0, b_s, cs0 * b_c);
-                        cc0 = nc;
-                        cs0 = ns;
-                    }
-                }
             }
         }
     };
@@ -449,6 +568,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     // group and the run B behind it are ONE queue (A's passes, B's passes); the next group slides on by one run (B
     // becomes A, its table stays) behind a barrier.
     auto has_passes = [&](int rr) { return rr < L.n && max(pb0, (uint32_t)L.pass_first[rr]) < min(pb1, (uint32_t)L.pass_end[rr]); };
+    tasks_front(0);
     int ra = 0;
     while (ra < L.n && !has_passes(ra)) ra++;
     Run ru = run0, rv = run0;
@@ -487,7 +607,6 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
             pre_issued = false;
         }
         if (first_stamp) stamp(13);
-        tasks_front(0);
         // (everything the queue reads from the kernel arguments by run, at once)
         // (run A of a later group is the previous group's run B: the lines stay in registers, one at a time is read)
         if (!first_seg) ru = rv;
@@ -523,12 +642,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         if (first_group) {  // (the first group of the workgroup: the small tasks)
             if constexpr ((EXP & 32) != 0) __builtin_amdgcn_s_setprio(3);
             tasks_back();
-            for (int round = 1; wb + round * L.grid < L.n_task; round++) {  // (uniform: calls with more tasks than workgroups)
-                __syncthreads();
-                tasks_front(round);
-                __syncthreads();
-                tasks_back();
-            }
+            tasks_backed = true;
             if constexpr ((EXP & 32) != 0) __builtin_amdgcn_s_setprio(1);
         }
         if constexpr ((EXP & 32) != 0) {
@@ -748,13 +862,17 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         a_done = true;
         if (!has_passes(ra + 1)) break;
     }
-    if (!tasks_done) {  // (a workgroup without a pass on the matrix path)
-        for (int round = 0; round == 0 || wb + round * L.grid < L.n_task; round++) {
-            if (round) __syncthreads();
-            tasks_front(round);
-            __syncthreads();
-            tasks_back();
-        }
+    history_tasks();
+    if (!tasks_backed) {  // (a workgroup without a pass on the matrix path: its task's sums)
+        __syncthreads();
+        tasks_back();
+    }
+#pragma unroll 1
+    for (int round = 1; wb + round * L.grid < L.n_task; round++) {  // (uniform: calls with more tasks than workgroups)
+        __syncthreads();
+        tasks_front(round);
+        __syncthreads();
+        tasks_back();
     }
     stamp(7);
 }

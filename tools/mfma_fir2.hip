@@ -223,7 +223,7 @@ int main(int argc, char **argv) {
     if (getenv("AB")) {  // A/B of the build's switches on one box, interleaved: EXP 0, 2048 (accumulator clears), 4 (no mixer)
         for (int r = 0; r < 3; r++) {
             run<0, 0>(in, out, taps, tab, n, ntaps, true);
-            run<2048, 0>(in, out, taps, tab, n, ntaps, true);
+            run<4096, 0>(in, out, taps, tab, n, ntaps, true);
             run<4, 0>(in, out, taps, tab, n, ntaps, true);
         }
         return 0;
