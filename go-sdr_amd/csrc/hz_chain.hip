@@ -222,6 +222,16 @@ void nco_shift_ulp1_map4(hzsdr_ctx *ctx, void *buf, size_t nvec4, uint64_t base,
                        (const void *)buf, (float2 *)buf, nvec4, base, P);
 }
 
+void nco_shift_exact_map2(hzsdr_ctx *ctx, void *buf, size_t nvec2, uint64_t base, double tau_shift, const NcoSegs &sg) {
+    EwProgram P{};
+    P.n = 1;
+    P.op[0].kind = EW_SHIFT;
+    P.op[0].tau_shift = tau_shift;
+    P.segs = sg;
+    hipLaunchKernelGGL((shift_exact_kernel<HZSDR_FMT_C64, false>), dim3(blocks_for(ctx, (nvec2 + kShiftU - 1) / kShiftU)), dim3(kThreads), 0, ctx->stream,
+                       (const void *)buf, (float4 *)buf, nvec2, base, P);
+}
+
 template <int FMT>
 static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, const EwProgram &P, bool ulp1) {
     using R = typename Raw<FMT>::t;
@@ -233,7 +243,16 @@ static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, cons
     const int shape = P.n == 1 && P.op[0].kind == EW_SHIFT ? SHAPE_SHIFT
                       : P.n == 2 && P.op[0].kind == EW_SHIFT && P.op[1].kind == EW_SCALE ? SHAPE_SHIFT_GAIN
                                                                                          : SHAPE_ANY;
-    if (ok(4) && n >= 4) {
+    if (!ulp1 && (shape == SHAPE_SHIFT || shape == SHAPE_SHIFT_GAIN) && ok(2) && n >= 2) {
+        // the bit-exact Shift (+ Gain): two samples per vector, the factor by sincos_narrow (shift_exact_kernel)
+        const size_t nvec = n / 2;
+        const dim3 grid(blocks_for(ctx, (nvec + kShiftU - 1) / kShiftU)), block(kThreads);
+        if (shape == SHAPE_SHIFT_GAIN)
+            hipLaunchKernelGGL((shift_exact_kernel<FMT, true>), grid, block, 0, ctx->stream, in, (float4 *)out, nvec, (uint64_t)0, P);
+        else
+            hipLaunchKernelGGL((shift_exact_kernel<FMT, false>), grid, block, 0, ctx->stream, in, (float4 *)out, nvec, (uint64_t)0, P);
+        done = nvec * 2;
+    } else if (ok(4) && n >= 4) {
         const size_t nvec = n / 4;
         const dim3 grid(blocks_for(ctx, nvec)), block(kThreads);
         if (shape == SHAPE_SHIFT_GAIN && ulp1)

@@ -273,6 +273,89 @@ __global__ __launch_bounds__(kThreads) void chain_map_kernel(const void *__restr
     }
 }
 
+// out[j] = Shift(convert(in[j])) (and Gain behind it, GAIN) -- BASELINE config 2, the ShiftReader / ShiftBuffer
+// map and hzsdr_nco_shift -- bit for bit as chain_map_kernel forms it from math.Sincos operation for operation,
+// at two thirds of its vector instructions (which bound it: 45 float64 instructions per sample there, 38 here,
+// and the quadrant logic in float32).  A lane holds U vectors of two samples; a tile that is ONE clock run whose
+// phases stay inside sincos_narrow's range takes the straight path: the clock by one exact fma from the lane's
+// run offset, the factor from sincos_narrow.  The vectors a lane cannot decide there (2^-18 of them), and every
+// vector of any other tile (a run boundary inside, the ragged last tile, tiny or huge phases, the long clock
+// table), go to the wave's queue in LDS -- their input is left where it is: the map may be in place -- and the
+// wave works the queue off behind the tile through ONE rolled copy of go_sincos.  (With go_sincos inline behind
+// each check the straight path lost more to the compiler's register and code layout than the check saves;
+// tools/nco_ablate.hip.)
+constexpr int kShiftU = 4;
+template <int FMT, bool GAIN>
+__global__ __launch_bounds__(kThreads) void shift_exact_kernel(const void *in, float4 *out, size_t nvec, uint64_t base, EwProgram P) {
+    using R = typename Raw<FMT>::t;
+    struct alignas(sizeof(R) * 2) RV { R v[2]; };
+    constexpr int U = kShiftU, kW = kThreads / 64;
+    __shared__ unsigned q_n[kW];
+    __shared__ unsigned short q[kW][64 * U];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) q_n[wave] = 0;
+    const double tau_shift = P.op[0].tau_shift;
+    const size_t tile = (size_t)kThreads * U;
+    for (size_t t0 = (size_t)blockIdx.x * tile; t0 < nvec; t0 += (size_t)gridDim.x * tile) {
+        const uint64_t j_lo = base + 2 * t0;
+        const NcoWin w = nco_window(P.segs, j_lo, j_lo + 2 * tile - 1);
+        const uint64_t d0 = j_lo - nco_first(P.segs, w.lo);
+        bool straight = w.lo == w.hi && P.segs.big_n == 0 && d0 + 2 * tile < (1ull << 32) && t0 + tile <= nvec;
+        double step = 0, tb = 0;
+        if (straight) {
+            step = P.segs.step[w.lo], tb = P.segs.t0[w.lo];
+            // the tile's phases: tau ts is monotonic in ts, ts in the sample; the smallest NONZERO one counts below
+            const double ts_lo = __fma_rn((double)(uint32_t)d0, step, tb), ts_1 = __fma_rn((double)((uint32_t)d0 + 1u), step, tb);
+            const double ts_hi = __fma_rn((double)((uint32_t)d0 + 2u * (uint32_t)tile - 1u), step, tb);
+            const double x_lo = fabs(__dmul_rn(tau_shift, ts_lo > 0.0 ? ts_lo : ts_1)), x_hi = fabs(__dmul_rn(tau_shift, ts_hi));
+            straight = ts_lo >= 0.0 && step > 0.0 && (x_lo >= 8.673617379884035e-19 || tau_shift == 0.0) && x_hi < 536870912.0;  // 2^-60, 2^29
+        }
+        if (__builtin_amdgcn_readfirstlane((int)straight)) {
+            RV a[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) a[u] = ((const RV *)in)[t0 + (size_t)u * kThreads + threadIdx.x];
+            const double k0 = (double)((uint32_t)d0 + 2u * threadIdx.x);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                float sl, cl, sh, ch;
+                const double kl = k0 + (double)(2 * u * kThreads), kh = k0 + (double)(2 * u * kThreads + 1);  // (exact)
+                bool ok = sincos_narrow(__dmul_rn(tau_shift, __fma_rn(kl, step, tb)), sl, cl);  // stream/shifter.go:81
+                ok &= sincos_narrow(__dmul_rn(tau_shift, __fma_rn(kh, step, tb)), sh, ch);
+                float2 l = go_cmul(Raw<FMT>::cvt(a[u].v[0]), make_float2(cl, sl));  // :82
+                float2 h = go_cmul(Raw<FMT>::cvt(a[u].v[1]), make_float2(ch, sh));
+                if constexpr (GAIN) {  // stream/gain.go:39-48
+                    l = make_float2(__fmul_rn(l.x, P.op[1].a), __fmul_rn(l.y, P.op[1].a));
+                    h = make_float2(__fmul_rn(h.x, P.op[1].a), __fmul_rn(h.y, P.op[1].a));
+                }
+                if (ok) out[t0 + (size_t)u * kThreads + threadIdx.x] = make_float4(l.x, l.y, h.x, h.y);
+                else q[wave][atomicAdd(&q_n[wave], 1u)] = (unsigned short)(u * kThreads + threadIdx.x);
+            }
+        } else {
+#pragma unroll 1
+            for (int u = 0; u < U; u++)
+                if (t0 + (size_t)u * kThreads + threadIdx.x < nvec) q[wave][atomicAdd(&q_n[wave], 1u)] = (unsigned short)(u * kThreads + threadIdx.x);
+        }
+        const unsigned nq = q_n[wave];  // (the LDS operations of one wave complete in order)
+        if (nq) {
+#pragma unroll 1
+            for (unsigned e = lane; e < nq; e += 64) {
+                const size_t i = t0 + q[wave][e];
+                const RV x = ((const RV *)in)[i];
+                float2 *const o2 = reinterpret_cast<float2 *>(out + i);
+#pragma unroll 1
+                for (int h = 0; h < 2; h++) {
+                    double sd, cd;
+                    go_sincos(__dmul_rn(tau_shift, nco_ts(P.segs, w, base + 2 * i + h)), sd, cd);
+                    float2 v = go_cmul(Raw<FMT>::cvt(h ? x.v[1] : x.v[0]), make_float2((float)cd, (float)sd));
+                    if constexpr (GAIN) v = make_float2(__fmul_rn(v.x, P.op[1].a), __fmul_rn(v.y, P.op[1].a));
+                    o2[h] = v;
+                }
+            }
+            if (lane == 0) q_n[wave] = 0;
+        }
+    }
+}
+
 // DecimateReader: 32 Ki-sample blocks, `per` = 32768 / factor outputs per block,
 // out[blk*per + i] = f(blk*32768 + i*factor)  (stream/decimate.go:34-101)
 template <int FMT>

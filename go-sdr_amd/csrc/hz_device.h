@@ -227,6 +227,52 @@ __device__ __forceinline__ void go_sincos(double x, double &sn, double &cs) {
     if (x == 0.0) sn = x;  // +-0 in, +-0 out (cs is already exactly 1)
 }
 
+// complex64(math.Sincos(x)) -- the float32 pair stream/shifter.go:82 narrows the float64 results to -- for
+// 2^-60 <= |x| < 2^29 or x = +-0, and whether that pair is CERTAIN to be math.Sincos' bit for bit.
+// The reduction is Go's own (j, z = ((|x| - y PI4A) - y PI4B) - y PI4C: y PI4A and y PI4B are exact products, so
+// the two fused steps round as Go's unfused ones do; the reduction is not relatively accurate near multiples of
+// pi/4 -- 6e-9 off the true sine there -- so a cheaper one cannot stand in for it); the two Cephes polynomials are
+// evaluated with fused Horner steps (16 float64 instructions where Go's unfused form has 28), which moves a result
+// by at most a few units in its last place: 2^-52 relative at worst over 2e8 arguments up to 2^29, random and
+// within 4 ulp of multiples of pi/4.  float32 drops mantissa bits 28..0 and rounds at their half point; a result
+// whose dropped bits lie more than 128 units (2^-46 .. 2^-45 of its value: 64 times the worst difference seen) from
+// that point narrows the same way as every float64 that close to it, math.Sincos' among them.  Elsewhere -- 2^-20
+// of the values -- the function returns false and the caller evaluates go_sincos.  The quadrant's exchange and
+// signs are applied to the float32 pair (exact either side of the narrowing).
+__device__ __forceinline__ bool sincos_narrow(double x, float &sn, float &cs) {
+    const double PI4A = 7.85398125648498535156e-1, PI4B = 3.77489470793079817668e-8, PI4C = 2.69515142907905952645e-15;
+    const double M4PI = 1.27323954473516268615107010698;
+    const double ax = fabs(x);
+    int32_t ji = __double2int_rz(__dmul_rn(ax, M4PI));
+    ji += ji & 1;
+    const double y = (double)ji;
+    double z = __fma_rn(-y, PI4A, ax);
+    z = __fma_rn(-y, PI4B, z);
+    z = __dsub_rn(z, __dmul_rn(y, PI4C));
+    const double zz = __dmul_rn(z, z);
+    double ps = __fma_rn(1.58962301576546568060e-10, zz, -2.50507477628578072866e-8);
+    ps = __fma_rn(ps, zz, 2.75573136213857245213e-6);
+    ps = __fma_rn(ps, zz, -1.98412698295895385996e-4);
+    ps = __fma_rn(ps, zz, 8.33333333332211858878e-3);
+    ps = __fma_rn(ps, zz, -1.66666666666666307295e-1);
+    const double s = __fma_rn(__dmul_rn(z, zz), ps, z);
+    double pc = __fma_rn(-1.13585365213876817300e-11, zz, 2.08757008419747316778e-9);
+    pc = __fma_rn(pc, zz, -2.75573141792967388112e-7);
+    pc = __fma_rn(pc, zz, 2.48015872888517045348e-5);
+    pc = __fma_rn(pc, zz, -1.38888888888730564116e-3);
+    pc = __fma_rn(pc, zz, 4.16666666666665929218e-2);
+    const double c = __fma_rn(__dmul_rn(zz, zz), pc, __fma_rn(-0.5, zz, 1.0));
+    const unsigned ds = ((unsigned)__double2loint(s) + (128u - 0x10000000u)) & 0x1FFFFFFFu;
+    const unsigned dc = ((unsigned)__double2loint(c) + (128u - 0x10000000u)) & 0x1FFFFFFFu;
+    const float sf = (float)s, cf = (float)c;
+    const bool swap = ji & 2;
+    const float a = swap ? cf : sf, b = swap ? sf : cf;
+    const unsigned t = (unsigned)ji << 29;  // bit 31 = quadrant bit 1, bit 30 = quadrant bit 0
+    sn = __uint_as_float(__float_as_uint(a) ^ (((unsigned)__double2hiint(x) ^ t) & 0x80000000u));
+    cs = __uint_as_float(__float_as_uint(b) ^ ((t ^ (t << 1)) & 0x80000000u));
+    return ds > 256u && dc > 256u;
+}
+
 // sin and cos of x, |x| < 2^30, for the LATE mixer (hz_chain_dev.h): the same Cephes kernels
 // as math.Sincos on the same float64 argument, but with a two-fma Cody-Waite reduction by
 // pi/2, fused Horner steps and branch-free quadrant logic -- a third of the issue slots of

@@ -146,6 +146,10 @@ int nco_shift_device(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, double sh
 // hz_chain.hip: the <= 1-ulp Shift over four samples per lane (chain_map_kernel<c64, 4, SHAPE_SHIFT_ULP1>: four
 // interleaved factor chains, 32-byte loads) on `nvec4` groups of four samples at a 32-byte aligned `buf`, the
 // clock table `sg` counted from sample `base` of the call
+// hz_chain.hip: the bit-exact Shift over `nvec2` vectors of two samples at a 16-byte aligned `buf`, in place
+// (shift_exact_kernel: the factor by sincos_narrow, go_sincos where that cannot tell), the clock table counted
+// from sample `base` of the call
+void nco_shift_exact_map2(hzsdr_ctx *ctx, void *buf, size_t nvec2, uint64_t base, double tau_shift, const NcoSegs &sg);
 void nco_shift_ulp1_map4(hzsdr_ctx *ctx, void *buf, size_t nvec4, uint64_t base, double tau_shift, const NcoSegs &sg);
 
 }  // namespace hz

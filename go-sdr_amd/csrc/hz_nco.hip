@@ -131,9 +131,13 @@ static int nco_shift_launch(hzsdr_ctx *ctx, uint64_t sample_rate, double *ts, do
     size_t nvec = (n - head) / 2, tail = n - head - 2 * nvec;
     if (head)
         hipLaunchKernelGGL(nco_shift_scalar_kernel<ULP1>, dim3(1), dim3(64), 0, ctx->stream, q, (uint64_t)0, head, tau_shift, sg);
-    if (nvec)
-        hipLaunchKernelGGL(nco_shift_vec_kernel<ULP1>, dim3(blocks_for(ctx, (nvec + kNcoUnroll - 1) / kNcoUnroll)), dim3(kThreads), 0,
-                           ctx->stream, (float4 *)(q + head), (uint64_t)head, nvec, tau_shift, sg);
+    if (nvec) {
+        if constexpr (ULP1 == 0)  // the reference's factor bit for bit: the straight path of shift_exact_kernel
+            nco_shift_exact_map2(ctx, q + head, nvec, (uint64_t)head, tau_shift, sg);
+        else
+            hipLaunchKernelGGL(nco_shift_vec_kernel<ULP1>, dim3(blocks_for(ctx, (nvec + kNcoUnroll - 1) / kNcoUnroll)), dim3(kThreads), 0,
+                               ctx->stream, (float4 *)(q + head), (uint64_t)head, nvec, tau_shift, sg);
+    }
     if (tail)
         hipLaunchKernelGGL(nco_shift_scalar_kernel<ULP1>, dim3(1), dim3(64), 0, ctx->stream,
                            q + head + 2 * nvec, (uint64_t)(head + 2 * nvec), tail, tau_shift, sg);

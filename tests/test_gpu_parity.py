@@ -384,6 +384,45 @@ def test_shift_bit_exact_at_volume(hz, orc):
     ctx.close()
 
 
+@pytest.mark.parametrize("rate,shift,t0,n", [
+    (20_000_000, 2.5e6, 0.0, 1 << 22),            # fs/8: half the factors have a component at the rounding noise of the phase
+    (20_000_000, -2.5e6, 2 * math.pi - 0.05, 1 << 22),  # across the 2 pi wrap: a burst of short clock runs
+    (20_000_000, 0.0, 1.0, 70_001),                # phase +0 throughout
+    (20_000_000, -0.0, 0.0, 70_001),               # phase -0: Sincos(-0) = (-0, 1)
+    (20_000_000, 1e-32, 0.0, 70_001),              # phases below 2^-60: float32 denormals, outside the straight path
+    (20_000_000, 3e-13, 0.0, 300_001),             # phases around 2^-60: tiles either side of the limit
+    (200_000_000, 95e6, 0.85, 300_001),            # phases crossing 2^29: tiles either side of the Payne-Hanek switch
+    (1000, 123.0, 0.0, 50_000),                    # a millisecond per sample
+    (2_400_000, 1e6 / 3, 0.0, (1 << 20) + 3)])
+def test_shift_straight_path_and_queue_bit_exact(hz, orc, rate, shift, t0, n):
+    """shift_exact_kernel: the factor from sincos_narrow where its check can tell, go_sincos through the wave's
+    queue elsewhere -- in place, at both alignments, bit for bit against the oracle's math.Sincos restatement;
+    inputs with signed zeros so that the sign of a zero factor component shows."""
+    import torch
+    x = rand_c64(31, n + 1)
+    x[5::7] = np.complex64(complex(-0.0, 0.0))
+    x[6::11] = np.complex64(complex(1.0, -0.0))
+    ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+    for off in (0, 1):  # 16-byte aligned, and a Go sub-slice starting one sample in
+        want = x[off:off + n].copy()
+        ref = orc.Shifter(rate)
+        ref.ts.value = t0
+        nco = ctx.nco(rate)
+        nco.ts = t0
+        d = torch.from_numpy(x.copy()).cuda()
+        cuts = [0, n // 2 + 1, n]
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            ref(shift, want[lo:hi])
+            nco(shift, d[off + lo:off + hi])
+            assert nco.ts == ref.ts.value
+        ctx.synchronize()
+        got = d.cpu().numpy()
+        assert bits_equal(got[off:off + n], want)
+        assert bits_equal(got[:off], x[:off]) and bits_equal(got[off + n:], x[off + n:])
+        nco.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("rate,shift,t0", [(20_000_000, 2.5e6, 3.25), (20_000_000, -7.3e6, 2 * math.pi - 0.5),
                                             (200_000_000, 95e6, 5.0)])
 def test_nco_shift_ulp1_is_within_one_ulp_of_the_factor_at_volume(hz, orc, rate, shift, t0):
