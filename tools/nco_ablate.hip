@@ -16,6 +16,15 @@
 
 using namespace hz;
 
+// the narrowing check with go_sincos inline behind it (the form that lost: see shift_exact_kernel's comment)
+__device__ __forceinline__ void go_sincos_f32(double x, float &sn, float &cs) {
+    if (!sincos_narrow(x, sn, cs) || !(fabs(x) < 536870912.0)) {
+        double s, c;
+        go_sincos(x, s, c);
+        sn = (float)s, cs = (float)c;
+    }
+}
+
 template <int SC> __device__ __forceinline__ float2 rot(float2 v, double ts, double tau_shift) {
     const double ph = __dmul_rn(tau_shift, ts);
     float s, c;
@@ -192,41 +201,7 @@ template <int MEM, int U, int TPB, int SLOW> static void run2(float4 *buf, size_
 // ---- the third cut: the narrowing check on the float64 BITS (the 29 mantissa bits float32 drops, against their half
 // point), a wave-private queue in LDS for the vectors a lane cannot decide, worked off behind the tile by one rolled
 // copy of go_sincos; tiles that are not one full clock run inside the straight range go to the queue whole
-__device__ __forceinline__ bool narrow_b(double x, float &sn, float &cs) {
-    const double PI4A = 7.85398125648498535156e-1, PI4B = 3.77489470793079817668e-8, PI4C = 2.69515142907905952645e-15;
-    const double M4PI = 1.27323954473516268615107010698;
-    const double ax = fabs(x);
-    int32_t ji = __double2int_rz(__dmul_rn(ax, M4PI));
-    ji += ji & 1;
-    const double y = (double)ji;
-    double z = __fma_rn(-y, PI4A, ax);
-    z = __fma_rn(-y, PI4B, z);
-    z = __dsub_rn(z, __dmul_rn(y, PI4C));
-    const double zz = __dmul_rn(z, z);
-    double ps = __fma_rn(1.58962301576546568060e-10, zz, -2.50507477628578072866e-8);
-    ps = __fma_rn(ps, zz, 2.75573136213857245213e-6);
-    ps = __fma_rn(ps, zz, -1.98412698295895385996e-4);
-    ps = __fma_rn(ps, zz, 8.33333333332211858878e-3);
-    ps = __fma_rn(ps, zz, -1.66666666666666307295e-1);
-    const double s = __fma_rn(__dmul_rn(z, zz), ps, z);
-    double pc = __fma_rn(-1.13585365213876817300e-11, zz, 2.08757008419747316778e-9);
-    pc = __fma_rn(pc, zz, -2.75573141792967388112e-7);
-    pc = __fma_rn(pc, zz, 2.48015872888517045348e-5);
-    pc = __fma_rn(pc, zz, -1.38888888888730564116e-3);
-    pc = __fma_rn(pc, zz, 4.16666666666665929218e-2);
-    const double c = __fma_rn(__dmul_rn(zz, zz), pc, __fma_rn(-0.5, zz, 1.0));
-    // float32 drops mantissa bits 28..0 and rounds at their half point 2^28: a value whose dropped bits are more than
-    // 128 units (2^-46 .. 2^-45 of the value) from the half point narrows the same way as anything that close to it
-    const unsigned ds = ((unsigned)__double2loint(s) + (128u - 0x10000000u)) & 0x1FFFFFFFu;
-    const unsigned dc = ((unsigned)__double2loint(c) + (128u - 0x10000000u)) & 0x1FFFFFFFu;
-    const float sf = (float)s, cf = (float)c;
-    const bool swap = ji & 2;
-    const float a = swap ? cf : sf, b = swap ? sf : cf;
-    const unsigned t = (unsigned)ji << 29;  // bit 31 = quadrant bit 1, bit 30 = quadrant bit 0
-    sn = __uint_as_float(__float_as_uint(a) ^ (((unsigned)__double2hiint(x) ^ t) & 0x80000000u));
-    cs = __uint_as_float(__float_as_uint(b) ^ ((t ^ (t << 1)) & 0x80000000u));
-    return ds > 256u && dc > 256u;
-}
+__device__ __forceinline__ bool narrow_b(double x, float &sn, float &cs) { return sincos_narrow(x, sn, cs); }
 
 template <int U, int TPB>
 __global__ __launch_bounds__(TPB) void k_shift3(float4 *buf, size_t nvec, uint64_t base, double tau_shift, NcoSegs sg) {
