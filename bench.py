@@ -444,16 +444,14 @@ def main():
         nco.set_ulp1()
         both("shift_c64_ulp1", lambda i: nco(2.5e6, cs[i % kRot]), 16)
         nco.close()
-        del cs[1:], outs[1:]
         # cfg 3: reference ConvolutionReader semantics, 1024 bins (16 B/sample)
         H = torch.from_numpy(np.fft.fft(np.asarray(taps, np.complex128) / ntaps).astype(np.complex64)).cuda()
-        _, ms = timed(torch, lambda: ctx.convolution_blocks(out, c, H), k, w)
-        extra["convolution_1024_circular"] = rate(n, float(np.median(ms)), 16)
+        both("convolution_1024_circular", lambda i: ctx.convolution_blocks(outs[i % kRot], cs[i % kRot], H), 16)
         # cfg 3, north-star form: 1024-tap FIR by overlap-save (N_fft 4096), no decimation
         chf = ctx.chain(hz.FMT_C64, fs).fir_decimate(taps, 1)
-        _, ms = timed(torch, lambda: chf.run(c, out), k, w)
-        extra["fir_1024_overlap_save_c64"] = rate(n, float(np.median(ms)), 16)
+        both("fir_1024_overlap_save_c64", lambda i: chf.run(cs[i % kRot], outs[i % kRot]), 16)
         chf.close()
+        del cs[1:], outs[1:]
         # cfg 4: Downsample by 8 from i16 (5 B/input sample)
         xi = torch.from_numpy(synth_i16(4, n)).cuda()
         o8 = torch.zeros(n // 8, dtype=torch.complex64, device="cuda")

@@ -247,8 +247,14 @@ static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, cons
         // the bit-exact Shift (+ Gain): two samples per vector, the factor by sincos_narrow (shift_exact_kernel)
         const size_t nvec = n / 2;
         const dim3 grid(blocks_for(ctx, (nvec + kShiftU - 1) / kShiftU)), block(kThreads);
-        if (shape == SHAPE_SHIFT_GAIN)
+        // (a call whose bytes exceed what the memory-side cache can hold streams past it: hz_vector.hip, beamform_kernel)
+        const bool nt = in != out && (sizeof(R) + 8) * n > ((size_t)192 << 20);
+        if (shape == SHAPE_SHIFT_GAIN && nt)
+            hipLaunchKernelGGL((shift_exact_kernel<FMT, true, true>), grid, block, 0, ctx->stream, in, (float4 *)out, nvec, (uint64_t)0, P);
+        else if (shape == SHAPE_SHIFT_GAIN)
             hipLaunchKernelGGL((shift_exact_kernel<FMT, true>), grid, block, 0, ctx->stream, in, (float4 *)out, nvec, (uint64_t)0, P);
+        else if (nt)
+            hipLaunchKernelGGL((shift_exact_kernel<FMT, false, true>), grid, block, 0, ctx->stream, in, (float4 *)out, nvec, (uint64_t)0, P);
         else
             hipLaunchKernelGGL((shift_exact_kernel<FMT, false>), grid, block, 0, ctx->stream, in, (float4 *)out, nvec, (uint64_t)0, P);
         done = nvec * 2;

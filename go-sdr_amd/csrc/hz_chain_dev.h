@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kThreads) void chain_map_kernel(const void *__restr
 // each check the straight path lost more to the compiler's register and code layout than the check saves;
 // tools/nco_ablate.hip.)
 constexpr int kShiftU = 4;
-template <int FMT, bool GAIN>
+template <int FMT, bool GAIN, bool NT = false>
 __global__ __launch_bounds__(kThreads) void shift_exact_kernel(const void *in, float4 *out, size_t nvec, uint64_t base, EwProgram P) {
     using R = typename Raw<FMT>::t;
     struct alignas(sizeof(R) * 2) RV { R v[2]; };
@@ -313,7 +313,10 @@ __global__ __launch_bounds__(kThreads) void shift_exact_kernel(const void *in, f
         if (__builtin_amdgcn_readfirstlane((int)straight)) {
             RV a[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) a[u] = ((const RV *)in)[t0 + (size_t)u * kThreads + threadIdx.x];
+            for (int u = 0; u < U; u++) {
+                const RV *const p = (const RV *)in + (t0 + (size_t)u * kThreads + threadIdx.x);
+                a[u] = NT ? nt_load(p) : *p;
+            }
             const double k0 = (double)((uint32_t)d0 + 2u * threadIdx.x);
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -327,8 +330,10 @@ __global__ __launch_bounds__(kThreads) void shift_exact_kernel(const void *in, f
                     l = make_float2(__fmul_rn(l.x, P.op[1].a), __fmul_rn(l.y, P.op[1].a));
                     h = make_float2(__fmul_rn(h.x, P.op[1].a), __fmul_rn(h.y, P.op[1].a));
                 }
-                if (ok) out[t0 + (size_t)u * kThreads + threadIdx.x] = make_float4(l.x, l.y, h.x, h.y);
-                else q[wave][atomicAdd(&q_n[wave], 1u)] = (unsigned short)(u * kThreads + threadIdx.x);
+                if (ok) {
+                    float4 *const p = out + (t0 + (size_t)u * kThreads + threadIdx.x);
+                    if (NT) nt_store(p, make_float4(l.x, l.y, h.x, h.y)); else *p = make_float4(l.x, l.y, h.x, h.y);
+                } else q[wave][atomicAdd(&q_n[wave], 1u)] = (unsigned short)(u * kThreads + threadIdx.x);
             }
         } else {
 #pragma unroll 1
@@ -727,7 +732,9 @@ __global__ __launch_bounds__(fv::block(N), conv_occupancy(N, STAGED)) void conv_
         // store phases of one block per workgroup left the memory pipes idle whenever the resident waves happened to
         // compute (4.3 TB/s -> 4.7).  (Loads return in order: the filter's bins, read behind the forward transform, wait
         // for the prefetch too -- it has the forward transform to arrive in.  Keeping the bins in registers across the
-        // blocks instead costs a wave per SIMD and was slower: 73 us against 57.)
+        // blocks instead costs a wave per SIMD and was slower: 73 us against 57.  Non-temporal loads and stores, for a
+        // call whose bytes exceed the memory-side cache: 67.8 us instead of 69.6 over a rotation of buffers, 67.6 instead
+        // of 56.5 over one pair -- not worth having.)
         using RT = typename Raw<FMT>::t;
         const size_t stride = (size_t)gridDim.x * XPB;
         size_t b = (size_t)blockIdx.x * XPB + sub;
