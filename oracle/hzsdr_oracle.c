@@ -490,6 +490,71 @@ void orc_go_sincos(double x, double *sn, double *cs) {
 /* stream.ShiftBuffer (stream/shifter.go:66-85)                        */
 /* ------------------------------------------------------------------ */
 
+/* A restatement of the device function sincos_narrow (go-sdr_amd/csrc/hz_device.h), for the CPU check of its claim:
+ * Go's range reduction (the first two steps fused: their products are exact), the Cephes polynomials with fused
+ * Horner steps, the narrowing decision on the float64 bits.  Returns 1 where the float32 pair is claimed to equal
+ * complex64(math.Sincos(x)).  Test infrastructure like everything here: tests/test_oracle.py compares it with
+ * orc_go_sincos over many arguments (orc_sincos_narrow_check below). */
+int orc_sincos_narrow(double x, float *sn, float *cs) {
+    const double PI4A = 7.85398125648498535156e-1, PI4B = 3.77489470793079817668e-8, PI4C = 2.69515142907905952645e-15;
+    const double M4PI = 1.27323954473516268615107010698;
+    const double ax = fabs(x);
+    int32_t ji = (int32_t)(ax * M4PI);
+    ji += ji & 1;
+    const double y = (double)ji;
+    double z = fma(-y, PI4A, ax);
+    z = fma(-y, PI4B, z);
+    z = z - y * PI4C;
+    const double zz = z * z;
+    double ps = fma(go_sin_c[0], zz, go_sin_c[1]);
+    ps = fma(ps, zz, go_sin_c[2]);
+    ps = fma(ps, zz, go_sin_c[3]);
+    ps = fma(ps, zz, go_sin_c[4]);
+    ps = fma(ps, zz, go_sin_c[5]);
+    const double s = fma(z * zz, ps, z);
+    double pc = fma(go_cos_c[0], zz, go_cos_c[1]);
+    pc = fma(pc, zz, go_cos_c[2]);
+    pc = fma(pc, zz, go_cos_c[3]);
+    pc = fma(pc, zz, go_cos_c[4]);
+    pc = fma(pc, zz, go_cos_c[5]);
+    const double c = fma(zz * zz, pc, fma(-0.5, zz, 1.0));
+    uint64_t sb, cb, xb;
+    memcpy(&sb, &s, 8);
+    memcpy(&cb, &c, 8);
+    memcpy(&xb, &x, 8);
+    const uint32_t ds = ((uint32_t)sb + (128u - 0x10000000u)) & 0x1FFFFFFFu;
+    const uint32_t dc = ((uint32_t)cb + (128u - 0x10000000u)) & 0x1FFFFFFFu;
+    const float sf = (float)s, cf = (float)c;
+    const int swap = ji & 2;
+    float a = swap ? cf : sf, b = swap ? sf : cf;
+    const uint32_t t = (uint32_t)ji << 29;
+    uint32_t ab, bb;
+    memcpy(&ab, &a, 4);
+    memcpy(&bb, &b, 4);
+    ab ^= ((uint32_t)(xb >> 32) ^ t) & 0x80000000u;
+    bb ^= (t ^ (t << 1)) & 0x80000000u;
+    memcpy(sn, &ab, 4);
+    memcpy(cs, &bb, 4);
+    return ds > 256u && dc > 256u;
+}
+
+/* Over xs[0..n): how many arguments the check accepts, and how many of THOSE differ from complex64(math.Sincos)
+ * in any bit (must be 0); the caller keeps |x| inside [2^-60, 2^29) or x = +-0, as the kernel does. */
+void orc_sincos_narrow_check(const double *xs, long n, long *accepted, long *wrong) {
+    long acc = 0, bad = 0;
+    for (long i = 0; i < n; i++) {
+        float sn, cs;
+        if (!orc_sincos_narrow(xs[i], &sn, &cs)) continue;
+        acc++;
+        double s, c;
+        orc_go_sincos(xs[i], &s, &c);
+        const float s32 = (float)s, c32 = (float)c;
+        if (memcmp(&s32, &sn, 4) != 0 || memcmp(&c32, &cs, 4) != 0) bad++;
+    }
+    *accepted = acc;
+    *wrong = bad;
+}
+
 /* The closure state `ts` persists across buffers: *ts is read and updated.
  * use_libm != 0 swaps math.Sincos for libm sincos (cross-check only). */
 void orc_shift(double *ts_state, unsigned long sample_rate, double freq_hz, float *buf, long n,

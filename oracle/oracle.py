@@ -147,6 +147,15 @@ def go_sincos(x):
     return s, c
 
 
+def sincos_narrow_check(xs):
+    """-> (accepted, wrong): arguments the restated sincos_narrow decides, and those of them whose float32 pair differs
+    from complex64(math.Sincos) (the device function's claim is that there are none)."""
+    xs = np.ascontiguousarray(xs, np.float64)
+    acc, bad = C.c_long(), C.c_long()
+    lib().orc_sincos_narrow_check(_p(xs), C.c_long(xs.size), C.byref(acc), C.byref(bad))
+    return acc.value, bad.value
+
+
 def go_mpi4():
     p = lib().orc_go_mpi4()
     return [int(p[i]) for i in range(20)]

@@ -295,6 +295,29 @@ def test_go_sincos_table_and_accuracy(orc):
     assert c0.tolist() == [1.0, 1.0] and np.signbit(s0).tolist() == [False, True]
 
 
+def test_sincos_narrow_never_accepts_a_pair_that_differs_from_math_sincos(orc):
+    """The straight path of shift_exact_kernel (csrc/hz_device.h sincos_narrow, restated in the oracle): wherever its
+    check on the float64 bits accepts, the float32 pair IS complex64(math.Sincos(x)) -- over random phases of every
+    size the path takes, the phases of the benchmark (multiples of pi/4 up to the phase's own rounding: half the
+    components are rounding noise), and the neighbours of multiples of pi/4 where Go's reduction is least accurate."""
+    rng = np.random.default_rng(5)
+    n = 3_000_000
+    sets = [rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(-17, 8.7, n)]
+    k = rng.integers(0, 680_000_000, n).astype(np.float64)
+    near = k * (np.pi / 4)
+    for _ in range(3):
+        near = np.where(rng.integers(0, 2, n) == 0, np.nextafter(near, np.inf), np.nextafter(near, -np.inf))
+    sets.append(np.where(rng.integers(0, 2, n) == 0, near, -near))
+    ts = np.arange(n, dtype=np.float64) * (1.0 / 20e6) + 3.0
+    sets.append(((np.pi * 2) * 2.5e6) * ts)
+    sets.append(np.array([0.0, -0.0, 2.0 ** -60, -(2.0 ** -60), np.nextafter(536870912.0, 0)]))
+    for xs in sets:
+        xs = xs[(np.abs(xs) < 536870912.0) & ((np.abs(xs) >= 2.0 ** -60) | (xs == 0))]
+        accepted, wrong = orc.sincos_narrow_check(xs)
+        assert wrong == 0
+        assert accepted >= xs.size * (1 - 2e-5) - 2  # the queue stays short: 2^-20 of the values per component
+
+
 def test_shift_roundtrip_kat(orc, kats):
     k = kats["shift_roundtrip"]
     cw = orc.cw(k["n"], k["freq"], k["rate"], 0.0)
