@@ -734,7 +734,9 @@ __global__ __launch_bounds__(fv::block(N), conv_occupancy(N, STAGED)) void conv_
         // for the prefetch too -- it has the forward transform to arrive in.  Keeping the bins in registers across the
         // blocks instead costs a wave per SIMD and was slower: 73 us against 57.  Non-temporal loads and stores, for a
         // call whose bytes exceed the memory-side cache: 67.8 us instead of 69.6 over a rotation of buffers, 67.6 instead
-        // of 56.5 over one pair -- not worth having.)
+        // of 56.5 over one pair -- not worth having.  The bins asked for in front of the prefetch, behind the forward
+        // transform, so that the product waits for L2 and not for HBM: 152 registers, three waves per SIMD, 57.3 / 70.1 us
+        // -- the same; with four waves it spills, 108 us.)
         using RT = typename Raw<FMT>::t;
         const size_t stride = (size_t)gridDim.x * XPB;
         size_t b = (size_t)blockIdx.x * XPB + sub;
