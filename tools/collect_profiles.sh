@@ -31,6 +31,12 @@ tools/bin/pk_glitch 200000 > $out/pk_glitch.txt 2>&1
 tools/bin/mm2_glitch 60000 2>&1 | cut -c1-600 > $out/mm2_glitch.txt
 tools/bin/mm2_glitch_unpatched 60000 2>&1 | cut -c1-600 > $out/mm2_glitch_unpatched_build.txt
 tools/bin/mfma_hazard 2000 > $out/mfma_hazard.txt 2>&1
+# round 4: config 2 -- the Shift map with its parts exchanged, what a copy reaches from the cache and from HBM, instruction costs
+tools/bin/nco_ablate > $out/nco_ablate.txt 2>&1
+tools/bin/copy_rate > $out/copy_rate.txt 2>&1
+tools/bin/issue_rate > $out/issue_rate.txt 2>&1
+python3 tools/conv_time.py 2>&1 | grep " us" > $out/conv_time.txt
+python3 tools/inplace_test.py 2>&1 | grep " us" > $out/shift_in_place.txt
 timeout 900 python3 tools/repeat_check.py 500 > $out/repeat_check.txt 2>&1
 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" > $out/firmm_probe.txt
 PROBE_IMPL=2 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" >> $out/firmm_probe.txt

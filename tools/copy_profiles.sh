@@ -13,5 +13,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   f=$(ls $d/*/*_counter_collection.csv | head -1)
   (head -1 $f; grep "hz::" $f) > profiles/${tag}_pmc_$c.csv
 done
-for t in sq_counters fir_ablate host_path mfma_fir mfma_fir2 mfma_rate firmm_probe pk_glitch mm2_glitch mm2_glitch_unpatched_build mfma_hazard repeat_check; do [ -f $src/$t.txt ] && cp $src/$t.txt profiles/${tag}_$t.txt; done
+for t in sq_counters fir_ablate host_path mfma_fir mfma_fir2 mfma_rate firmm_probe pk_glitch mm2_glitch mm2_glitch_unpatched_build mfma_hazard repeat_check nco_ablate copy_rate issue_rate conv_time shift_in_place; do [ -f $src/$t.txt ] && cp $src/$t.txt profiles/${tag}_$t.txt; done
 ls -la profiles/${tag}_*
