@@ -274,6 +274,9 @@ public:
     }
     int SampleFormat() const override { return r_->SampleFormat(); }
     unsigned SampleRate() const override { return r_->SampleRate(); }
+    // hzsdr_nco_set_ulp1 (go/hip/stream.go Shifter.SetULP1): the factor within one float32 ulp of the reference's
+    // instead of bit-identical to it; off by default
+    void SetULP1(bool on) { check(x_.raw(), hzsdr_nco_set_ulp1(nco_, on ? 1 : 0)); }
 
 private:
     const Context &x_;
@@ -281,7 +284,7 @@ private:
     double shift_;
     hzsdr_nco *nco_ = nullptr;
 };
-inline ReaderPtr ShiftReader(const Context &x, ReaderPtr r, double shift_hz) {
+inline std::shared_ptr<ShiftReaderImpl> ShiftReader(const Context &x, ReaderPtr r, double shift_hz) {
     return std::make_shared<ShiftReaderImpl>(x, std::move(r), shift_hz);
 }
 

@@ -151,6 +151,24 @@ int main() {
                  std::fabs((1 + cw[i].imag()) - (1 + buf[i].imag())) <= 1e-4 * std::fabs(1 + cw[i].imag()) + 1e-7;
         EXPECT(ok);
     }
+    {  // the same round trip with the opt-in <= 1-ulp factor on both readers (Shifter.SetULP1 of the Go package)
+        const size_t n = 1024 * 60;
+        std::vector<c64> cw(n), buf(n);
+        for (size_t i = 0; i < n; i++) {
+            double now = double(i) / 1.8e6;
+            cw[i] = c64((float)std::cos(2 * M_PI * now), (float)std::sin(2 * M_PI * now));
+        }
+        auto src = std::make_shared<BufferReader>(view(HZSDR_FMT_C64, cw, 1), 1800000u, 7000);
+        auto up = stream::ShiftReader(ctx, src, 1000.0);
+        up->SetULP1(true);
+        auto down = stream::ShiftReader(ctx, up, -1000.0);
+        down->SetULP1(true);
+        EXPECT(ReadFull(*down, view(HZSDR_FMT_C64, buf, 1)) == n);
+        bool ok = true;
+        for (size_t i = 0; i < n && ok; i++)
+            ok = std::fabs(cw[i].real() - buf[i].real()) <= 1e-4 && std::fabs(cw[i].imag() - buf[i].imag()) <= 1e-4;
+        EXPECT(ok);
+    }
     {  // stream/multiply_test.go:36-69 TestRotate: CW(phase pi/2) * (0-1i) == CW(phase 0)
         const size_t n = 1024 * 60;
         std::vector<c64> cw0(n), cw90(n), buf(n);
