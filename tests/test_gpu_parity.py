@@ -423,6 +423,39 @@ def test_shift_straight_path_and_queue_bit_exact(hz, orc, rate, shift, t0, n):
     ctx.close()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_shift_random_rates_shifts_and_clocks_bit_exact(hz, orc, seed):
+    """Eight random (sample rate, shift, clock start, length, alignment) per seed against the oracle, bit for bit:
+    rates 1 kHz .. 1 GHz, shifts up to the rate and beyond, clocks anywhere in [0, 2 pi) (and, rarely, set far
+    outside by hand), buffers cut in two calls at a random sample."""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+    for case in range(8):
+        rate = int(10.0 ** rng.uniform(3, 9))
+        shift = float(rng.uniform(-1.2, 1.2) * rate) if rng.integers(0, 4) else float(10.0 ** rng.uniform(-6, 9.5) * rng.choice([-1, 1]))
+        t0 = float(rng.uniform(0, 2 * math.pi)) if rng.integers(0, 8) else float(10.0 ** rng.uniform(-12, 6))
+        n = int(rng.integers(1, 400_000))
+        off = int(rng.integers(0, 2))
+        cut = int(rng.integers(0, n + 1))
+        x = rand_c64(100 * seed + case, n + off)
+        want = x[off:].copy()
+        ref = orc.Shifter(rate)
+        ref.ts.value = t0
+        nco = ctx.nco(rate)
+        nco.ts = t0
+        d = torch.from_numpy(x.copy()).cuda()
+        for lo, hi in ((0, cut), (cut, n)):
+            if hi > lo:
+                ref(shift, want[lo:hi])
+                nco(shift, d[off + lo:off + hi])
+        ctx.synchronize()
+        assert nco.ts == ref.ts.value, (rate, shift, t0, n, off, cut)
+        assert bits_equal(d.cpu().numpy()[off:], want), (rate, shift, t0, n, off, cut)
+        nco.close()
+    ctx.close()
+
+
 @pytest.mark.parametrize("rate,shift,t0", [(20_000_000, 2.5e6, 3.25), (20_000_000, -7.3e6, 2 * math.pi - 0.5),
                                             (200_000_000, 95e6, 5.0)])
 def test_nco_shift_ulp1_is_within_one_ulp_of_the_factor_at_volume(hz, orc, rate, shift, t0):

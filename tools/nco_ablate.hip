@@ -1,7 +1,7 @@
 // nco_ablate.hip -- times the Shift map (csrc/hz_nco.hip: nco_shift_vec_kernel, BASELINE config 2) with its parts
 // exchanged or switched off: which Sincos, with or without the loads / the stores, how many 16-byte vectors a lane
 // keeps in flight.  One clock run (ts = k / fs), 2^24 samples in place; the values are not checked here.
-//   SC 0 = go_sincos_f32 (narrowing check + fallback), 1 = go_sincos (math.Sincos operation for operation),
+//   SC 0 = sincos_narrow with go_sincos inline behind it, 1 = go_sincos (math.Sincos operation for operation),
 //      2 = sincos_late unchecked, 3 = no Sincos (factor from the clock's bits), 4 = check only, no fallback code
 //   MEM 0 = loads and stores, 1 = no loads, 2 = no stores, 3 = neither
 #include <stdio.h>
@@ -317,25 +317,25 @@ int main() {
     float4 *buf;
     CK(hipMalloc(&buf, n * 8));
     CK(hipMemset(buf, 0, n * 8));
-    run<0, 0, 4, 256>(buf, nvec, 0, "checked, as shipped");
+    run<0, 0, 4, 256>(buf, nvec, 0, "narrow, go_sincos inline");
     run<1, 0, 4, 256>(buf, nvec, 0, "math.Sincos op for op");
     run<2, 0, 4, 256>(buf, nvec, 0, "late, unchecked");
     run<4, 0, 4, 256>(buf, nvec, 0, "check, no fallback code");
     run<3, 0, 4, 256>(buf, nvec, 0, "no Sincos");
-    run<0, 3, 4, 256>(buf, nvec, 0, "checked, no memory");
+    run<0, 3, 4, 256>(buf, nvec, 0, "narrow inline, no memory");
     run<1, 3, 4, 256>(buf, nvec, 0, "op for op, no memory");
     run<2, 3, 4, 256>(buf, nvec, 0, "late, no memory");
     run<3, 3, 4, 256>(buf, nvec, 0, "no Sincos, no memory");
-    run<0, 1, 4, 256>(buf, nvec, 0, "checked, no loads");
-    run<0, 2, 4, 256>(buf, nvec, 0, "checked, no stores");
-    run<0, 0, 2, 256>(buf, nvec, 0, "checked U 2");
-    run<0, 0, 8, 256>(buf, nvec, 0, "checked U 8");
-    run<0, 0, 1, 256>(buf, nvec, 0, "checked U 1");
-    run<0, 0, 4, 256>(buf, nvec, 8, "checked, 2048 workgroups");
-    run<0, 0, 4, 256>(buf, nvec, 16, "checked, 4096 workgroups");
-    run<0, 0, 2, 256>(buf, nvec, 16, "checked U 2, 4096 workgroups");
-    run<0, 0, 4, 128>(buf, nvec, 0, "checked, 128 threads");
-    run<0, 0, 4, 512>(buf, nvec, 0, "checked, 512 threads");
+    run<0, 1, 4, 256>(buf, nvec, 0, "narrow inline, no loads");
+    run<0, 2, 4, 256>(buf, nvec, 0, "narrow inline, no stores");
+    run<0, 0, 2, 256>(buf, nvec, 0, "narrow inline U 2");
+    run<0, 0, 8, 256>(buf, nvec, 0, "narrow inline U 8");
+    run<0, 0, 1, 256>(buf, nvec, 0, "narrow inline U 1");
+    run<0, 0, 4, 256>(buf, nvec, 8, "narrow inline, 2048 workgroups");
+    run<0, 0, 4, 256>(buf, nvec, 16, "narrow inline, 4096 workgroups");
+    run<0, 0, 2, 256>(buf, nvec, 16, "narrow inline U 2, 4096 wgs");
+    run<0, 0, 4, 128>(buf, nvec, 0, "narrow inline, 128 threads");
+    run<0, 0, 4, 512>(buf, nvec, 0, "narrow inline, 512 threads");
     run2<0, 4, 256, 1>(buf, nvec, 0, "second cut");
     run2<0, 4, 256, 0>(buf, nvec, 0, "no slow code");
     run2<0, 4, 256, 2>(buf, nvec, 0, "slow code = late");
