@@ -857,7 +857,10 @@ constexpr int fir_occupancy(int n, int fold, bool late) {
 // traffic.  Results are wrong by construction with any of them set.  (Round 4, config 3's form -- c64, full backward
 // transform, D = 1 -- in that tool: 66 us of which input loads 7, filter loads 5, stores 9, the transforms alone 50;
 // tried and dropped, no gain either: the filter's bins asked for in front of the forward transform, and persistent
-// workgroups that keep the bins in registers from block to block -- 150 registers, one wave per SIMD less.)
+// workgroups that keep the bins in registers from block to block -- 150 registers, one wave per SIMD less; and
+// workgroups that WALK consecutive blocks with the next block's samples in flight under the transforms, the N - hop
+// samples two blocks share passed on in registers (12 loads per lane and block instead of 16, read amplification 1.0):
+// 73.3 us over one buffer pair and 88.7 over a rotation against 71.6-75.5 and 89-97 -- the input is not what it waits for.)
 template <int N, int FMT, int FOLD, bool LATE, int EXP = 0>
 __global__ __launch_bounds__(fv::block(N), fir_occupancy(N, FOLD, LATE)) void fir_decimate_kernel16(
     const void *in, float2 *out, const float2 *__restrict__ hist, float2 *__restrict__ new_hist,
