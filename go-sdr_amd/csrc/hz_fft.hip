@@ -318,7 +318,9 @@ __device__ __forceinline__ float2 big_twiddle(const BigTw &t, uint32_t m, bool i
 // column and no LDS (fully coalesced: the column pass 56.8 us -- but the row pass at N2 = 4096 then writes single
 // 8-byte elements at a 128-byte stride: 244 us); the scratch between the passes in tiles of 16 k1 x 16 n2 so that
 // both passes move 2 KB pieces (the column pass 84.5 us instead of 72.9: worse -- every workgroup's tiles of one
-// register slot then sit 32 KB apart and the slots of all workgroups hit the same channels together).)
+// register slot then sit 32 KB apart and the slots of all workgroups hit the same channels together); two adjacent
+// columns per lane, 16-byte loads and stores, 256-byte pieces, the two transforms one behind the other through the
+// same LDS (tools/fftbig_time.py: 120.8 us for both passes against 111.3 -- worse as well).)
 template <int N1, bool FWD>
 __global__ __launch_bounds__(256) void fft2_cols_kernel(const float2 *__restrict__ in, float2 *__restrict__ a_out,
                                                         fv::FvTabs tabs, BigTw bt, uint32_t n2_total) {
