@@ -1,4 +1,6 @@
-// hz_chain.hip -- fused operator chains and the FFT-convolution kernels.
+// hz_chain.hip -- fused operator chains: the chain API, the elementwise stages and the streaming terminals (the
+// FIR-decimate terminal lives in hz_chain_fir.hip, the convolution launches in hz_conv.hip, the pinned ring in
+// hz_ring.hip; hz_chain_host.h holds what they share).
 //
 // A chain is nested stream.* Readers collapsed into one launch per buffer:
 // the "source functor" converts a raw input sample to complex64 and applies the
@@ -15,202 +17,9 @@
 //
 // Every variant is one kernel on the context's stream; nothing is written to
 // HBM between stages.
-#include <math.h>
-
-#include <algorithm>
-
-#include "hz_chain_dev.h"
-#include "hz_firmm.h"
-#include "hz_firmm2.h"
-#include "hz_fft_api.h"
-
-// =============================================================================
-
-enum ChainTerm { TERM_NONE = 0, TERM_DECIMATE, TERM_DOWNSAMPLE, TERM_CONV, TERM_FIR };
-
-struct hzsdr_chain {
-    hzsdr_ctx *ctx;
-    int src_fmt;
-    uint64_t sample_rate;
-    // elementwise stages
-    int n_ops = 0;
-    hz::EwOp ops[hz::kMaxEw];
-    bool has_shift = false;
-    double ts = 0.0;  // the shared NCO clock
-    // terminal
-    int term = TERM_NONE;
-    unsigned factor = 1;
-    // convolution
-    void *filt = nullptr;  // device, flen bins
-    size_t flen = 0;
-    // fir-decimate
-    void *hfreq = nullptr;  // device, nfft bins (FFT(taps)/nfft)
-    void *hfreq_late = nullptr;  // the same times late_scale() (chains without a Shift; see late_scale)
-    void *hist[2] = {nullptr, nullptr};
-    int hist_cur = 0;
-    size_t ntaps = 0;
-    unsigned nfft = 0, hop = 0, off = 0;
-    // late mixer (see fir_decimate_kernel16): the taps, and FFT(taps * exp(-i*Omega*k*step))/N
-    // per distinct clock step seen so far (one per binade of the NCO clock)
-    std::vector<double> taps_host;  // (re, im) pairs, exact copies of the caller's float32 taps
-    std::map<uint64_t, void *> late_cache;
-    bool mix_in_order = false;
-    bool shift_ulp1 = false;  // hzsdr_chain_shift_ulp1
-    bool poly = false;  // hfreq / late_cache hold the polyphase layout (fold_poly)
-    // int8 matrix form (hz_firmm.h): geometry, the taps on the device (fix-up workgroups) and
-    // one digit table per distinct clock step (key 0: no Shift stage)
-    bool mm_ok = false;
-    int mm_ver = 1;  // 1: hz_firmm.h (one round of chunk workgroups), 2: hz_firmm2.h (persistent passes; D = 8)
-    hz::mm::Geom mmg{};
-    void *taps_dev = nullptr;
-    std::map<uint64_t, void *> mm_cache;
-    // the last `off` RAW samples of the previous call (two buffers, flipped with hist[]): valid
-    // after a call on the matrix path; rh_step / rh_len describe the clock run they end in
-    void *rhist[2] = {nullptr, nullptr};
-    bool rh_valid = false;
-    double rh_step = 0.0, rh_next = 0.0;
-    uint64_t rh_len = 0;
-    bool debug_mm = false;  // HZ_DEBUG_MM (diag_env)
-    // hzsdr_chain_fir_options: which implementation the FIR-decimate terminal takes (0: the library chooses),
-    // the smallest overlap-save block, the matrix loop's form -- A/B measurements and tests
-    int fir_impl = HZSDR_FIR_IMPL_AUTO;
-    unsigned fir_nfft_min = 0;
-    int fir_loop_form = 0;
-    int last_path = HZSDR_FIR_PATH_NONE;
-};
-
-struct hzsdr_conv {
-    hzsdr_ctx *ctx;
-    int kind;  // 0 = ConvolveFreq, 1 = Convolve, 2 = CrossCorrelate
-    void *dst;
-    const void *src1, *src2;
-    size_t n;
-    void *filt;  // device copy of the frequency-domain filter (kind 0)
-};
+#include "hz_chain_host.h"
 
 namespace hz {
-
-// The diagnostic environment switches (README.md), read ONCE per process -- getenv is not safe against a
-// concurrent setenv, and a chain's behaviour must not depend on what the environment holds at the moment a stage is
-// added -- and only in a library built with -DHZSDR_DIAG (csrc/Makefile: DIAG=1).  Programs select an
-// implementation per chain with hzsdr_chain_fir_options instead.
-struct DiagEnv {
-    bool fir_fft = false, mm_v1 = false, no_slow_first = false, debug_late = false, debug_mm = false;
-    unsigned nfft_min = 0;
-    int rolled = 0;
-};
-static const DiagEnv &diag_env() {
-    static const DiagEnv e = [] {
-        DiagEnv d;
-#ifdef HZSDR_DIAG
-        d.fir_fft = getenv("HZ_FIR_FFT") != nullptr;
-        d.mm_v1 = getenv("HZ_MM_V1") != nullptr;
-        d.no_slow_first = getenv("HZ_NO_SLOW_FIRST") != nullptr;
-        d.debug_late = getenv("HZ_DEBUG_LATE") != nullptr;
-        d.debug_mm = getenv("HZ_DEBUG_MM") != nullptr;
-        if (const char *v = getenv("HZ_FIR_NFFT_MIN")) d.nfft_min = (unsigned)atoi(v);
-        if (const char *v = getenv("HZ_MM_ROLLED")) d.rolled = atoi(v);
-#endif
-        return d;
-    }();
-    return e;
-}
-
-// Launch with `lds` bytes of dynamic LDS; above the 64 KiB default a kernel needs its limit
-// raised once (160 KiB per CU on gfx950).
-template <class K, class... A>
-static void launch_fv(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, A... args) {
-    // (a failure here makes the launch below fail, which the stage's hipGetLastError reports)
-    if (lds > 48 * 1024) (void)raise_dynamic_lds((const void *)kernel);
-    hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
-}
-
-template <int N, int FMT>
-static void launch_conv_n(hzsdr_ctx *ctx, const void *in, void *out, const void *filt, const float2 *tw,
-                          const FvTabs &tabs, size_t nblocks, unsigned dec, size_t per, const EwProgram &P) {
-    const bool direct = FMT == HZSDR_FMT_C64 && P.n == 0;
-    if constexpr (fv::ok(N)) {  // packed-math core
-        constexpr int XPB = fv::xpb(N);
-        const dim3 grid((unsigned)((nblocks + XPB - 1) / XPB)), block(fv::block(N));
-        const size_t lds = (size_t)XPB * fv::lds_elems(N) * sizeof(cf);
-        if (direct) {
-            // (a grid the chip holds at once: each workgroup walks its blocks with the next one's loads in flight)
-            const size_t resident = (size_t)ctx->num_cus * (size_t)(conv_occupancy(N, false) * 4 * 64 / fv::block(N));
-            const dim3 grid_p((unsigned)std::min<size_t>(grid.x, std::max<size_t>(resident, 1)));
-            launch_fv(conv_blocks_kernel16<N, FMT, false>, grid_p, block, lds, ctx->stream, in, (float2 *)out,
-                      (const float2 *)filt, tabs, nblocks, dec, per, P);
-        }
-        else
-            launch_fv(conv_blocks_kernel16<N, FMT, true>, grid, block, lds, ctx->stream, in, (float2 *)out,
-                      (const float2 *)filt, tabs, nblocks, dec, per, P);
-    } else {  // radix-4 core: N < 256
-        constexpr int XPB = fft_xpb(N);
-        const dim3 grid((unsigned)((nblocks + XPB - 1) / XPB)), block(fft_block(N));
-        if (direct)
-            hipLaunchKernelGGL((conv_blocks_kernel<N, FMT, false>), grid, block, 0, ctx->stream, in,
-                               (float2 *)out, (const float2 *)filt, tw, nblocks, dec, per, P);
-        else
-            hipLaunchKernelGGL((conv_blocks_kernel<N, FMT, true>), grid, block, 0, ctx->stream, in,
-                               (float2 *)out, (const float2 *)filt, tw, nblocks, dec, per, P);
-    }
-}
-
-template <int FMT>
-static int launch_conv_fmt(hzsdr_ctx *ctx, size_t n, const void *in, void *out, const void *filt,
-                           const float2 *tw, const FvTabs &tabs, size_t nblocks, unsigned dec, size_t per,
-                           const EwProgram &P) {
-    switch (n) {
-    case 4: launch_conv_n<4, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 8: launch_conv_n<8, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 16: launch_conv_n<16, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 32: launch_conv_n<32, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 64: launch_conv_n<64, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 128: launch_conv_n<128, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 256: launch_conv_n<256, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 512: launch_conv_n<512, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 1024: launch_conv_n<1024, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 2048: launch_conv_n<2048, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 4096: launch_conv_n<4096, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 8192: launch_conv_n<8192, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    default: return HZSDR_ERR_INVALID_ARGUMENT;
-    }
-    return HZSDR_OK;
-}
-
-// Block-circular convolution of nblocks blocks of length n from a source of
-// format fmt with elementwise program P (device pointers).
-static int conv_blocks_device(hzsdr_ctx *ctx, int fmt, size_t n, const void *in, void *out,
-                              const void *filt, size_t nblocks, unsigned dec, size_t per,
-                              const EwProgram &P) {
-    if (nblocks == 0) return HZSDR_OK;
-    const float2 *tw = nullptr;
-    FvTabs tabs{};
-    if (fv::ok((int)n)) HZ_TRY(get_fv_tables(ctx, n, &tabs));
-    else HZ_TRY(get_twiddles(ctx, n, &tw));
-    switch (fmt) {
-    case HZSDR_FMT_C64: return launch_conv_fmt<HZSDR_FMT_C64>(ctx, n, in, out, filt, tw, tabs, nblocks, dec, per, P);
-    case HZSDR_FMT_U8: return launch_conv_fmt<HZSDR_FMT_U8>(ctx, n, in, out, filt, tw, tabs, nblocks, dec, per, P);
-    case HZSDR_FMT_I8: return launch_conv_fmt<HZSDR_FMT_I8>(ctx, n, in, out, filt, tw, tabs, nblocks, dec, per, P);
-    default: return launch_conv_fmt<HZSDR_FMT_I16>(ctx, n, in, out, filt, tw, tabs, nblocks, dec, per, P);
-    }
-}
-
-// Generic (any power of two) single-block path: three steps through scratch.
-static int conv_generic_device(hzsdr_ctx *ctx, void *dst, const void *src1, const void *src2_or_filt,
-                               size_t n, int kind) {
-    HZ_TRY(ensure_slot(ctx, 6, n * 8));
-    void *f1 = ctx->slots[6].ptr;
-    HZ_TRY(fft_device(ctx, src1, f1, n, 1, true));
-    if (kind == 0) {
-        pointwise_mul_device(ctx, f1, src2_or_filt, n, false);
-    } else {
-        HZ_TRY(ensure_slot(ctx, 7, n * 8));
-        void *f2 = ctx->slots[7].ptr;
-        HZ_TRY(fft_device(ctx, src2_or_filt, f2, n, 1, true));
-        pointwise_mul_device(ctx, f1, f2, n, kind == 2);
-    }
-    return fft_device(ctx, f1, dst, n, 1, false);
-}
 
 void nco_shift_ulp1_map4(hzsdr_ctx *ctx, void *buf, size_t nvec4, uint64_t base, double tau_shift, const NcoSegs &sg) {
     EwProgram P{};
@@ -289,438 +98,6 @@ static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, cons
                            (uint64_t)done, P);
 }
 
-// In-place radix-2 transform in float64 (host): the filter spectra are computed once per
-// chain (and once per clock binade for the late mixer), so they are formed in double
-// precision and rounded to float32 ONCE -- a float32 transform of the taps would put its
-// own ~1e-7 relative error, the same in every block, into every output.
-static void host_fft(std::vector<double> &re, std::vector<double> &im, size_t off, size_t n) {
-    for (size_t i = 1, j = 0; i < n; i++) {
-        size_t bit = n >> 1;
-        for (; j & bit; bit >>= 1) j ^= bit;
-        j ^= bit;
-        if (i < j) {
-            std::swap(re[off + i], re[off + j]);
-            std::swap(im[off + i], im[off + j]);
-        }
-    }
-    for (size_t len = 2; len <= n; len <<= 1) {
-        const size_t half = len / 2;
-        for (size_t k = 0; k < half; k++) {
-            const double a = -2.0 * M_PI * (double)k / (double)len, wr = cos(a), wi = sin(a);
-            for (size_t i = k; i < n; i += len) {
-                const size_t u = off + i, v = off + i + half;
-                const double tr = re[v] * wr - im[v] * wi, ti = re[v] * wi + im[v] * wr;
-                re[v] = re[u] - tr;
-                im[v] = im[u] - ti;
-                re[u] += tr;
-                im[u] += ti;
-            }
-        }
-    }
-}
-
-// The taps' spectrum in the layout the analysis kernel multiplies by: H[k] = FFT_N(h)[k] / N,
-// or, for the polyphase form, G[r][k] = FFT_M(g_r)[k] / M with g_r[j] = h[D j - r] (see
-// fold_poly).  `taps`: ntaps complex values (real, imaginary) in host memory, float64;
-// `dst`: N complex64 of device memory.  Uploaded through the context's stream; returns
-// after the copy has completed (the staging vector is local).
-static int filter_spectrum(hzsdr_chain *c, const double *taps, void *dst, double extra_scale = 1.0) {
-    hzsdr_ctx *ctx = c->ctx;
-    const unsigned nfft = c->nfft;
-    std::vector<double> re(nfft, 0.0), im(nfft, 0.0);
-    size_t len = nfft, batch = 1;
-    if (c->poly) {
-        const unsigned F = c->factor, M = nfft / F;
-        for (unsigned r = 0; r < F; r++)
-            for (unsigned j = 0; j < M; j++) {
-                const long idx = (long)F * j - (long)r;
-                if (idx < 0 || (size_t)idx >= c->ntaps) continue;
-                re[(size_t)r * M + j] = taps[2 * idx];
-                im[(size_t)r * M + j] = taps[2 * idx + 1];
-            }
-        len = M;
-        batch = F;
-    } else {
-        for (size_t k = 0; k < c->ntaps; k++) {
-            re[k] = taps[2 * k];
-            im[k] = taps[2 * k + 1];
-        }
-    }
-    for (size_t t = 0; t < batch; t++) host_fft(re, im, t * len, len);
-    std::vector<float> h(2 * (size_t)nfft);
-    const double scale = extra_scale / (double)len;
-    for (size_t i = 0; i < nfft; i++) {
-        h[2 * i] = (float)(re[i] * scale);
-        h[2 * i + 1] = (float)(im[i] * scale);
-    }
-    HZ_HIP(ctx, hipMemcpyAsync(dst, h.data(), (size_t)nfft * 8, hipMemcpyHostToDevice, ctx->stream));
-    HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return HZSDR_OK;
-}
-
-// LATE blocks of a u8 source feed the transform b - 127.5 (exact in float32) instead of the
-// converter's (b - 127.5) / 127.5: the division's scale moves into the late filters' spectra
-// (formed in float64), three packed instructions per sample instead of five in the analysis
-// kernel.  The converter's per-sample rounding (half an ulp, which the reference-order path
-// and the oracle do perform) is thereby skipped: ~3e-8 relative, inside the FIR's error bound.
-static double late_scale(const hzsdr_chain *c) { return c->src_fmt == HZSDR_FMT_U8 ? 1.0 / 127.5 : 1.0; }
-
-// The spectrum of taps[k] * exp(-i * omega * k * step) for one clock step.  A miss uploads,
-// transforms and WAITS (filter_spectrum), so callers on the streaming path only look up
-// (`make` = false: *dev = nullptr on a miss); hzsdr_chain_fir_decimate / _set_time prepare
-// every step a stream can meet ahead of time (prepare_late_filters).  Entries are never
-// evicted while the chain lives: pointers handed to enqueued kernels stay valid.
-constexpr size_t kLateCacheMax = 64;
-static int late_filter_for(hzsdr_chain *c, double step, double omega, void **dev, bool make) {
-    hzsdr_ctx *ctx = c->ctx;
-    *dev = nullptr;
-    uint64_t key;
-    memcpy(&key, &step, 8);
-    auto it = c->late_cache.find(key);
-    if (it != c->late_cache.end()) {
-        *dev = it->second;
-        return HZSDR_OK;
-    }
-    if (!make || c->late_cache.size() >= kLateCacheMax) return HZSDR_OK;  // that run mixes in reference order
-    std::vector<double> mod(2 * c->ntaps);
-    for (size_t k = 0; k < c->ntaps; k++) {
-        const double ph = -omega * ((double)k * step);
-        const double cr = cos(ph), ci = sin(ph);
-        const double hr = c->taps_host[2 * k], hi = c->taps_host[2 * k + 1];
-        mod[2 * k] = hr * cr - hi * ci;
-        mod[2 * k + 1] = hr * ci + hi * cr;
-    }
-    void *h = nullptr;
-    HZ_HIP(ctx, hipMalloc(&h, (size_t)c->nfft * 8));
-    int rc = filter_spectrum(c, mod.data(), h, late_scale(c));
-    if (rc != HZSDR_OK) {
-        (void)hipFree(h);
-        return rc;
-    }
-    c->late_cache[key] = h;
-    *dev = h;
-    return HZSDR_OK;
-}
-
-static double chain_omega(const hzsdr_chain *c) {
-    double omega = 0.0;
-    for (int i = 0; i < c->n_ops; i++)
-        if (c->ops[i].kind == EW_SHIFT) omega += c->ops[i].tau_shift;
-    return omega;
-}
-
-// The late mixer's modulated spectra for every long run the clock can produce from `ts0`
-// on: the rest of the current 2*pi period plus one whole period from 0 (the clock's step is
-// a function of the binade alone, so after the first wrap the runs repeat).  Done at chain
-// construction and whenever the clock is set, so hzsdr_chain_run never allocates or waits.
-static int prepare_late_filters(hzsdr_chain *c, double ts0) {
-    if (!c->has_shift || !late_capable(c->nfft) || c->taps_host.empty()) return HZSDR_OK;
-    const double omega = chain_omega(c);
-    const uint64_t period = (uint64_t)(6.283185307179586 * (double)c->sample_rate) + 2;
-    for (int pass = 0; pass < 2; pass++) {
-        std::vector<hzsdr_nco_segment> segs(96);
-        size_t need = 0;
-        double ts_end = 0.0;
-        if (hzsdr_nco_segments(c->sample_rate, pass == 0 ? ts0 : 0.0, period, segs.data(), segs.size(), &need,
-                               &ts_end) != HZSDR_OK)
-            continue;
-        const size_t have = need < segs.size() ? need : segs.size();
-        for (size_t q = 0; q < have; q++) {
-            if (segs[q].count < 2 * (uint64_t)c->nfft) continue;
-            void *dev;
-            HZ_TRY(late_filter_for(c, segs[q].step, omega, &dev, true));
-        }
-    }
-    return HZSDR_OK;
-}
-
-// ---- int8 matrix form (hz_firmm.h) -------------------------------------------------------------
-
-static double mm_scale(const hzsdr_chain *c) { return c->src_fmt == HZSDR_FMT_U8 ? 1.0 / 127.5 : 1.0 / 128.0; }
-
-// Byte sources with a decimation of 8 or 16, up to the tap count at which the direct form's work
-// (proportional to the taps) passes the transforms' (tools/firmm_probe.py, 2^24 samples, us per
-// call, matrix / transform: D = 8: 64 taps 33 / 152, 256: 35 / 73, 512: 41 / 50, 1024: 48 / 53,
-// 1536: 70 / 70, 2048: 87 / 73; D = 16 (chunks of 1024 outputs): 256: 24 / 70, 512: 28 / 78, 1024: 36 / 48,
-// 1536: 46 / 67, 2047: 54 / 69, 3000: 85 / 82; D = 32: 256: 31 / 71, 1024: 41 / 80, 4096: 99 / 151; D = 64: 1024:
-// 39 / 79, 4096: 77 / 152; the D = 8 / 16 transform figures from before N_fft started at 256 D).
-// hzsdr_chain_fir_options(HZSDR_FIR_IMPL_TRANSFORMS) keeps a chain on the transform kernels (A/B measurements, tests).
-static bool mm_eligible(const hzsdr_chain *c) {
-    if (c->fir_impl == HZSDR_FIR_IMPL_TRANSFORMS || (c->fir_impl == HZSDR_FIR_IMPL_AUTO && diag_env().fir_fft)) return false;
-    if (c->src_fmt != HZSDR_FMT_U8 && c->src_fmt != HZSDR_FMT_I8) return false;
-    if (!mm::factor_ok(c->factor)) return false;
-    return c->ntaps >= 16 && c->ntaps <= (c->factor == 8 ? 1536u : c->factor <= 24 ? 2560u : 4096u);
-}
-
-// hz_firmm2.h (the persistent-pass form): D = 8, and a pass image / table that fit its fixed register counts.
-// hzsdr_chain_fir_options(HZSDR_FIR_IMPL_MATRIX_CHUNKS) keeps the first form (A/B measurements).
-static bool mm2_eligible(const hzsdr_chain *c) {
-    if (c->fir_impl == HZSDR_FIR_IMPL_MATRIX_CHUNKS || (c->fir_impl == HZSDR_FIR_IMPL_AUTO && diag_env().mm_v1)) return false;
-    if (!mm2::factor_ok(c->factor)) return false;
-    const mm2::Geom g = mm2::make_geom((int)c->ntaps, (int)c->factor, c->off, 0);
-    const int D = (int)c->factor;
-    return mm2::image_bytes(D, g.ks) <= (size_t)mm2::kU * 64 * 16 && mm2::table_bytes(g.ne) <= (size_t)4 * mm2::kThreads * 16 &&
-           mm2::lds_bytes(D, g.ks, g.ne, g.ntaps) <= 160 * 1024 && g.ntaps + D * (mm2::kFixOut - 1) <= 5 * 256;
-}
-
-static void mm_geometry(hzsdr_chain *c) {
-    const int D = (int)c->factor;
-    c->mm_ver = mm2_eligible(c) ? 2 : 1;
-    // q = round(h' 2^S) with |q| <= 2^30 (hz_firmm_plan.h: digit_shift)
-    const int S = mm::digit_shift(c->taps_host.data(), c->ntaps, mm_scale(c));
-    if (c->mm_ver == 2) {
-        const mm2::Geom g2 = mm2::make_geom((int)c->ntaps, D, c->off, S);
-        mm::Geom &g = c->mmg;
-        g.ntaps = g2.ntaps, g.w0 = g2.w0, g.ks = g2.ks, g.ne = g2.ne, g.e0 = g2.e0, g.shift = g2.shift, g.off = g2.off;
-    } else {
-        c->mmg = mm::make_geom((int)c->ntaps, D, c->off, S);
-    }
-}
-
-// The digit table of taps[k] * exp(-i omega k step) * scale (hz_firmm.h: F[digit][E][part][16],
-// then the constant term).  Like late_filter_for: a miss builds, uploads and WAITS unless
-// `make` is false.
-static int mm_table_for(hzsdr_chain *c, double step, double omega, void **dev, bool make) {
-    hzsdr_ctx *ctx = c->ctx;
-    *dev = nullptr;
-    uint64_t key;
-    memcpy(&key, &step, 8);
-    auto it = c->mm_cache.find(key);
-    if (it != c->mm_cache.end()) {
-        *dev = it->second;
-        return HZSDR_OK;
-    }
-    if (!make || c->mm_cache.size() >= kLateCacheMax) return HZSDR_OK;
-    // (the table's contents: hz_firmm_plan.h, HIP-free and fuzzed on the host)
-    const std::vector<uint8_t> tab = mm::digit_table(c->mmg, (int)c->factor, c->taps_host.data(), mm_scale(c), step, omega,
-                                                     c->src_fmt == HZSDR_FMT_U8, c->mm_ver == 2);
-    void *d = nullptr;
-    HZ_HIP(ctx, hipMalloc(&d, tab.size()));
-    hipError_t e = hipMemcpyAsync(d, tab.data(), tab.size(), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) {
-        (void)hipFree(d);
-        HZ_HIP(ctx, e);
-    }
-    c->mm_cache[key] = d;
-    *dev = d;
-    return HZSDR_OK;
-}
-
-// Tables for every long run the clock can produce from ts0 on (see prepare_late_filters).
-static int prepare_mm_tables(hzsdr_chain *c, double ts0) {
-    if (!c->mm_ok) return HZSDR_OK;
-    void *dev;
-    if (!c->has_shift) return mm_table_for(c, 0.0, 0.0, &dev, true);
-    const double omega = chain_omega(c);
-    const uint64_t period = (uint64_t)(6.283185307179586 * (double)c->sample_rate) + 2;
-    for (int pass = 0; pass < 2; pass++) {
-        std::vector<hzsdr_nco_segment> segs(96);
-        size_t need = 0;
-        double ts_end = 0.0;
-        if (hzsdr_nco_segments(c->sample_rate, pass == 0 ? ts0 : 0.0, period, segs.data(), segs.size(), &need,
-                               &ts_end) != HZSDR_OK)
-            continue;
-        const size_t have = need < segs.size() ? need : segs.size();
-        for (size_t q = 0; q < have; q++) {
-            if (segs[q].count < 8 * (uint64_t)c->ntaps) continue;
-            HZ_TRY(mm_table_for(c, segs[q].step, omega, &dev, true));
-        }
-    }
-    return HZSDR_OK;
-}
-
-// Splits the outputs of one call between the matrix path (per clock run) and the fix-up
-// workgroups.  false: the call stays on the transform kernels.
-static bool mm_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in, const void *out, mm::Runs *R,
-                    mm::Fix *F) {
-    memset(R, 0, sizeof *R);
-    memset(F, 0, sizeof *F);
-    if (!c->mm_ok || c->mix_in_order || P.segs.big_n != 0 || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) return false;
-    for (int i = 0; i < P.n; i++)
-        if (P.op[i].kind == EW_SHIFT && !(fabs(P.op[i].tau_shift) * 6.2832 < 1073741824.0)) return false;
-    const int nr = c->has_shift ? P.segs.n : 1;
-    if (nr < 1 || nr > mm::kMaxRuns) return false;
-    // does run 0 continue the run the previous call ended in (same step, no reset in between)?  Then
-    // the clock is exactly linear across the call boundary and the first windows may reach back
-    // into the raw history instead of going to the fix-up tasks.
-    const bool cont = c->rh_valid && (!c->has_shift || (P.segs.step[0] == c->rh_step && c->rh_len >= c->ntaps && c->rh_next == P.segs.t0[0]));
-    const void *tabs[mm::kMaxRuns];
-    for (int r = 0; r < nr; r++) {
-        void *dev = nullptr;
-        (void)mm_table_for(c, c->has_shift ? P.segs.step[r] : 0.0, 0.0, &dev, false);
-        tabs[r] = dev;
-    }
-    const uint64_t zero_first = 0;
-    // the planner itself is host-only code (hz_firmm_plan.h: sanitizer-built and fuzzed in tests/host/)
-    const mm::ChunkPlanIn pin{n, c->factor, (int)c->ntaps, cont, nr, c->has_shift ? P.segs.first : &zero_first, tabs};
-    uint64_t fix_total = 0;
-    const bool ok = mm::plan_chunks(pin, R, F, &fix_total);
-    const uint64_t n_chunks = (uint64_t)R->n_wg;
-    if (c->debug_mm) {
-        fprintf(stderr, "hzsdr mm: %d runs, cont %d, %llu chunks, %d fix intervals (%d tasks, %llu outputs)\n", nr, R->cont,
-                (unsigned long long)n_chunks, F->n, F->n_wg, (unsigned long long)fix_total);
-        for (int r = 0; r < nr; r++)
-            fprintf(stderr, "   run %d first %llu valid [%u, %u) first chunk %d table %p\n", r,
-                    (unsigned long long)(c->has_shift ? P.segs.first[r] : 0), R->m_lo[r], R->m_hi[r], R->wg_first[r], R->tab[r]);
-        for (int k = 0; k < F->n; k++) fprintf(stderr, "   fix [%u, %u) first task %d\n", F->m_a[k], F->m_b[k], F->wg_first[k]);
-    }
-    return ok;
-}
-
-static int mm_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const EwProgram &P, const mm::Runs &R,
-                     const mm::Fix &F) {
-    return mm::launch_fir(c->ctx->stream, c->src_fmt, c->factor, in, (float2 *)out, (const float2 *)c->hist[c->hist_cur],
-                          (float2 *)c->hist[c->hist_cur ^ 1], (const uint8_t *)c->rhist[c->hist_cur],
-                          (uint8_t *)c->rhist[c->hist_cur ^ 1], (const float2 *)c->taps_dev, n, c->mmg, P, R, F);
-}
-
-// hz_firmm2.h: the plan of one call for the persistent-pass kernel.  Every clock run with a table gets the
-// outputs whose whole window lies in it (tile-aligned) and the passes of the call's 512-output grid that hold
-// them -- a pass that straddles a boundary is multiplied once per run, each time with that run's table and
-// valid range (a second short pass costs one wave 6 us; the fix-up tasks it replaces cost ~10 us EACH).  What
-// no run holds -- windows that cross a boundary, the stream's start, runs without a table -- are fix-up tasks
-// of 8 outputs.  false: the call stays on the transform kernels.
-static bool mm2_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in, const void *out, mm2::Plan *L,
-                     mm2::Fix *F) {
-    memset(L, 0, sizeof *L);
-    memset(F, 0, sizeof *F);
-    if (!c->mm_ok || c->mix_in_order || P.segs.big_n != 0 || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) return false;
-    for (int i = 0; i < P.n; i++)
-        if (P.op[i].kind == EW_SHIFT && !(fabs(P.op[i].tau_shift) * 6.2832 < 1073741824.0)) return false;
-    const int nr = c->has_shift ? P.segs.n : 1;
-    if (nr < 1 || nr > kNcoMaxSegs) return false;
-    // the planner itself is host-only code (hz_firmm2_plan.h: sanitizer-built and fuzzed in tests/host/)
-    mm2::PlanIn pin{};
-    pin.n_in = n, pin.D = c->factor, pin.ntaps = (int)c->ntaps, pin.has_shift = c->has_shift;
-    pin.cont = c->rh_valid && (!c->has_shift || (P.segs.step[0] == c->rh_step && c->rh_len >= c->ntaps && c->rh_next == P.segs.t0[0]));
-    pin.n_ops = P.n;
-    pin.max_grid = c->ctx->num_cus;
-    pin.shift_op = -1;
-    int n_shift = 0;
-    for (int i = 0; i < P.n; i++)
-        if (P.op[i].kind == EW_SHIFT) {
-            pin.shift_op = i;
-            n_shift++;
-        }
-    if (n_shift != 1) pin.shift_op = -1;
-    else pin.tau = P.op[pin.shift_op].tau_shift;
-    const void *tabs[kNcoMaxSegs];
-    const uint64_t zero_first = 0;
-    const double zero = 0.0;
-    for (int r = 0; r < nr; r++) {
-        void *dev = nullptr;
-        (void)mm_table_for(c, c->has_shift ? P.segs.step[r] : 0.0, 0.0, &dev, false);
-        tabs[r] = dev;
-    }
-    mm2::ClockRuns cr{nr, c->has_shift ? P.segs.first : &zero_first, c->has_shift ? P.segs.t0 : &zero, c->has_shift ? P.segs.step : &zero, tabs};
-    uint64_t fix_total = 0;
-    const bool ok = mm2::plan_call(pin, cr, L, F, &fix_total);
-    if (c->debug_mm) {
-        fprintf(stderr, "hzsdr mm2: %s: %d of %d runs on the matrix path, cont %d, %d passes, %d fix intervals (%d tasks, %llu outputs)\n",
-                ok ? "matrix path" : "transform kernels", L->n, nr, L->cont, L->n_pass, F->n, F->n_task, (unsigned long long)fix_total);
-        for (int r = 0; r < L->n; r++)
-            fprintf(stderr, "   run first %llu valid [%u, %u) passes [%d, %d) table %p\n", (unsigned long long)L->run[r].first, L->run[r].m_lo,
-                    L->run[r].m_hi, L->run[r].pass_first, L->run[r].pass_end, L->run[r].tab);
-        for (int k = 0; k < F->n; k++) fprintf(stderr, "   fix [%u, %u) first task %d\n", F->m_a[k], F->m_b[k], F->task_first[k]);
-    }
-    return ok;
-}
-
-static int mm2_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const EwProgram &P, const mm2::Plan &L,
-                      const mm2::Fix &F) {
-    mm2::Geom g2{};
-    g2.ntaps = c->mmg.ntaps, g2.w0 = c->mmg.w0, g2.ks = c->mmg.ks, g2.ne = c->mmg.ne, g2.e0 = c->mmg.e0, g2.shift = c->mmg.shift,
-    g2.off = c->mmg.off;
-    return mm2::launch_fir(c->ctx->stream, c->ctx->num_cus, c->src_fmt, c->factor, in, (float2 *)out,
-                           (const float2 *)c->hist[c->hist_cur], (float2 *)c->hist[c->hist_cur ^ 1],
-                           (const uint8_t *)c->rhist[c->hist_cur], (uint8_t *)c->rhist[c->hist_cur ^ 1],
-                           (const float2 *)c->taps_dev, n, g2, L, P, F, c->fir_loop_form);
-}
-
-// The modulated filter of every clock run long enough to hold a whole block (lookups only).
-static int late_filters(hzsdr_chain *c, const EwProgram &P, size_t n, LateFilters *out, bool *any) {
-    *any = false;
-    memset(out, 0, sizeof *out);
-    if (c->mix_in_order || P.segs.big_n != 0 || c->taps_host.empty()) return HZSDR_OK;
-    if (!c->has_shift) {
-        // no clock involved: Gain / Multiply commute with the filter everywhere, with the
-        // taps as they are (the kernel sees an empty run table: run 0)
-        out->h[0] = (const float2 *)(c->hfreq_late ? c->hfreq_late : c->hfreq);
-        *any = true;
-        return HZSDR_OK;
-    }
-    // sincos_late (the late mixer's Sincos) takes |tau * ts| < 2^30, ts <= 2 pi
-    for (int i = 0; i < P.n; i++)
-        if (P.op[i].kind == EW_SHIFT && !(fabs(P.op[i].tau_shift) * 6.2832 < 1073741824.0)) return HZSDR_OK;
-    const double omega = chain_omega(c);
-    for (int r = 0; r < P.segs.n; r++) {
-        const uint64_t first = P.segs.first[r], end = r + 1 < P.segs.n ? P.segs.first[r + 1] : (uint64_t)n;
-        if (end - first < 2 * (uint64_t)c->nfft) continue;
-        void *dev;
-        HZ_TRY(late_filter_for(c, P.segs.step[r], omega, &dev, false));
-        out->h[r] = (const float2 *)dev;
-        if (dev) *any = true;
-    }
-    return HZSDR_OK;
-}
-
-// The blocks of this run that mix in reference order, ascending, for the analysis kernel's
-// dispatch order (device side: late_block).  Block b spans [b*hop - off, b*hop - off + N) and
-// is late iff that span lies in [0, n - off] AND inside one clock run that has a filter.
-// Walks the runs, not the blocks; more than kMaxSlowBlocks of them -> empty list (stream order).
-static void slow_blocks(const hzsdr_chain *c, const EwProgram &P, const LateFilters &late, size_t n,
-                        size_t nblocks, SlowBlocks *out) {
-    out->n = 0;
-    if (diag_env().no_slow_first) return;  // measurement aid (tools/wrap_probe.py): stream order
-    const int64_t N = c->nfft, hop = c->hop, off = c->off;
-    std::vector<unsigned> v;
-    auto add_range = [&](int64_t lo, int64_t hi) {  // blocks lo .. hi inclusive, clipped
-        if (lo < 0) lo = 0;
-        if (hi >= (int64_t)nblocks) hi = (int64_t)nblocks - 1;
-        for (int64_t b = lo; b <= hi && v.size() <= (size_t)kMaxSlowBlocks; b++) v.push_back((unsigned)b);
-    };
-    // every block whose span contains a sample of [s_lo, s_hi]: b*hop - off <= s_hi and b*hop - off + N > s_lo
-    auto touching = [&](int64_t s_lo, int64_t s_hi) {
-        int64_t lo = s_lo + off - N;            // b*hop > lo
-        lo = lo < 0 ? 0 : lo / hop + 1;
-        add_range(lo, (s_hi + off) / hop);
-    };
-    // stream edges: spans that start before sample 0 (b*hop < off) or end after n - off (b*hop > n - N)
-    if (off > 0) add_range(0, (off - 1) / hop);
-    add_range((int64_t)n >= N ? ((int64_t)n - N) / hop + 1 : 0, (int64_t)nblocks - 1);
-    const int nr = P.segs.n > 0 ? P.segs.n : 1;
-    for (int r = 0; r < nr; r++) {
-        const int64_t first = P.segs.n > 0 ? (int64_t)P.segs.first[r] : 0;
-        const int64_t end = (P.segs.n > 0 && r + 1 < P.segs.n) ? (int64_t)P.segs.first[r + 1] : (int64_t)n;
-        if (late.h[r] == nullptr) touching(first, end - 1);      // a run without a filter: every block in it
-        else if (r > 0) touching(first - 1, first);              // a boundary: the blocks that straddle it
-        if (v.size() > (size_t)kMaxSlowBlocks) return;
-    }
-    std::sort(v.begin(), v.end());
-    v.erase(std::unique(v.begin(), v.end()), v.end());
-    if (v.size() > (size_t)kMaxSlowBlocks) return;
-    out->n = (int)v.size();
-    for (size_t i = 0; i < v.size(); i++) out->idx[i] = v[i];
-    if (diag_env().debug_late) {
-        int nh = 0;
-        for (int r = 0; r < nr; r++) nh += late.h[r] != nullptr;
-        fprintf(stderr, "hzsdr: %d runs, %d with a late filter, %d of %zu blocks listed as reference-order:", nr, nh, out->n, nblocks);
-        for (int i = 0; i < out->n; i++) fprintf(stderr, " %u", out->idx[i]);
-        fprintf(stderr, "\n");
-        for (int r = 0; r < nr; r++)
-            fprintf(stderr, "   run %d first %llu step %.17g filter %p\n", r, (unsigned long long)P.segs.first[r], P.segs.step[r], (const void *)late.h[r]);
-    }
-}
-
-// workgroups of fir_decimate_kernel16: with the late mixer, the listed blocks first, then the
-// rest in eight contiguous runs (one per XCD), padded to whole rounds of eight
-static unsigned fir_grid(size_t nblocks, int xpb, bool late, int n_slow) {
-    if (!late) return (unsigned)((nblocks + xpb - 1) / xpb);
-    const size_t rest = nblocks - (size_t)n_slow;
-    return (unsigned)(n_slow + 8 * ((rest + 7) / 8));
-}
-
 template <int FMT>
 static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, size_t n_out,
                    const EwProgram &P) {
@@ -739,142 +116,14 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
     case TERM_CONV:
         return conv_blocks_device(ctx, FMT, c->flen, in, out, c->filt, n_cons / c->flen, c->factor,
                                   c->factor > 1 ? kReaderBlock / c->factor : 0, P);
-    case TERM_FIR: {
-        const size_t nblocks = (n_cons + c->hop - 1) / c->hop;
-        const float2 *hist = (const float2 *)c->hist[c->hist_cur];
-        float2 *nhist = (float2 *)c->hist[c->hist_cur ^ 1];
-        const unsigned D = c->factor;
-        if (c->mm_ok) {
-            // byte source, D = 8, 16, ...: the int8 matrix form (hz_firmm2.h / hz_firmm.h), one launch
-            mm::Runs R;
-            mm::Fix F;
-            mm2::Plan L2;
-            mm2::Fix F2;
-            bool ran = false;
-            int cont = 0;
-            if (c->mm_ver == 2) {
-                if (mm2_plan(c, P, n_cons, in, out, &L2, &F2)) {
-                    const int rc = mm2_launch(c, in, out, n_cons, P, L2, F2);
-                    if (rc != HZSDR_OK) {  // (nothing was committed: the histories are the previous call's)
-                        c->rh_valid = false;
-                        return rc;
-                    }
-                    ran = true;
-                    cont = L2.cont;
-                }
-            } else if (mm_plan(c, P, n_cons, in, out, &R, &F)) {
-                const int rc = mm_launch(c, in, out, n_cons, P, R, F);
-                if (rc != HZSDR_OK) {
-                    c->rh_valid = false;
-                    return rc;
-                }
-                ran = true;
-                cont = R.cont;
-            }
-            if (ran) {
-                c->hist_cur ^= 1;
-                c->last_path = HZSDR_FIR_PATH_MATRIX;
-                // the raw history now ends in this call's last clock run
-                const bool was = c->rh_valid;
-                c->rh_valid = n_cons >= c->off || was;
-                if (c->has_shift) {
-                    const int last = P.segs.n - 1;
-                    const uint64_t len = n_cons - P.segs.first[last];
-                    c->rh_len = (last == 0 && cont) ? c->rh_len + len : len;
-                    c->rh_step = P.segs.step[last];
-                    // the clock the run assigns to the NEXT sample: a call that continues the run starts there
-                    // (equal steps alone do not say so: with a sample rate whose 1/fs is a power of two every
-                    // binade has the same step, and a 2*pi wrap on a call boundary would pass unnoticed)
-                    c->rh_next = fma((double)len, P.segs.step[last], P.segs.t0[last]);
-                }
-                break;
-            }
-        }
-        if (!fv::ok((int)c->nfft)) return HZSDR_ERR_INVALID_ARGUMENT;
-        FvTabs tabs{}, tabs_m{};
-        PolyTabs ptabs{};
-        HZ_TRY(get_fv_tables(ctx, c->nfft, &tabs));
-        LateFilters late{};
-        SlowBlocks slow{};
-// packed-math core: fold when D is a power of two <= 16 and N/D is itself a core size
-#define HZ_FIR16_L(N, FOLD, LATE, SPEC)                                                                        \
-    launch_fv(fir_decimate_kernel16<N, FMT, FOLD, LATE>, dim3(fir_grid(nblocks, fv::xpb(N), LATE, slow.n)),      \
-              dim3(fv::block(N)), fir_lds_bytes(N, FOLD), ctx->stream, in,                                      \
-              (float2 *)out, hist, nhist, (const float2 *)c->hfreq, tabs, SPEC, nblocks, n_cons, c->hop, c->off, D, \
-              P, late, ptabs, slow)
-#define HZ_FIR16(N, FOLD) HZ_FIR16_L(N, FOLD, false, (float2 *)nullptr)
-#define HZ_SYNTH16(N, F, LATE)                                                                                 \
-    launch_fv(fir_synth_kernel16<N, F, LATE>,                                                                  \
-              dim3((unsigned)((nblocks + SynthGeom<N, F>::XPB - 1) / SynthGeom<N, F>::XPB)),                    \
-              dim3(SynthGeom<N, F>::BS), (size_t)SynthGeom<N, F>::XPB * fv::lds_elems(N / F) * sizeof(cf),      \
-              ctx->stream, (const float2 *)spec, (float2 *)out, tabs_m.bwd, nblocks, n_cons, c->hop, c->off, P, late)
-#define HZ_FIR16_FOLD(N, F)                                                            \
-    if (D == F) {                                                                      \
-        if constexpr (fv::xpb(N) == 1 && fv::ok(N / F)) {                              \
-            HZ_TRY(get_fv_tables(ctx, N / F, &tabs_m));                                \
-            if constexpr (fold_poly(N, F)) HZ_TRY(get_fv_poly_tables(ctx, N, F, &ptabs)); \
-            bool any_late = false;                                                     \
-            HZ_TRY(late_filters(c, P, n_cons, &late, &any_late));                      \
-            if (any_late) slow_blocks(c, P, late, n_cons, nblocks, &slow);             \
-            HZ_TRY(ensure_slot(ctx, 11, nblocks * (size_t)(N / F) * 8));               \
-            float2 *spec = (float2 *)ctx->slots[11].ptr;                               \
-            if (any_late) {                                                            \
-                HZ_FIR16_L(N, F, true, spec);                                          \
-                HZ_SYNTH16(N, F, true);                                                \
-            } else {                                                                   \
-                HZ_FIR16_L(N, F, false, spec);                                         \
-                HZ_SYNTH16(N, F, false);                                               \
-            }                                                                          \
-            break;                                                                     \
-        }                                                                              \
-    }
-// any other factor (1, 3, 5, 10, ...): full backward transform in the analysis kernel; the
-// late mixer applies there too when a workgroup is one block (N >= 1024)
-#define HZ_FIR16_FULL(N)                                                               \
-    if constexpr (fv::xpb(N) == 1) {                                                   \
-        bool any_late = false;                                                         \
-        HZ_TRY(late_filters(c, P, n_cons, &late, &any_late));                          \
-        if (any_late) slow_blocks(c, P, late, n_cons, nblocks, &slow);                 \
-        if (any_late) HZ_FIR16_L(N, 0, true, (float2 *)nullptr);                       \
-        else HZ_FIR16(N, 0);                                                           \
-    } else {                                                                           \
-        HZ_FIR16(N, 0);                                                                \
-    }
-#define HZ_FIR16_N(N)            \
-    do {                         \
-        HZ_FIR16_FOLD(N, 2)      \
-        HZ_FIR16_FOLD(N, 4)      \
-        HZ_FIR16_FOLD(N, 8)      \
-        HZ_FIR16_FOLD(N, 16)     \
-        HZ_FIR16_FULL(N)         \
-    } while (0)
-        switch (c->nfft) {
-        case 256: HZ_FIR16_N(256); break;
-        case 512: HZ_FIR16_N(512); break;
-        case 1024: HZ_FIR16_N(1024); break;
-        case 2048: HZ_FIR16_N(2048); break;
-        case 4096: HZ_FIR16_N(4096); break;
-        case 8192: HZ_FIR16_N(8192); break;
-        default: return HZSDR_ERR_INVALID_ARGUMENT;
-        }
-#undef HZ_FIR16_N
-#undef HZ_FIR16_FULL
-#undef HZ_FIR16_FOLD
-#undef HZ_FIR16
-#undef HZ_FIR16_L
-#undef HZ_SYNTH16
-        c->hist_cur ^= 1;  // the kernel wrote the next run's history into nhist
-        c->rh_valid = false;  // (the transform kernels keep no raw history)
-        c->last_path = HZSDR_FIR_PATH_TRANSFORM;
-        break;
-    }
+    case TERM_FIR: return fir_run<FMT>(c, in, n_cons, out, P);
     }
     return HZSDR_OK;
 }
 
 // The chain's kernel(s) over device buffers, enqueued on the context's stream.
 // *ts_after is the NCO clock after `cons` samples; the caller commits it.
-static int chain_launch(hzsdr_chain *c, const void *din, size_t cons, void *dout, size_t outn, double *ts_after) {
+int chain_launch(hzsdr_chain *c, const void *din, size_t cons, void *dout, size_t outn, double *ts_after) {
     EwProgram P{};
     P.n = c->n_ops;
     for (int i = 0; i < c->n_ops; i++) P.op[i] = c->ops[i];
@@ -896,14 +145,14 @@ static int chain_launch(hzsdr_chain *c, const void *din, size_t cons, void *dout
 // in a DEVICE context the filter may still be being produced by work enqueued on that
 // stream (an hzsdr_fft_transform, a torch kernel), which the legacy null stream does not
 // order against.  HOST contexts wait, so the caller's slice may be reused on return.
-static int upload_filter(hzsdr_ctx *ctx, void *dst, const void *src, size_t bytes) {
+int upload_filter(hzsdr_ctx *ctx, void *dst, const void *src, size_t bytes) {
     const bool host = ctx->memspace == HZSDR_MEM_HOST;
     HZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
     if (host) HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HZSDR_OK;
 }
 
-static int chain_terminal_set(hzsdr_chain *c) {
+int chain_terminal_set(hzsdr_chain *c) {
     if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
     if (c->term != TERM_NONE) return fail(c->ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: terminal stage already set");
     return HZSDR_OK;
@@ -1002,93 +251,6 @@ int hzsdr_chain_convolution(hzsdr_chain *c, const void *filter_freq, size_t filt
     c->flen = filter_len;
     c->factor = decimate_factor;
     c->term = TERM_CONV;
-    return HZSDR_OK;
-}
-
-int hzsdr_chain_fir_options(hzsdr_chain *c, int impl, unsigned nfft_min, int loop_form) {
-    if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
-    if (c->term != TERM_NONE) return hz::fail(c->ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: fir options go in front of the terminal stage");
-    if (impl < HZSDR_FIR_IMPL_AUTO || impl > HZSDR_FIR_IMPL_MATRIX_CHUNKS || (nfft_min && (nfft_min < 256 || nfft_min > 8192 || (nfft_min & (nfft_min - 1)))))
-        return hz::fail(c->ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: fir options");
-    c->fir_impl = impl;
-    c->fir_nfft_min = nfft_min;
-    c->fir_loop_form = loop_form;
-    return HZSDR_OK;
-}
-
-int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps, size_t n_taps, unsigned factor) {
-    using namespace hz;
-    HZ_TRY(chain_terminal_set(c));
-    hzsdr_ctx *ctx = c->ctx;
-    if (!taps || n_taps == 0 || factor == 0) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: fir taps / factor");
-    // N_fft = next power of two >= 4 * taps, in [N_min, 8192].  N_min is the smallest size at which the
-    // fast forms of the kernels apply: the late mixer needs one block per workgroup (N >= 1024) and
-    // the polyphase analysis N / D >= 256 for D = 2, 4, 8, 16.  Measured on 2^24 u8 samples (us per
-    // chain_run, N_min = 256 as in round 1 -> now): D = 8, 64 taps 152 -> 43, 256 taps 71 -> 45;
-    // D = 16, 256 taps 69 -> 41; D = 4, 128 taps 167 -> 54; D = 2, 64 taps 157 -> 78.
-    // (hzsdr_chain_fir_options' nfft_min overrides N_min: the measurement aid those numbers come from.)
-    unsigned nfft = 1024;
-    if (factor == 2 || factor == 4 || factor == 8 || factor == 16) nfft = std::max(1024u, 256u * factor);
-    if (c->fir_nfft_min) nfft = c->fir_nfft_min;
-    if (nfft < 256 || nfft > 8192 || (nfft & (nfft - 1))) nfft = 1024;
-    while (nfft < 4 * n_taps && nfft < 8192) nfft <<= 1;
-    unsigned off = (unsigned)(n_taps - 1);
-    off = (off + factor - 1) / factor * factor;  // first valid output on the decimation grid
-    if (off + factor > nfft) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: too many taps for the 8192-point overlap-save block");
-    unsigned hop = (nfft - off) / factor * factor;
-    HZ_TRY(enter(ctx));
-    const size_t hb = (size_t)(off ? off : 1) * 8;
-    c->ntaps = n_taps;
-    c->nfft = nfft;
-    c->hop = hop;
-    c->off = off;
-    c->factor = factor;
-    c->poly = fold_poly((int)nfft, (int)factor);
-    c->taps_host.assign(taps, taps + 2 * n_taps);
-    // every allocation is released again if a later step fails: the chain stays without a
-    // terminal stage (a retry starts clean, nothing leaks)
-    auto build = [&]() -> int {
-        HZ_HIP(ctx, hipMalloc(&c->hfreq, (size_t)nfft * 8));
-        HZ_HIP(ctx, hipMalloc(&c->hist[0], hb));
-        HZ_HIP(ctx, hipMalloc(&c->hist[1], hb));
-        HZ_HIP(ctx, hipMemsetAsync(c->hist[0], 0, hb, ctx->stream));
-        HZ_HIP(ctx, hipMemsetAsync(c->hist[1], 0, hb, ctx->stream));
-        HZ_TRY(filter_spectrum(c, c->taps_host.data(), c->hfreq));
-        if (late_scale(c) != 1.0) {
-            HZ_HIP(ctx, hipMalloc(&c->hfreq_late, (size_t)nfft * 8));
-            HZ_TRY(filter_spectrum(c, c->taps_host.data(), c->hfreq_late, late_scale(c)));
-        }
-        HZ_TRY(prepare_late_filters(c, c->ts));
-        c->mm_ok = mm_eligible(c);
-        if (c->mm_ok) {
-            mm_geometry(c);
-            std::vector<float> tf(2 * n_taps);
-            for (size_t i = 0; i < 2 * n_taps; i++) tf[i] = taps[i];
-            HZ_HIP(ctx, hipMalloc(&c->rhist[0], hb));
-            HZ_HIP(ctx, hipMalloc(&c->rhist[1], hb));
-            HZ_HIP(ctx, hipMalloc(&c->taps_dev, 8 * n_taps));
-            HZ_HIP(ctx, hipMemcpyAsync(c->taps_dev, tf.data(), 8 * n_taps, hipMemcpyHostToDevice, ctx->stream));
-            HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            HZ_TRY(prepare_mm_tables(c, c->ts));
-        }
-        return HZSDR_OK;
-    };
-    const int rc = build();
-    if (rc != HZSDR_OK) {
-        (void)hipStreamSynchronize(ctx->stream);
-        for (void **p : {&c->hfreq, &c->hfreq_late, &c->hist[0], &c->hist[1], &c->taps_dev, &c->rhist[0], &c->rhist[1]}) {
-            if (*p) (void)hipFree(*p);
-            *p = nullptr;
-        }
-        for (auto &kv : c->late_cache) (void)hipFree(kv.second);
-        c->late_cache.clear();
-        for (auto &kv : c->mm_cache) (void)hipFree(kv.second);
-        c->mm_cache.clear();
-        c->mm_ok = false;
-        c->taps_host.clear();
-        return rc;
-    }
-    c->term = TERM_FIR;
     return HZSDR_OK;
 }
 
@@ -1222,287 +384,5 @@ int hzsdr_chain_mix_in_order(hzsdr_chain *c, int in_order) {
     c->mix_in_order = in_order != 0;
     return HZSDR_OK;
 }
-
-// ---- fft.ConvolveFreq / Convolve / CrossCorrelate closures --------------------------------
-
-int hzsdr_convolve_freq_create(hzsdr_ctx *ctx, void *dst, size_t dst_len, const void *src,
-                               size_t src_len, const void *freq, size_t freq_len, hzsdr_conv **out) {
-    using namespace hz;
-    if (!ctx || !out) return HZSDR_ERR_INVALID_ARGUMENT;
-    *out = nullptr;
-    if (src_len != dst_len || src_len != freq_len)  // fft/convolution.go:156-158
-        return fail(ctx, HZSDR_ERR_LENGTH_MISMATCH, "sdr/fft.Convolve: Lengths do not match exactly");
-    const size_t n = src_len;
-    if (n == 0 || (n & (n - 1)) || !dst || !src || !freq)
-        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "convolve: power-of-two length and non-null buffers");
-    HZ_TRY(enter(ctx));
-    void *filt = nullptr;
-    HZ_HIP(ctx, hipMalloc(&filt, n * 8));
-    int rc = upload_filter(ctx, filt, freq, n * 8);
-    if (rc != HZSDR_OK) {
-        (void)hipFree(filt);
-        return rc;
-    }
-    *out = new hzsdr_conv{ctx, 0, dst, src, nullptr, n, filt};
-    return HZSDR_OK;
-}
-
-int hzsdr_convolve_create(hzsdr_ctx *ctx, void *dst, size_t dst_len, const void *iq1, size_t iq1_len,
-                          const void *iq2, size_t iq2_len, int mode, hzsdr_conv **out) {
-    using namespace hz;
-    if (!ctx || !out) return HZSDR_ERR_INVALID_ARGUMENT;
-    *out = nullptr;
-    if (iq1_len != iq2_len || iq1_len != dst_len)  // fft/convolution.go:37-39
-        return fail(ctx, HZSDR_ERR_LENGTH_MISMATCH, "sdr/fft: IQ/Dest buffer lengths do not match exactly");
-    const size_t n = iq1_len;
-    if (n == 0 || (n & (n - 1)) || !dst || !iq1 || !iq2)
-        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "convolve: power-of-two length and non-null buffers");
-    if (mode != HZSDR_CONV_CONVOLVE && mode != HZSDR_CONV_CROSS_CORRELATE) return HZSDR_ERR_INVALID_ARGUMENT;
-    *out = new hzsdr_conv{ctx, mode == HZSDR_CONV_CONVOLVE ? 1 : 2, dst, iq1, iq2, n, nullptr};
-    return HZSDR_OK;
-}
-
-int hzsdr_conv_exec(hzsdr_conv *cv) {
-    using namespace hz;
-    if (!cv) return HZSDR_ERR_INVALID_ARGUMENT;
-    hzsdr_ctx *ctx = cv->ctx;
-    HZ_TRY(enter(ctx));
-    const size_t bytes = cv->n * 8;
-    Stage st(ctx);
-    const void *d1, *d2 = nullptr;
-    void *dd;
-    HZ_TRY(st.in(0, cv->src1, bytes, &d1));
-    if (cv->kind != 0) HZ_TRY(st.in(2, cv->src2, bytes, &d2));
-    HZ_TRY(st.out(1, cv->dst, bytes, &dd));
-    if (cv->kind == 0 && fft_lds_ok(cv->n)) {
-        EwProgram P{};
-        HZ_TRY(conv_blocks_device(ctx, HZSDR_FMT_C64, cv->n, d1, dd, cv->filt, 1, 1, 0, P));
-    } else {
-        HZ_TRY(conv_generic_device(ctx, dd, d1, cv->kind == 0 ? cv->filt : d2, cv->n, cv->kind));
-    }
-    return st.finish();
-}
-
-int hzsdr_conv_set_filter(hzsdr_conv *cv, const void *freq, size_t freq_len) {
-    using namespace hz;
-    if (!cv) return HZSDR_ERR_INVALID_ARGUMENT;
-    hzsdr_ctx *ctx = cv->ctx;
-    if (cv->kind != 0 || !freq) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "conv: not a ConvolveFreq closure");
-    if (freq_len != cv->n) return fail(ctx, HZSDR_ERR_LENGTH_MISMATCH, "sdr/fft.Convolve: Lengths do not match exactly");
-    HZ_TRY(enter(ctx));
-    return upload_filter(ctx, cv->filt, freq, cv->n * 8);  // stream-ordered after earlier execs
-}
-
-int hzsdr_conv_free(hzsdr_conv *cv) {
-    if (!cv) return HZSDR_ERR_INVALID_ARGUMENT;
-    (void)hipSetDevice(cv->ctx->device);
-    (void)hipStreamSynchronize(cv->ctx->stream);
-    if (cv->filt) (void)hipFree(cv->filt);
-    delete cv;
-    return HZSDR_OK;
-}
-
-int hzsdr_convolution_blocks(hzsdr_ctx *ctx, void *out, size_t out_len, const void *in, size_t in_len,
-                             const void *filter_freq, size_t filter_len, size_t *n_out) {
-    using namespace hz;
-    if (n_out) *n_out = 0;
-    if (!ctx) return HZSDR_ERR_INVALID_ARGUMENT;
-    if (!fft_lds_ok(filter_len) || !filter_freq)
-        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "convolution: filter length must be a power of two in 4..8192");
-    const size_t nblocks = in_len / filter_len, n = nblocks * filter_len;
-    if (out_len < n) return fail(ctx, HZSDR_ERR_DST_TOO_SMALL, "convolution: output buffer too small");
-    if (n && (!in || !out)) return HZSDR_ERR_INVALID_ARGUMENT;
-    HZ_TRY(enter(ctx));
-    if (n == 0) return HZSDR_OK;
-    Stage st(ctx);
-    const void *din, *dfilt;
-    void *dout;
-    HZ_TRY(st.in(0, in, n * 8, &din));
-    HZ_TRY(st.in(2, filter_freq, filter_len * 8, &dfilt));
-    HZ_TRY(st.out(1, out, n * 8, &dout));
-    EwProgram P{};
-    HZ_TRY(conv_blocks_device(ctx, HZSDR_FMT_C64, filter_len, din, dout, dfilt, nblocks, 1, 0, P));
-    HZ_TRY(st.finish());
-    if (n_out) *n_out = n;
-    return HZSDR_OK;
-}
-
-}  // extern "C"
-
-// =============================================================================
-// Pinned ring in front of a chain: the memory a
-// stream.RingBuffer's IQBufferAllocator hands out (stream/ring.go:60-68) is ONE
-// hipHostMalloc region of slots * slot_length samples; each submitted slot goes
-// upload -> chain kernel -> download on three streams chained by events, so the
-// PCIe transfers of neighbouring slots overlap the kernel.
-// =============================================================================
-
-struct hzsdr_ring {
-    hzsdr_chain *chain = nullptr;
-    hzsdr_ctx *ctx = nullptr;
-    size_t slot_len = 0, out_len = 0;  // samples per slot in / out
-    int nslots = 0;
-    hipStream_t s_up = nullptr, s_down = nullptr;
-    char *pin_in = nullptr, *pin_out = nullptr;  // nslots * slot bytes each, contiguous
-    char *dev_in = nullptr, *dev_out = nullptr;
-    struct Slot {
-        hipEvent_t up = nullptr, done = nullptr, down = nullptr;
-        size_t n_out = 0;
-        int state = 0;  // 0 free, 1 acquired, 2 in flight
-    };
-    std::vector<Slot> slots;
-    size_t widx = 0, ridx = 0;  // next slot to acquire / to pop
-    int inflight = 0;
-    size_t in_bytes() const { return slot_len * (size_t)hz::format_size(chain->src_fmt); }
-    size_t out_bytes() const { return out_len * 8; }
-};
-
-extern "C" {
-
-int hzsdr_ring_free(hzsdr_ring *r) {
-    if (!r) return HZSDR_ERR_INVALID_ARGUMENT;
-    (void)hipSetDevice(r->ctx->device);
-    if (r->s_up) (void)hipStreamSynchronize(r->s_up);
-    (void)hipStreamSynchronize(r->ctx->stream);
-    if (r->s_down) (void)hipStreamSynchronize(r->s_down);
-    for (auto &s : r->slots) {
-        if (s.up) (void)hipEventDestroy(s.up);
-        if (s.done) (void)hipEventDestroy(s.done);
-        if (s.down) (void)hipEventDestroy(s.down);
-    }
-    for (char *p : {r->pin_in, r->pin_out})
-        for (size_t i = 0; p && i < r->ctx->pinned_ranges.size(); i++)
-            if (r->ctx->pinned_ranges[i].first == p) {
-                r->ctx->pinned_ranges.erase(r->ctx->pinned_ranges.begin() + (long)i);
-                break;
-            }
-    if (r->pin_in) (void)hipHostFree(r->pin_in);
-    if (r->pin_out) (void)hipHostFree(r->pin_out);
-    if (r->dev_in) (void)hipFree(r->dev_in);
-    if (r->dev_out) (void)hipFree(r->dev_out);
-    if (r->s_up) (void)hipStreamDestroy(r->s_up);
-    if (r->s_down) (void)hipStreamDestroy(r->s_down);
-    delete r;
-    return HZSDR_OK;
-}
-
-int hzsdr_ring_create(hzsdr_chain *c, size_t slot_length, int slots, hzsdr_ring **out) {
-    using namespace hz;
-    if (!c || !out) return HZSDR_ERR_INVALID_ARGUMENT;
-    *out = nullptr;
-    hzsdr_ctx *ctx = c->ctx;
-    if (slots < 2 || slots > 64 || slot_length == 0)
-        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "ring: needs 2..64 slots of at least one sample");
-    size_t cons, outn;
-    hzsdr_chain_plan(c, slot_length, &cons, &outn);
-    if (cons != slot_length)
-        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "ring: slot length must be a whole number of the chain's blocks");
-    HZ_TRY(enter(ctx));
-    hzsdr_ring *r = new hzsdr_ring();
-    r->chain = c;
-    r->ctx = ctx;
-    r->slot_len = slot_length;
-    r->out_len = outn ? outn : 1;
-    r->nslots = slots;
-    r->slots.resize(slots);
-#define HZ_RING(call)                                                         \
-    do {                                                                      \
-        hipError_t e__ = (call);                                              \
-        if (e__ != hipSuccess) {                                              \
-            int rc__ = hip_fail(ctx, e__, #call, __FILE__, __LINE__);         \
-            hzsdr_ring_free(r);                                               \
-            return rc__;                                                      \
-        }                                                                     \
-    } while (0)
-    HZ_RING(hipStreamCreateWithFlags(&r->s_up, hipStreamNonBlocking));
-    HZ_RING(hipStreamCreateWithFlags(&r->s_down, hipStreamNonBlocking));
-    HZ_RING(hipHostMalloc((void **)&r->pin_in, r->in_bytes() * slots, hipHostMallocDefault));
-    HZ_RING(hipHostMalloc((void **)&r->pin_out, r->out_bytes() * slots, hipHostMallocDefault));
-    HZ_RING(hipMalloc((void **)&r->dev_in, r->in_bytes() * slots));
-    HZ_RING(hipMalloc((void **)&r->dev_out, r->out_bytes() * slots));
-    // ring slots are pinned and GPU-visible: any HOST-space call on them skips its staging
-    ctx->pinned_ranges.push_back({r->pin_in, r->in_bytes() * slots});
-    ctx->pinned_ranges.push_back({r->pin_out, r->out_bytes() * slots});
-    for (auto &s : r->slots) {
-        HZ_RING(hipEventCreateWithFlags(&s.up, hipEventDisableTiming));
-        HZ_RING(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-        HZ_RING(hipEventCreateWithFlags(&s.down, hipEventDisableTiming));
-    }
-#undef HZ_RING
-    *out = r;
-    return HZSDR_OK;
-}
-
-int hzsdr_ring_iq_buffer(const hzsdr_ring *r, void **base, size_t *n_samples, size_t *slot_length) {
-    if (!r) return HZSDR_ERR_INVALID_ARGUMENT;
-    if (base) *base = r->pin_in;
-    if (n_samples) *n_samples = r->slot_len * (size_t)r->nslots;
-    if (slot_length) *slot_length = r->slot_len;
-    return HZSDR_OK;
-}
-
-int hzsdr_ring_acquire(hzsdr_ring *r, int *slot, void **iq) {
-    using namespace hz;
-    if (!r || !slot) return HZSDR_ERR_INVALID_ARGUMENT;
-    const int i = (int)(r->widx % (size_t)r->nslots);
-    if (r->slots[i].state != 0)
-        return fail(r->ctx, HZSDR_ERR_DST_TOO_SMALL, "ring: every slot is in flight (pop first)");  // the overrun case
-    r->slots[i].state = 1;
-    *slot = i;
-    if (iq) *iq = r->pin_in + (size_t)i * r->in_bytes();
-    return HZSDR_OK;
-}
-
-int hzsdr_ring_submit(hzsdr_ring *r, int slot, size_t n) {
-    using namespace hz;
-    if (!r || slot < 0 || slot >= r->nslots) return HZSDR_ERR_INVALID_ARGUMENT;
-    hzsdr_ctx *ctx = r->ctx;
-    auto &s = r->slots[slot];
-    if (s.state != 1 || slot != (int)(r->widx % (size_t)r->nslots))
-        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "ring: submit of a slot that is not the acquired one");
-    size_t cons, outn;
-    hzsdr_chain_plan(r->chain, n, &cons, &outn);
-    if (n == 0 || n > r->slot_len || cons != n)
-        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "ring: a slot must hold a whole number of the chain's blocks");
-    HZ_TRY(enter(ctx));
-    const size_t fs = (size_t)format_size(r->chain->src_fmt);
-    char *hin = r->pin_in + (size_t)slot * r->in_bytes(), *din = r->dev_in + (size_t)slot * r->in_bytes();
-    char *hout = r->pin_out + (size_t)slot * r->out_bytes(), *dout = r->dev_out + (size_t)slot * r->out_bytes();
-    HZ_HIP(ctx, hipMemcpyAsync(din, hin, n * fs, hipMemcpyHostToDevice, r->s_up));
-    HZ_HIP(ctx, hipEventRecord(s.up, r->s_up));
-    HZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.up, 0));
-    double ts;
-    HZ_TRY(chain_launch(r->chain, din, n, dout, outn, &ts));
-    HZ_HIP(ctx, hipGetLastError());
-    r->chain->ts = ts;
-    HZ_HIP(ctx, hipEventRecord(s.done, ctx->stream));
-    HZ_HIP(ctx, hipStreamWaitEvent(r->s_down, s.done, 0));
-    HZ_HIP(ctx, hipMemcpyAsync(hout, dout, outn * 8, hipMemcpyDeviceToHost, r->s_down));
-    HZ_HIP(ctx, hipEventRecord(s.down, r->s_down));
-    s.n_out = outn;
-    s.state = 2;
-    r->widx++;
-    r->inflight++;
-    return HZSDR_OK;
-}
-
-int hzsdr_ring_pop(hzsdr_ring *r, const void **out, size_t *n_out) {
-    using namespace hz;
-    if (!r) return HZSDR_ERR_INVALID_ARGUMENT;
-    hzsdr_ctx *ctx = r->ctx;
-    const int i = (int)(r->ridx % (size_t)r->nslots);
-    auto &s = r->slots[i];
-    if (s.state != 2) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "ring: nothing in flight");  // the underrun case
-    HZ_TRY(enter(ctx));
-    HZ_HIP(ctx, hipEventSynchronize(s.down));
-    if (out) *out = r->pin_out + (size_t)i * r->out_bytes();
-    if (n_out) *n_out = s.n_out;
-    s.state = 0;
-    r->ridx++;
-    r->inflight--;
-    return HZSDR_OK;
-}
-
-int hzsdr_ring_in_flight(const hzsdr_ring *r) { return r ? r->inflight : -1; }
 
 }  // extern "C"

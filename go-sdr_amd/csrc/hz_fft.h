@@ -1,5 +1,5 @@
 // hz_fft.h -- the workgroup-level FFT core shared by the Plan kernels
-// (hz_fft.hip) and the fused convolution / FIR-decimate kernels (hz_chain.hip).
+// (hz_fft.hip) and the fused convolution / FIR-decimate kernels (hz_conv.hip, hz_chain_fir.hip).
 //
 // Stockham autosort, power-of-two N, 4 <= N <= 8192, one transform per group of
 // TPT = min(256, N/4) lanes, data resident in LDS (N * 8 bytes) between passes:

@@ -1,4 +1,4 @@
-// hz_fft_api.h -- host-side entry points of hz_fft.hip used by hz_chain.hip.
+// hz_fft_api.h -- host-side entry points of hz_fft.hip used by hz_conv.hip and hz_chain_fir.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>

@@ -1,5 +1,5 @@
 // hz_firmm.hip -- the instantiations of the int8 matrix FIR kernel (hz_firmm.h) and their launcher,
-// in a translation unit of their own (they compile in parallel with hz_chain.hip, which plans the
+// in a translation unit of their own (they compile in parallel with hz_chain_fir.hip, which plans the
 // launch: mm_plan / mm_table_for).
 #include <algorithm>
 
