@@ -455,8 +455,13 @@ def main():
         # cfg 4: Downsample by 8 from i16 (5 B/input sample)
         xi = torch.from_numpy(synth_i16(4, n)).cuda()
         o8 = torch.zeros(n // 8, dtype=torch.complex64, device="cuda")
+        xis = [xi] + [torch.roll(xi, 1000 * (i + 1), 0) for i in range(5)]  # 6 x 80 MiB: past the cache
+        o8s = [o8] + [torch.zeros(n // 8, dtype=torch.complex64, device="cuda") for _ in range(5)]
         _, ms = timed(torch, lambda: ctx.downsample(o8, xi, 8), k, w)
         extra["downsample8_i16"] = rate(n, float(np.median(ms)), 5)
+        _, ms = timed_rot(torch, lambda i: ctx.downsample(o8s[i % 6], xis[i % 6], 8), k, w)
+        extra["downsample8_i16"]["hbm"] = dict(rate(n, float(np.median(ms)), 5), buffer_pairs=6)
+        del xis[1:], o8s[1:]
         # cfg 4, north-star form: a designed FIR-decimate by 8 from i16 (polyphase: 256 and 1024 taps; 4 + 8/8 B per
         # input sample), on the overlap-save transform kernels (i16 has no matrix form)
         for nt in (256, 1024):
