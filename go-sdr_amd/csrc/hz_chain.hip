@@ -31,14 +31,23 @@ void nco_shift_ulp1_map4(hzsdr_ctx *ctx, void *buf, size_t nvec4, uint64_t base,
                        (const void *)buf, (float2 *)buf, nvec4, base, P);
 }
 
+// A call of shift_exact_kernel that touches `bytes` (an in-place buffer counted once) uses non-temporal loads and
+// stores from 96 MiB on: the next buffer of a stream then finds nothing of this one in the 256 MB memory-side cache
+// anyway, and past the cache the map takes 47.8 us per 2^24 samples where plain accesses take 53.9 (from the cache
+// the kernel is bound by its float64 instructions at ~46 us either way; tools/nco_ablate.hip, "rotation").
+static bool shift_streams_past_cache(size_t bytes) { return bytes >= ((size_t)96 << 20); }
+
 void nco_shift_exact_map2(hzsdr_ctx *ctx, void *buf, size_t nvec2, uint64_t base, double tau_shift, const NcoSegs &sg) {
     EwProgram P{};
     P.n = 1;
     P.op[0].kind = EW_SHIFT;
     P.op[0].tau_shift = tau_shift;
     P.segs = sg;
-    hipLaunchKernelGGL((shift_exact_kernel<HZSDR_FMT_C64, false>), dim3(blocks_for(ctx, (nvec2 + kShiftU - 1) / kShiftU)), dim3(kThreads), 0, ctx->stream,
-                       (const void *)buf, (float4 *)buf, nvec2, base, P);
+    const dim3 grid(blocks_for(ctx, (nvec2 + kShiftU - 1) / kShiftU, kShiftThreads)), block(kShiftThreads);
+    if (shift_streams_past_cache(nvec2 * 16))
+        hipLaunchKernelGGL((shift_exact_kernel<HZSDR_FMT_C64, false, true>), grid, block, 0, ctx->stream, (const void *)buf, (float4 *)buf, nvec2, base, P);
+    else
+        hipLaunchKernelGGL((shift_exact_kernel<HZSDR_FMT_C64, false>), grid, block, 0, ctx->stream, (const void *)buf, (float4 *)buf, nvec2, base, P);
 }
 
 template <int FMT>
@@ -55,9 +64,8 @@ static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, cons
     if (!ulp1 && (shape == SHAPE_SHIFT || shape == SHAPE_SHIFT_GAIN) && ok(2) && n >= 2) {
         // the bit-exact Shift (+ Gain): two samples per vector, the factor by sincos_narrow (shift_exact_kernel)
         const size_t nvec = n / 2;
-        const dim3 grid(blocks_for(ctx, (nvec + kShiftU - 1) / kShiftU)), block(kThreads);
-        // (a call whose bytes exceed what the memory-side cache can hold streams past it: hz_vector.hip, beamform_kernel)
-        const bool nt = in != out && (sizeof(R) + 8) * n > ((size_t)192 << 20);
+        const dim3 grid(blocks_for(ctx, (nvec + kShiftU - 1) / kShiftU, kShiftThreads)), block(kShiftThreads);
+        const bool nt = shift_streams_past_cache(in == out ? 8 * n : (sizeof(R) + 8) * n);
         if (shape == SHAPE_SHIFT_GAIN && nt)
             hipLaunchKernelGGL((shift_exact_kernel<FMT, true, true>), grid, block, 0, ctx->stream, in, (float4 *)out, nvec, (uint64_t)0, P);
         else if (shape == SHAPE_SHIFT_GAIN)

@@ -284,18 +284,18 @@ __global__ __launch_bounds__(kThreads) void chain_map_kernel(const void *__restr
 // wave works the queue off behind the tile through ONE rolled copy of go_sincos.  (With go_sincos inline behind
 // each check the straight path lost more to the compiler's register and code layout than the check saves;
 // tools/nco_ablate.hip.)
-constexpr int kShiftU = 4;
+constexpr int kShiftU = 4, kShiftThreads = 128;  // (two waves per workgroup: 46.5 us where four take 47.8, tools/nco_ablate.hip)
 template <int FMT, bool GAIN, bool NT = false>
-__global__ __launch_bounds__(kThreads) void shift_exact_kernel(const void *in, float4 *out, size_t nvec, uint64_t base, EwProgram P) {
+__global__ __launch_bounds__(kShiftThreads) void shift_exact_kernel(const void *in, float4 *out, size_t nvec, uint64_t base, EwProgram P) {
     using R = typename Raw<FMT>::t;
     struct alignas(sizeof(R) * 2) RV { R v[2]; };
-    constexpr int U = kShiftU, kW = kThreads / 64;
+    constexpr int U = kShiftU, kW = kShiftThreads / 64, TPB = kShiftThreads;
     __shared__ unsigned q_n[kW];
     __shared__ unsigned short q[kW][64 * U];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) q_n[wave] = 0;
     const double tau_shift = P.op[0].tau_shift;
-    const size_t tile = (size_t)kThreads * U;
+    const size_t tile = (size_t)TPB * U;
     for (size_t t0 = (size_t)blockIdx.x * tile; t0 < nvec; t0 += (size_t)gridDim.x * tile) {
         const uint64_t j_lo = base + 2 * t0;
         const NcoWin w = nco_window(P.segs, j_lo, j_lo + 2 * tile - 1);
@@ -314,14 +314,14 @@ __global__ __launch_bounds__(kThreads) void shift_exact_kernel(const void *in, f
             RV a[U];
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const RV *const p = (const RV *)in + (t0 + (size_t)u * kThreads + threadIdx.x);
+                const RV *const p = (const RV *)in + (t0 + (size_t)u * TPB + threadIdx.x);
                 a[u] = NT ? nt_load(p) : *p;
             }
             const double k0 = (double)((uint32_t)d0 + 2u * threadIdx.x);
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 float sl, cl, sh, ch;
-                const double kl = k0 + (double)(2 * u * kThreads), kh = k0 + (double)(2 * u * kThreads + 1);  // (exact)
+                const double kl = k0 + (double)(2 * u * TPB), kh = k0 + (double)(2 * u * TPB + 1);  // (exact)
                 bool ok = sincos_narrow(__dmul_rn(tau_shift, __fma_rn(kl, step, tb)), sl, cl);  // stream/shifter.go:81
                 ok &= sincos_narrow(__dmul_rn(tau_shift, __fma_rn(kh, step, tb)), sh, ch);
                 float2 l = go_cmul(Raw<FMT>::cvt(a[u].v[0]), make_float2(cl, sl));  // :82
@@ -331,14 +331,14 @@ __global__ __launch_bounds__(kThreads) void shift_exact_kernel(const void *in, f
                     h = make_float2(__fmul_rn(h.x, P.op[1].a), __fmul_rn(h.y, P.op[1].a));
                 }
                 if (ok) {
-                    float4 *const p = out + (t0 + (size_t)u * kThreads + threadIdx.x);
+                    float4 *const p = out + (t0 + (size_t)u * TPB + threadIdx.x);
                     if (NT) nt_store(p, make_float4(l.x, l.y, h.x, h.y)); else *p = make_float4(l.x, l.y, h.x, h.y);
-                } else q[wave][atomicAdd(&q_n[wave], 1u)] = (unsigned short)(u * kThreads + threadIdx.x);
+                } else q[wave][atomicAdd(&q_n[wave], 1u)] = (unsigned short)(u * TPB + threadIdx.x);
             }
         } else {
 #pragma unroll 1
             for (int u = 0; u < U; u++)
-                if (t0 + (size_t)u * kThreads + threadIdx.x < nvec) q[wave][atomicAdd(&q_n[wave], 1u)] = (unsigned short)(u * kThreads + threadIdx.x);
+                if (t0 + (size_t)u * TPB + threadIdx.x < nvec) q[wave][atomicAdd(&q_n[wave], 1u)] = (unsigned short)(u * TPB + threadIdx.x);
         }
         const unsigned nq = q_n[wave];  // (the LDS operations of one wave complete in order)
         if (nq) {

@@ -203,7 +203,7 @@ template <int MEM, int U, int TPB, int SLOW> static void run2(float4 *buf, size_
 // copy of go_sincos; tiles that are not one full clock run inside the straight range go to the queue whole
 __device__ __forceinline__ bool narrow_b(double x, float &sn, float &cs) { return sincos_narrow(x, sn, cs); }
 
-template <int U, int TPB>
+template <int U, int TPB, int NT = 0>
 __global__ __launch_bounds__(TPB) void k_shift3(float4 *buf, size_t nvec, uint64_t base, double tau_shift, NcoSegs sg) {
     constexpr int kW = TPB / 64;
     __shared__ unsigned q_n[kW];
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(TPB) void k_shift3(float4 *buf, size_t nvec, uint64
         if (__builtin_amdgcn_readfirstlane((int)fast)) {
             float4 a[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) a[u] = buf[t0 + (size_t)u * TPB + threadIdx.x];
+            for (int u = 0; u < U; u++) a[u] = NT ? nt_load(buf + (t0 + (size_t)u * TPB + threadIdx.x)) : buf[t0 + (size_t)u * TPB + threadIdx.x];
             const double k0 = (double)((uint32_t)d0 + 2u * threadIdx.x);
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -236,8 +236,10 @@ __global__ __launch_bounds__(TPB) void k_shift3(float4 *buf, size_t nvec, uint64
                 ok &= narrow_b(__dmul_rn(tau_shift, __fma_rn(kh, step, tb)), sh, ch);
                 const float2 l = go_cmul(make_float2(a[u].x, a[u].y), make_float2(cl, sl));
                 const float2 h = go_cmul(make_float2(a[u].z, a[u].w), make_float2(ch, sh));
-                if (ok) buf[t0 + (size_t)u * TPB + threadIdx.x] = make_float4(l.x, l.y, h.x, h.y);
-                else q[wave][atomicAdd(&q_n[wave], 1u)] = (unsigned short)(u * TPB + threadIdx.x);
+                if (ok) {
+                    if (NT) nt_store(buf + (t0 + (size_t)u * TPB + threadIdx.x), make_float4(l.x, l.y, h.x, h.y));
+                    else buf[t0 + (size_t)u * TPB + threadIdx.x] = make_float4(l.x, l.y, h.x, h.y);
+                } else q[wave][atomicAdd(&q_n[wave], 1u)] = (unsigned short)(u * TPB + threadIdx.x);
             }
         } else {
 #pragma unroll 1
@@ -285,6 +287,29 @@ template <int U, int TPB> static void run3(float4 *buf, size_t nvec, unsigned gr
         if (r >= 3) { best = ms < best ? ms : best; sum += ms; }
     }
     printf("v3 U %d TPB %3d grid %6zu  %-24s min %.1f us  avg %.1f us\n", U, TPB, blocks, what, best * 1e3f, sum / reps * 1e3f);
+}
+
+// the third cut in place over a ROTATION of eight buffers (1 GiB: every call's bytes from HBM and to it)
+template <int U, int TPB, int NT> static void run3_rot(float4 **bufs, size_t nvec, unsigned grid_mult, const char *what) {
+    NcoSegs sg{};
+    sg.n = 1;
+    sg.first[0] = 0, sg.t0[0] = 0.0, sg.step[0] = 1.0 / 20e6;
+    const double tau_shift = (M_PI * 2) * 2.5e6;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const size_t tile = (size_t)TPB * U;
+    size_t blocks = (nvec + tile - 1) / tile;
+    if (grid_mult) blocks = blocks < 256u * grid_mult ? blocks : 256u * grid_mult;
+    const int reps = 64;
+    for (int r = 0; r < 16; r++) hipLaunchKernelGGL((k_shift3<U, TPB, NT>), dim3((unsigned)blocks), dim3(TPB), 0, 0, bufs[r % 8], nvec, (uint64_t)0, tau_shift, sg);
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL((k_shift3<U, TPB, NT>), dim3((unsigned)blocks), dim3(TPB), 0, 0, bufs[r % 8], nvec, (uint64_t)0, tau_shift, sg);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("v3 rotation U %d TPB %3d NT %d grid %6zu  %-20s %.1f us per call\n", U, TPB, NT, blocks, what, ms / reps * 1e3f);
 }
 
 template <int SC, int MEM, int U, int TPB> static void run(float4 *buf, size_t nvec, unsigned grid_mult, const char *what) {
@@ -381,5 +406,19 @@ int main() {
     run3<4, 256>(buf, nvec, 16, "third cut");
     run3<4, 128>(buf, nvec, 0, "third cut");
     run3<4, 512>(buf, nvec, 0, "third cut");
+    {
+        float4 *bufs[8];
+        for (int b = 0; b < 8; b++) { CK(hipMalloc(&bufs[b], n * 8)); CK(hipMemset(bufs[b], 0, n * 8)); }
+        run3_rot<4, 256, 0>(bufs, nvec, 0, "plain");
+        run3_rot<4, 256, 1>(bufs, nvec, 0, "non-temporal");
+        run3_rot<2, 256, 0>(bufs, nvec, 0, "plain");
+        run3_rot<2, 256, 1>(bufs, nvec, 0, "non-temporal");
+        run3_rot<4, 128, 0>(bufs, nvec, 0, "plain");
+        run3_rot<4, 128, 1>(bufs, nvec, 0, "non-temporal");
+        run3_rot<2, 128, 1>(bufs, nvec, 0, "non-temporal");
+        run3_rot<4, 256, 1>(bufs, nvec, 16, "non-temporal");
+        run3_rot<8, 256, 1>(bufs, nvec, 0, "non-temporal");
+        run3_rot<4, 256, 0>(bufs, nvec, 0, "plain (again)");
+    }
     return 0;
 }
