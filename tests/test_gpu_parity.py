@@ -811,6 +811,52 @@ def test_chain_convert_shift_gain_equals_separate_ops(env, orc):
     ch.close()
 
 
+@pytest.mark.parametrize("fmt,gain", [("u8", None), ("i8", 0.25), ("i16", None), ("c64", 3.0)])
+def test_chain_shift_from_every_source_format_bit_exact(env, orc, fmt, gain):
+    """shift_exact_kernel behind each converter (Shift, and Shift then Gain): the converter's float32, the factor and the
+    product bit for bit as the separate reference operations give them; a clock that crosses run boundaries."""
+    hz = env.hz
+    rate, shift, n = 2_400_000, -333_333.25, 262_144 + 2
+    x = {"u8": rand_u8, "i8": rand_i8, "i16": rand_i16, "c64": rand_c64}[fmt](21, n)
+    want = zeros("c64", n)
+    orc.convert(want, x)
+    ref = orc.Shifter(rate)
+    ref.ts.value = 6.1
+    ref(shift, want)
+    if gain is not None:
+        orc.scale(want, gain)
+    ch = env.ctx.chain({"u8": hz.FMT_U8, "i8": hz.FMT_I8, "i16": hz.FMT_I16, "c64": hz.FMT_C64}[fmt], rate).shift(shift)
+    if gain is not None:
+        ch = ch.gain(gain)
+    ch.set_time(6.1)
+    out = env.zeros("c64", n)
+    assert ch.run(env.put(x), out) == (n, n)
+    assert bits_equal(env.get(out), want)
+    ch.close()
+
+
+def test_chain_shift_gain_past_the_cache_bit_exact(hz, orc):
+    """A call of 128 MiB takes the non-temporal form of shift_exact_kernel (out of place, 2^23 c64 samples): the same
+    bits as the oracle."""
+    import torch
+    n, rate, shift, gain = 1 << 23, 20_000_000, 2.5e6, 0.5
+    x = rand_c64(55, n)
+    want = x.copy()
+    ref = orc.Shifter(rate)
+    ref.ts.value = 1.75
+    ref(shift, want)
+    orc.scale(want, gain)
+    ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+    ch = ctx.chain(hz.FMT_C64, rate).shift(shift).gain(gain)
+    ch.set_time(1.75)
+    out = torch.zeros(n, dtype=torch.complex64, device="cuda")
+    assert ch.run(torch.from_numpy(x).cuda(), out) == (n, n)
+    ctx.synchronize()
+    assert bits_equal(out.cpu().numpy(), want)
+    ch.close()
+    ctx.close()
+
+
 def test_chain_shift_ulp1_is_within_one_ulp_of_the_factor(env, orc):
     """hzsdr_chain_shift_ulp1 (opt-in): unit inputs, so the output IS the rotation factor times the gain 1.
     The reference's factor is complex64(math.Sincos(float64 phase)) = the true value rounded once (half an
