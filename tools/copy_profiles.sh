@@ -4,13 +4,15 @@ set -u
 tag=${1:-r04}
 src=gpurun_out/prof_$tag
 cp $src/bench.json profiles/${tag}_bench.json
-cp $src/bench_trace/*/*kernel_stats.csv profiles/${tag}_bench_kernel_stats.csv
-cp $src/kern_trace/*/*kernel_stats.csv profiles/${tag}_kernels_kernel_stats.csv
-cp $src/fft_trace/*/*kernel_stats.csv profiles/${tag}_fft_kernel_stats.csv
+# (a directory collects one file set per profiled process and run: the newest is this collection's)
+newest() { ls -t $1 | head -1; }
+cp $(newest "$src/bench_trace/*/*kernel_stats.csv") profiles/${tag}_bench_kernel_stats.csv
+cp $(newest "$src/kern_trace/*/*kernel_stats.csv") profiles/${tag}_kernels_kernel_stats.csv
+cp $(newest "$src/fft_trace/*/*kernel_stats.csv") profiles/${tag}_fft_kernel_stats.csv
 cp $src/traffic.json profiles/${tag}_traffic.json
 for c in FETCH_SIZE WRITE_SIZE; do
   d=$src/pmc_fetch; [ $c = WRITE_SIZE ] && d=$src/pmc_write
-  f=$(ls $d/*/*_counter_collection.csv | head -1)
+  f=$(newest "$d/*/*_counter_collection.csv")
   (head -1 $f; grep "hz::" $f) > profiles/${tag}_pmc_$c.csv
 done
 for t in sq_counters fir_ablate host_path mfma_fir mfma_fir2 mfma_rate firmm_probe pk_glitch mm2_glitch mm2_glitch_unpatched_build mfma_hazard repeat_check nco_ablate copy_rate issue_rate conv_time shift_in_place; do [ -f $src/$t.txt ] && cp $src/$t.txt profiles/${tag}_$t.txt; done
