@@ -142,7 +142,9 @@ static void launch_convert(hzsdr_ctx *ctx, const void *src, void *dst, size_t nc
     const bool aligned = ((uintptr_t)s % (sizeof(S) * G::K) == 0) && ((uintptr_t)d % (sizeof(D) * G::K) == 0);
     size_t nvec = aligned ? ncomp / G::K : 0;
     if (nvec) {
-        hipLaunchKernelGGL((convert_vec_kernel<C, SW>), dim3(blocks_for(ctx, (nvec + 3) / 4)), dim3(kThreads),
+        // (one vector per lane up to the grid's cap of 128 workgroups per CU, the kernel's four-deep loop only beyond:
+        // u8 -> c64 over 2^24 samples 26.7 us instead of 27.5 from the cache, 35.5 instead of 36.7 from HBM)
+        hipLaunchKernelGGL((convert_vec_kernel<C, SW>), dim3(blocks_for(ctx, nvec)), dim3(kThreads),
                            0, ctx->stream, s, d, nvec, arg);
     }
     size_t done = nvec * G::K;
