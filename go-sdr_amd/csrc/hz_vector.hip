@@ -56,7 +56,7 @@ static void launch_map(hzsdr_ctx *ctx, void *buf, size_t n, Op op) {
     size_t tail = n - head - 2 * nvec;
     if (head) hipLaunchKernelGGL(map_inplace_scalar<Op>, dim3(1), dim3(64), 0, ctx->stream, p, head, op);
     if (nvec)
-        hipLaunchKernelGGL(map_inplace_vec<Op>, dim3(blocks_for(ctx, (nvec + 3) / 4)), dim3(kThreads), 0,
+        hipLaunchKernelGGL(map_inplace_vec<Op>, dim3(blocks_for(ctx, nvec)), dim3(kThreads), 0,  // (one vector per lane up to the grid cap: hz_convert.hip)
                            ctx->stream, (float4 *)(p + head), nvec, op);
     if (tail)
         hipLaunchKernelGGL(map_inplace_scalar<Op>, dim3(1), dim3(64), 0, ctx->stream, p + head + 2 * nvec, tail, op);
