@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kThreads) void chain_map_kernel(const void *__restr
 // at two thirds of its vector instructions (which bound it: 45 float64 instructions per sample there, 38 here,
 // and the quadrant logic in float32).  A lane holds U vectors of two samples; a tile that is ONE clock run whose
 // phases stay inside sincos_narrow's range takes the straight path: the clock by one exact fma from the lane's
-// run offset, the factor from sincos_narrow.  The vectors a lane cannot decide there (2^-18 of them), and every
+// run offset, the factor from sincos_narrow.  The vectors a lane cannot decide there (2^-19 of them), and every
 // vector of any other tile (a run boundary inside, the ragged last tile, tiny or huge phases, the long clock
 // table), go to the wave's queue in LDS -- their input is left where it is: the map may be in place -- and the
 // wave works the queue off behind the tile through ONE rolled copy of go_sincos.  (With go_sincos inline behind

@@ -236,9 +236,9 @@ __device__ __forceinline__ void go_sincos(double x, double &sn, double &cs) {
 // by at most a few units in its last place: 2^-52 relative at worst over 2e8 arguments up to 2^29, random and
 // within 4 ulp of multiples of pi/4.  float32 drops mantissa bits 28..0 and rounds at their half point; a result
 // whose dropped bits lie more than 128 units (2^-46 .. 2^-45 of its value: 64 times the worst difference seen) from
-// that point narrows the same way as every float64 that close to it, math.Sincos' among them.  Elsewhere -- 2^-20
-// of the values -- the function returns false and the caller evaluates go_sincos.  The quadrant's exchange and
-// signs are applied to the float32 pair (exact either side of the narrowing).
+// that point narrows the same way as every float64 that close to it, math.Sincos' among them.  Elsewhere -- 2^-21
+// of the components, 2^-20 of the factors -- the function returns false and the caller evaluates go_sincos.  The
+// quadrant's exchange and signs are applied to the float32 pair (exact either side of the narrowing).
 __device__ __forceinline__ bool sincos_narrow(double x, float &sn, float &cs) {
     const double PI4A = 7.85398125648498535156e-1, PI4B = 3.77489470793079817668e-8, PI4C = 2.69515142907905952645e-15;
     const double M4PI = 1.27323954473516268615107010698;

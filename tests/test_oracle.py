@@ -315,7 +315,7 @@ def test_sincos_narrow_never_accepts_a_pair_that_differs_from_math_sincos(orc):
         xs = xs[(np.abs(xs) < 536870912.0) & ((np.abs(xs) >= 2.0 ** -60) | (xs == 0))]
         accepted, wrong = orc.sincos_narrow_check(xs)
         assert wrong == 0
-        assert accepted >= xs.size * (1 - 2e-5) - 2  # the queue stays short: 2^-20 of the values per component
+        assert accepted >= xs.size * (1 - 2e-5) - 2  # the queue stays short: 2^-20 of the factors
 
 
 def test_shift_roundtrip_kat(orc, kats):
