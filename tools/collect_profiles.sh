@@ -35,6 +35,7 @@ tools/bin/mfma_hazard 2000 > $out/mfma_hazard.txt 2>&1
 tools/bin/nco_ablate > $out/nco_ablate.txt 2>&1
 tools/bin/copy_rate > $out/copy_rate.txt 2>&1
 tools/bin/issue_rate > $out/issue_rate.txt 2>&1
+timeout 600 tools/bin/narrow_check 40 > $out/narrow_check_device.txt 2>&1
 python3 tools/conv_time.py 2>&1 | grep " us" > $out/conv_time.txt
 python3 tools/inplace_test.py 2>&1 | grep " us" > $out/shift_in_place.txt
 timeout 900 python3 tools/repeat_check.py 500 > $out/repeat_check.txt 2>&1
