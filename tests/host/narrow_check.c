@@ -1,6 +1,6 @@
 /* narrow_check.c -- the claim of sincos_narrow (csrc/hz_device.h) over many more phases than the test suite's 9e6:
  * oracle/hzsdr_oracle.c's restatement of the device function against its restatement of math.Sincos, on every core.
- *   gcc -O2 -ffp-contract=off -fopenmp tools/narrow_check.c oracle/hzsdr_oracle.c oracle/oracle_parallel.c -lm -o /tmp/narrow_check
+ *   gcc -O2 -ffp-contract=off -fopenmp tests/host/narrow_check.c oracle/hzsdr_oracle.c oracle/oracle_parallel.c -lm -o /tmp/narrow_check
  *   /tmp/narrow_check 2000000000
  * Phases: a third uniform over +-10^u, u in [-17, 8.7]; a third within 3 ulp of multiples of pi/4 up to 2^29; a third
  * tau shift ts as the kernel forms it (ts = k / fs exactly linear, fs and shift random). */

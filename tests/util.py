@@ -87,7 +87,7 @@ def in_epsilon(expected, actual, eps):
 FIR_ABS = 6e-7
 FIR_REL_L2 = 3e-7
 # The two mixer orders against EACH OTHER.  Each is a float32 FFT pipeline of ~45 sequential
-# roundings (1.6e-7 .. 2.0e-7 relative L2 from the oracle, tools/accuracy_probe.py) whose
+# roundings (1.6e-7 .. 2.0e-7 relative L2 from the oracle, tests/accuracy_probe.py) whose
 # rounding errors are independent of the other's, so their distance measures sqrt(2) times
 # that: 2.1e-7 .. 2.5e-7 on the cases here.  A late-mixer defect (a wrong modulated-tap
 # spectrum, a phase slip of 1e-6 rad) shows up as 1e-6 or more.
