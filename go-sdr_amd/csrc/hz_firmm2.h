@@ -217,19 +217,17 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
             pre_issued = true;
         }
     }
-    // ---- the small tasks: waves 4-7 of a workgroup, in front of and behind its first barrier -----------------
+    // ---- the small tasks: waves 0-3 of a workgroup, behind their last pass (the calls are at the kernel's end) ------
     // A FIX-UP TASK = 16 outputs in reference order (direct form, float64).  One wave alone took 18-27 us over one
-    // (measured: ~3000 instructions per lane, every load a full trip): workgroup t takes task t, its four young
+    // (measured: ~3000 instructions per lane, every load a full trip): workgroup t takes task t, its four old
     // waves stage the window's 1144 samples together (load, convert, the elementwise program: five per thread,
-    // all loads in flight at once) into a scratch of their own in LDS while the workgroup's first bytes and
-    // table are on their way, and behind the barrier the same 256 threads -- 16 per output, 64 taps each -- sum
-    // and store.  The matrix pipes are idle for the kernel's first ~5 us anyway.  At most ONE per workgroup: a
-    // call with more fix-up tasks than workgroups keeps the transform kernels (the host).
-    // A HISTORY TASK = 64 samples of the next call's history, one wave (4-7) each.
+    // all loads in flight at once) into a scratch of their own in LDS while the young waves run the workgroup's
+    // last pass, and behind the barrier the same 256 threads -- 16 per output, 64 taps each -- sum and store.  One
+    // per workgroup and round: a call with more fix-up tasks than four rounds keeps the transform kernels (the host).
+    // A HISTORY TASK = 64 samples of the next call's history, one old wave each.
     using RWT = typename Raw<FMT>::t;
     uint32_t fix_m0 = 0;
     int fix_cnt = 0;
-    bool tasks_backed = false;
     // (the tasks' scratch in LDS behind the slots: the window's samples, the taps beside them)
     auto task_xs = [&](const Geom &G) { return reinterpret_cast<float2 *>(mm_lds + 2 * table_lds(G.ne) + kCtlBytes + (size_t)kWaves * slot_bytes(D, G.ks)); };
     auto tasks_front_cold = [&](int round, const void *in, const float2 *hist, float2 *new_hist, const uint8_t *rhist, uint8_t *new_rhist,
@@ -238,7 +236,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         float2 *const tl = xs + (G.ntaps + D * (kFixOut - 1));
         const int ftask = wb + round * L.grid;
         if (ftask < L.n_task) {
-            const int ct = tid - 64 * (kWaves / 2);  // 0 .. 255
+            const int ct = tid;  // 0 .. 255: the old waves
             const int k = find_le(F.task_first, F.n, ftask);
             fix_m0 = F.m_a[k] + (uint32_t)(ftask - F.task_first[k]) * kFixOut;
             fix_cnt = (int)min((uint32_t)kFixOut, F.m_b[k] - fix_m0);
@@ -302,7 +300,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     // Sincos' twenty-two polynomial constants, for one) is hoisted to the loop's head, i.e. into every launch's first
     // microseconds.
     auto tasks_front = [&](int round) {
-        if (wave < kWaves / 2) return;
+        if (wave >= kWaves / 2) return;
         if (wb + round * L.grid >= L.n_task) return;  // (what most workgroups of most calls find)
         if constexpr ((EXP & 4096) != 0) {
             tasks_front_cold(round, in, hist, new_hist, rhist, new_rhist, taps, n_in, G, L, P, F);
@@ -314,7 +312,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     auto tasks_back_cold = [&](float2 *out, const Geom &G) {
         float2 *const xs = task_xs(G);
         float2 *const tl = xs + (G.ntaps + D * (kFixOut - 1));
-        const int ct = tid - 64 * (kWaves / 2);
+        const int ct = tid;
         const int o = ct >> 4, sl = ct & 15;  // output, tap slice: sixteen lanes per output
         // a lane's 64 (ntaps / 16) taps as two packed float32 fma chains -- the reference's own arithmetic is float32
         // throughout; a chain of 64 terms stays below 1e-7 here -- and the sixteen lanes' partial sums in float64:
@@ -340,7 +338,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         fix_cnt = 0;
     };
     auto tasks_back = [&]() {  // behind the barrier that follows tasks_front
-        if (wave < kWaves / 2 || fix_cnt == 0) return;
+        if (wave >= kWaves / 2 || fix_cnt == 0) return;
         if constexpr ((EXP & 4096) != 0) {
             tasks_back_cold(out, G);
         } else {
@@ -568,7 +566,6 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     // group and the run B behind it are ONE queue (A's passes, B's passes); the next group slides on by one run (B
     // becomes A, its table stays) behind a barrier.
     auto has_passes = [&](int rr) { return rr < L.n && max(pb0, (uint32_t)L.pass_first[rr]) < min(pb1, (uint32_t)L.pass_end[rr]); };
-    tasks_front(0);
     int ra = 0;
     while (ra < L.n && !has_passes(ra)) ra++;
     Run ru = run0, rv = run0;
@@ -639,12 +636,6 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         if (tid == 0) *ctr = kEarly;
         __syncthreads();
         if (first_stamp) stamp(11);
-        if (first_group) {  // (the first group of the workgroup: the small tasks)
-            if constexpr ((EXP & 32) != 0) __builtin_amdgcn_s_setprio(3);
-            tasks_back();
-            tasks_backed = true;
-            if constexpr ((EXP & 32) != 0) __builtin_amdgcn_s_setprio(1);
-        }
         if constexpr ((EXP & 32) != 0) {
             if (first_group) __builtin_amdgcn_s_setprio(1);
         }
@@ -863,13 +854,14 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         if (!has_passes(ra + 1)) break;
     }
     history_tasks();
-    if (!tasks_backed) {  // (a workgroup without a pass on the matrix path: its task's sums)
-        __syncthreads();
-        tasks_back();
-    }
+    // The fix-up tasks, BEHIND the passes: the old waves stage round 0's window while the young ones are still in
+    // the workgroup's last pass (~5 us of slack), the sums follow the barrier that ends the passes.  (Rounds 2-4
+    // did round 0 in front of the first pass -- "the matrix pipes idle there anyway" -- but the workgroup's first
+    // barrier then waited for the window's loads and the young waves started their passes behind the sums: a call
+    // with a clock boundary took 3-4 us longer than one without, four calls of 7.5.)
 #pragma unroll 1
-    for (int round = 1; wb + round * L.grid < L.n_task; round++) {  // (uniform: calls with more tasks than workgroups)
-        __syncthreads();
+    for (int round = 0; wb + round * L.grid < L.n_task; round++) {  // (uniform; round > 0: more tasks than workgroups)
+        if (round > 0) __syncthreads();
         tasks_front(round);
         __syncthreads();
         tasks_back();
