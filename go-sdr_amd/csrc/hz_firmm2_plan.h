@@ -226,7 +226,7 @@ inline bool plan_call(const PlanIn &in, const ClockRuns &cr, Plan *L, Fix *F, ui
     if (L->grid < 1) L->grid = 1;
     if (fix_outputs) *fix_outputs = fix_total;
     // the fix-up tasks are the slow way: a call that is mostly boundaries keeps the transforms; a workgroup takes
-    // them one at a time (the first in front of its passes, further ones behind them)
+    // them one at a time, behind its passes
     return !too_many && F->n_task <= 4 * L->grid && fix_total * 8 <= n_out;
 }
 
