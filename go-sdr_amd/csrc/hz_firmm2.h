@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                                 const float2 *taps, size_t n_in, const Geom &G, const Plan &L, const EwProgram &P, const Fix &F) {
         float2 *const xs = task_xs(G);
         float2 *const tl = xs + (G.ntaps + D * (kFixOut - 1));
-        const int ftask = wb + round * L.grid;
+        const int ftask = (L.grid - 1 - wb) + round * L.grid;  // (from the grid's far end: see the calls)
         if (ftask < L.n_task) {
             const int ct = tid;  // 0 .. 255: the old waves
             const int k = find_le(F.task_first, F.n, ftask);
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     // microseconds.
     auto tasks_front = [&](int round) {
         if (wave >= kWaves / 2) return;
-        if (wb + round * L.grid >= L.n_task) return;  // (what most workgroups of most calls find)
+        if ((L.grid - 1 - wb) + round * L.grid >= L.n_task) return;  // (what most workgroups of most calls find)
         if constexpr ((EXP & 4096) != 0) {
             tasks_front_cold(round, in, hist, new_hist, rhist, new_rhist, taps, n_in, G, L, P, F);
         } else {
@@ -860,7 +860,9 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     // barrier then waited for the window's loads and the young waves started their passes behind the sums: a call
     // with a clock boundary took 3-4 us longer than one without, four calls of 7.5.)
 #pragma unroll 1
-    for (int round = 0; wb + round * L.grid < L.n_task; round++) {  // (uniform; round > 0: more tasks than workgroups)
+    // (Task t of a round goes to workgroup grid - 1 - t: the history tasks sit on the first sixteen workgroups' old
+    // waves, and the few tasks of a call with one clock boundary should not queue up behind them.)
+    for (int round = 0; (L.grid - 1 - wb) + round * L.grid < L.n_task; round++) {  // (uniform; round > 0: more tasks than workgroups)
         if (round > 0) __syncthreads();
         tasks_front(round);
         __syncthreads();
