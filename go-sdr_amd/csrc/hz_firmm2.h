@@ -208,6 +208,8 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     // launch, and the path from the kernel's first instruction to this one decides when the matrix pipes start
     // (measured: 2.4 us of the kernel's first 5.5 went by between two stamps with ~300 instructions in between).
     // Waves 0-3 take passes pb0 .. pb0 + 3 when those lie in run 0 (the group loop below checks that it agrees).
+    // (The first run's TABLE asked for here as well, 0.7 us ahead of the group loop's head where it is: medians 37.8-38.4
+    // against 37.9-38.9 us, minima 36.7-36.9 against 36.3-36.4, interleaved on one box -- nothing, and not kept.)
     v4i x[KU];
     bool pre_issued = false;
     if (wave < kWaves / 2) {
