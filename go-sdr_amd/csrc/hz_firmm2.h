@@ -845,7 +845,9 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
             // No wave priorities in the library (EXP & 32 turns them on for study: the matrix pipe goes to the wave of
             // higher priority, then to the OLDER one, and ranking a wave on its first pass above one that has finished
             // a pass makes the two waves of a SIMD alternate pass by pass): the kernel is as fast without them
-            // (tools/mfma_fir2.hip: 38.6 against 38.9 us).
+            // (tools/mfma_fir2.hip: 38.6 against 38.9 us).  Round 4, tasks off the head: launch by launch with an event
+            // pair each (AB=1) the priorities are worth 0.4-1.8 us of the median -- and in bench.py's back-to-back
+            // stream they COST 0.6 us per step (0.0392 against 0.0386, three times over on one box).  Still off.
             if constexpr ((EXP & 32) != 0) __builtin_amdgcn_s_setprio(0);
             cur = nxt;
         }
