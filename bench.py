@@ -123,6 +123,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the per-config side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle TIMING (the parity check still runs)")
     ap.add_argument("--no-oracle", action="store_true", help="skip everything that needs oracle/ (profiling runs)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="the headline chain WITHOUT hzsdr_chain_pipeline: one launch behind the other, as rounds 1-3 measured")
     ap.add_argument("--buffers", type=int, default=12,
                     help="distinct 2^log2n-sample input buffers the steps rotate through (12 x 32 MiB of u8 "
                          "is more than the 256 MiB Infinity Cache: every step reads its input from HBM)")
@@ -178,6 +180,12 @@ def main():
     ys = [torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(min(nbuf, 4))]
     x, y = xs[0], ys[0]
     chain = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D)
+    # hzsdr_chain_pipeline (round 4): consecutive calls of the chain overlap -- the next launch's workgroups start on
+    # the compute units as this one's finish instead of behind its last one; bit-identical results, the inputs are
+    # resident and complete long before the calls (the mode's contract)
+    piped = not args.no_pipeline
+    if piped:
+        chain.pipeline(True)
     it = [0]
 
     def step():
@@ -218,6 +226,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # device time per step, launch gaps included
+    # the same chain one launch behind the other, in the same run: what ONE launch takes (and what rocprofv3 lists
+    # per launch, `--no-pipeline`), beside the time per step of overlapping launches
+    kernel_ms_plain = None
+    if piped and world == 1:
+        plain = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D)
+        for i in range(150):
+            plain.run(xs[i % nbuf], ys[i % len(ys)])
+        torch.cuda.synchronize()
+        pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        pe0.record()
+        for i in range(300):
+            plain.run(xs[i % nbuf], ys[i % len(ys)])
+        pe1.record()
+        torch.cuda.synchronize()
+        kernel_ms_plain = pe0.elapsed_time(pe1) / 300
+        plain.close()
     value = world * n * args.steps / elapsed / 1e6  # Msamples/s, whole job
     alg_bytes = (2 + 8 / D) * n                     # 2 B read + 8/D B written per input sample
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -257,8 +281,12 @@ def main():
         roof.update({
             "kernel": ("hz::mm2::fir_mm2_kernel<u8, D = 8, 17 groups>" if passes_form else "hz::mm::fir_mm_kernel<u8, D = 8>"),
             "kernel_ms": round(kernel_ms, 4),
-            "kernel_ms_is": "device time per chain_run (one kernel), one HIP-event pair around the timed "
-                            "loop / steps",
+            "kernel_ms_is": ("device time per chain_run (one kernel), one HIP-event pair around the timed loop / steps"
+                             + ("; the chain is PIPELINED (hzsdr_chain_pipeline): consecutive launches overlap on two streams of "
+                                "the chain's own (the context's stream, on which the events sit, waits for every launch), so this "
+                                "is time per step of the overlapped sequence -- ONE launch by itself takes kernel_ms_unpipelined, "
+                                "which is what rocprofv3 lists per launch" if piped else "")),
+            "kernel_ms_unpipelined": (round(kernel_ms_plain, 4) if kernel_ms_plain else None),
             "algorithmic_bytes_per_launch": int(alg_bytes),
             "fp32_vector_frac": round(fp32_vec, 4),
             "mfma_algorithmic_frac": round(alg_ops / t_s / 1e12 / I8_PEAK_TOPS, 4),
@@ -316,6 +344,7 @@ def main():
                          "decimated rate), input resident in HBM"),
             "samples_per_buffer": n, "sample_rate": fs, "taps": ntaps, "decimation": D,
             "parallelism": "1 stream per GPU (replicas)" if world > 1 else "1 GPU",
+            "pipelined": piped,
         },
         "roofline": roof,
     }
@@ -530,9 +559,16 @@ def main():
         want = np.zeros(ns // D, np.complex64)
         orc.par_fir_decimate_f64(want, buf, taps, D)
         chk = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D)
+        if piped:
+            chk.pipeline(True)
         chk.set_time(ts0)
         yg = torch.zeros(ns // D, dtype=torch.complex64, device="cuda")
-        chk.run(torch.from_numpy(xs0).cuda(), yg)
+        xg = torch.from_numpy(xs0).cuda()
+        torch.cuda.synchronize()
+        # (four calls: with the pipeline on, the second to fourth read a history formed by the history kernel and overlap)
+        q = ns // 4
+        for j in range(4):
+            chk.run(xg[j * q:(j + 1) * q], yg[j * q // D:(j + 1) * q // D])
         torch.cuda.synchronize()
         got = yg.cpu().numpy().astype(np.complex128)
         err = float(np.abs(got - want).max())

@@ -574,6 +574,13 @@ class Chain:
         self.ctx._ck(lib.hzsdr_chain_fir_options(self._h, int(impl), int(nfft_min), int(loop_form)))
         return self
 
+    def pipeline(self, on=True):
+        """Opt in to overlapping consecutive runs of a FIR-decimate chain on the matrix path (include/hzsdr.h:
+        hzsdr_chain_pipeline): the input of a run must be complete when run() is called; outputs stay ordered on the
+        context's stream; results are bit-identical."""
+        self.ctx._ck(lib.hzsdr_chain_pipeline(self._h, int(on)))
+        return self
+
     def shift_ulp1(self, on=True):
         """Opt in to the <= 1-ulp Shift of terminal-less chains (include/hzsdr.h: hzsdr_chain_shift_ulp1)."""
         self.ctx._ck(lib.hzsdr_chain_shift_ulp1(self._h, int(on)))

@@ -145,6 +145,7 @@ SIGNATURES = {
     "hzsdr_chain_mix_in_order": (i32, [vp, i32]),
     "hzsdr_chain_shift_ulp1": (i32, [vp, i32]),
     "hzsdr_chain_fir_options": (i32, [vp, i32, u32, i32]),
+    "hzsdr_chain_pipeline": (i32, [vp, i32]),
     "hzsdr_chain_plan": (i32, [vp, sz, psz, psz]),
     "hzsdr_chain_run": (i32, [vp, vp, sz, vp, sz, psz, psz]),
     "hzsdr_mgpu_open": (i32, [C.POINTER(C.c_int), i32, pvp]),

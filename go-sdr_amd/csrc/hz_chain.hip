@@ -324,8 +324,8 @@ int hzsdr_chain_reset(hzsdr_chain *c) {
     c->rh_valid = false;
     if (c->term == TERM_FIR) {
         const size_t hb = (size_t)(c->off ? c->off : 1) * 8;
-        HZ_HIP(ctx, hipMemsetAsync(c->hist[0], 0, hb, ctx->stream));
-        HZ_HIP(ctx, hipMemsetAsync(c->hist[1], 0, hb, ctx->stream));
+        HZ_TRY(hz::pipeline_drain(c));
+        for (int k = 0; k < hzsdr_chain::kHist; k++) HZ_HIP(ctx, hipMemsetAsync(c->hist[k], 0, hb, ctx->stream));
     }
     return HZSDR_OK;
 }
@@ -335,6 +335,7 @@ int hzsdr_chain_set_time(hzsdr_chain *c, double ts) {
     if (!(ts >= 0.0) || ts > 6.283185307179586476925286766559)  // the closure's clock lives in [0, 2*pi]
         return hz::fail(c->ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: clock outside [0, 2*pi]");
     HZ_TRY(hz::enter(c->ctx));
+    HZ_TRY(hz::pipeline_drain(c));
     c->ts = ts;
     c->rh_valid = false;  // the clock no longer continues the previous call's run
     if (c->term == TERM_FIR) {
@@ -353,17 +354,25 @@ int hzsdr_chain_time(const hzsdr_chain *c, double *ts) {
 int hzsdr_chain_free(hzsdr_chain *c) {
     if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
     (void)hipSetDevice(c->ctx->device);
+    for (hipStream_t s : {c->pstream[0], c->pstream[1]})
+        if (s) {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
+    for (int k = 0; k < 4; k++)
+        if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     (void)hipStreamSynchronize(c->ctx->stream);
     if (c->filt) (void)hipFree(c->filt);
     if (c->hfreq) (void)hipFree(c->hfreq);
     if (c->hfreq_late) (void)hipFree(c->hfreq_late);
-    if (c->hist[0]) (void)hipFree(c->hist[0]);
-    if (c->hist[1]) (void)hipFree(c->hist[1]);
+    for (int k = 0; k < hzsdr_chain::kHist; k++)
+        if (c->hist[k]) (void)hipFree(c->hist[k]);
     for (auto &kv : c->late_cache) (void)hipFree(kv.second);
     for (auto &kv : c->mm_cache) (void)hipFree(kv.second);
     if (c->taps_dev) (void)hipFree(c->taps_dev);
-    if (c->rhist[0]) (void)hipFree(c->rhist[0]);
-    if (c->rhist[1]) (void)hipFree(c->rhist[1]);
+    for (int k = 0; k < hzsdr_chain::kHist; k++)
+        if (c->rhist[k]) (void)hipFree(c->rhist[k]);
     delete c;
     return HZSDR_OK;
 }

@@ -288,9 +288,10 @@ static bool mm_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in
 
 static int mm_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const EwProgram &P, const mm::Runs &R,
                      const mm::Fix &F) {
+    HZ_TRY(pipeline_drain(c));
     return mm::launch_fir(c->ctx->stream, c->src_fmt, c->factor, in, (float2 *)out, (const float2 *)c->hist[c->hist_cur],
-                          (float2 *)c->hist[c->hist_cur ^ 1], (const uint8_t *)c->rhist[c->hist_cur],
-                          (uint8_t *)c->rhist[c->hist_cur ^ 1], (const float2 *)c->taps_dev, n, c->mmg, P, R, F);
+                          (float2 *)c->hist[c->hist_next()], (const uint8_t *)c->rhist[c->hist_cur],
+                          (uint8_t *)c->rhist[c->hist_next()], (const float2 *)c->taps_dev, n, c->mmg, P, R, F);
 }
 
 // hz_firmm2.h: the plan of one call for the persistent-pass kernel.  Every clock run with a table gets the
@@ -345,14 +346,71 @@ static bool mm2_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *i
     return ok;
 }
 
+// ---- hzsdr_chain_pipeline ----------------------------------------------------------------------------------------
+// A stream runs its launches one behind the other: the next call's workgroups wait for the LAST workgroup of this
+// one (they end over ~3 us) and then pay the kernel's head in full -- two independent chains on two streams take
+// 32.7 us per call where one takes 37.5 (tools/two_streams.py).  Consecutive calls of ONE chain depend on each other
+// through the history alone, and that is a function of the call's INPUT: a pipelined chain forms it with a small
+// kernel of its own (mm2::launch_history) and alternates its calls between two streams A, B of its own:
+//     call k:    history kernel k (writes the history call k+1 reads) on stream (k+1) mod 2,
+//                the call's kernel on stream k mod 2
+// so stream order alone puts kernel k+1 behind history kernel k, and history kernel k behind kernel k-3, the last
+// reader of the buffer it writes (a ring of four histories) -- no event between them, four API calls per call: two
+// launches, and the context's stream made to wait for the call's kernel (the caller's later work sees the output).
+// The launches are NOT ordered behind whatever else the context's stream holds: the caller guarantees the input is
+// complete when it calls.
+static int pipeline_ready(hzsdr_chain *c) {
+    hzsdr_ctx *ctx = c->ctx;
+    if (c->pstream[0]) return HZSDR_OK;
+    for (hipStream_t *s : {&c->pstream[0], &c->pstream[1]}) HZ_HIP(ctx, hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    for (int k = 0; k < 4; k++) HZ_HIP(ctx, hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
+    HZ_HIP(ctx, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    return HZSDR_OK;
+}
+
+int pipeline_drain(hzsdr_chain *c) {
+    if (c->pcall == 0) return HZSDR_OK;
+    hzsdr_ctx *ctx = c->ctx;
+    // (the calls' kernels are joined as they are launched; what is left is the last history kernel, on the stream
+    // of the call that has not come)
+    hipStream_t b = c->pstream[c->pcall & 1];
+    HZ_HIP(ctx, hipEventRecord(c->ev_in, b));
+    HZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->ev_in, 0));
+    c->pcall = 0;
+    return HZSDR_OK;
+}
+
+static int mm2_launch_pipelined(hzsdr_chain *c, const void *in, void *out, size_t n, const EwProgram &P, const mm2::Plan &L,
+                                const mm2::Fix &F, const mm2::Geom &g2) {
+    hzsdr_ctx *ctx = c->ctx;
+    HZ_TRY(pipeline_ready(c));
+    const uint64_t k = c->pcall;
+    hipStream_t a = c->pstream[k & 1], b = c->pstream[(k + 1) & 1];
+    if (k == 0) {  // the first call behind a drain: the history it reads was written on the context's stream
+        HZ_HIP(ctx, hipEventRecord(c->ev_in, ctx->stream));
+        HZ_HIP(ctx, hipStreamWaitEvent(a, c->ev_in, 0));
+        HZ_HIP(ctx, hipStreamWaitEvent(b, c->ev_in, 0));
+    }
+    HZ_TRY(mm2::launch_history(b, c->src_fmt, in, (float2 *)c->hist[c->hist_next()], (uint8_t *)c->rhist[c->hist_next()], n, c->mmg.off, P));
+    const int rc = mm2::launch_fir(a, ctx->num_cus, c->src_fmt, c->factor, in, (float2 *)out, (const float2 *)c->hist[c->hist_cur], nullptr,
+                                   (const uint8_t *)c->rhist[c->hist_cur], nullptr, (const float2 *)c->taps_dev, n, g2, L, P, F, c->fir_loop_form);
+    // (whatever happened, the streams stay consistent: the call is joined)
+    HZ_HIP(ctx, hipEventRecord(c->ev_done[k & 3], a));
+    HZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->ev_done[k & 3], 0));
+    c->pcall = k + 1;
+    return rc;
+}
+
 static int mm2_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const EwProgram &P, const mm2::Plan &L,
                       const mm2::Fix &F) {
     mm2::Geom g2{};
     g2.ntaps = c->mmg.ntaps, g2.w0 = c->mmg.w0, g2.ks = c->mmg.ks, g2.ne = c->mmg.ne, g2.e0 = c->mmg.e0, g2.shift = c->mmg.shift,
     g2.off = c->mmg.off;
+    if (c->pipelined && n >= c->mmg.off && c->mmg.off > 0) return mm2_launch_pipelined(c, in, out, n, P, L, F, g2);
+    HZ_TRY(pipeline_drain(c));
     return mm2::launch_fir(c->ctx->stream, c->ctx->num_cus, c->src_fmt, c->factor, in, (float2 *)out,
-                           (const float2 *)c->hist[c->hist_cur], (float2 *)c->hist[c->hist_cur ^ 1],
-                           (const uint8_t *)c->rhist[c->hist_cur], (uint8_t *)c->rhist[c->hist_cur ^ 1],
+                           (const float2 *)c->hist[c->hist_cur], (float2 *)c->hist[c->hist_next()],
+                           (const uint8_t *)c->rhist[c->hist_cur], (uint8_t *)c->rhist[c->hist_next()],
                            (const float2 *)c->taps_dev, n, g2, L, P, F, c->fir_loop_form);
 }
 
@@ -445,7 +503,7 @@ int fir_run(hzsdr_chain *c, const void *in, size_t n_cons, void *out, const EwPr
     do {
         const size_t nblocks = (n_cons + c->hop - 1) / c->hop;
         const float2 *hist = (const float2 *)c->hist[c->hist_cur];
-        float2 *nhist = (float2 *)c->hist[c->hist_cur ^ 1];
+        float2 *nhist = (float2 *)c->hist[c->hist_next()];
         const unsigned D = c->factor;
         if (c->mm_ok) {
             // byte source, D = 8, 16, ...: the int8 matrix form (hz_firmm2.h / hz_firmm.h), one launch
@@ -475,7 +533,7 @@ int fir_run(hzsdr_chain *c, const void *in, size_t n_cons, void *out, const EwPr
                 cont = R.cont;
             }
             if (ran) {
-                c->hist_cur ^= 1;
+                c->hist_cur = c->hist_next();
                 c->last_path = HZSDR_FIR_PATH_MATRIX;
                 // the raw history now ends in this call's last clock run
                 const bool was = c->rh_valid;
@@ -494,6 +552,7 @@ int fir_run(hzsdr_chain *c, const void *in, size_t n_cons, void *out, const EwPr
             }
         }
         if (!fv::ok((int)c->nfft)) return HZSDR_ERR_INVALID_ARGUMENT;
+        HZ_TRY(pipeline_drain(c));  // (the transform kernels run on the context's stream)
         FvTabs tabs{}, tabs_m{};
         PolyTabs ptabs{};
         HZ_TRY(get_fv_tables(ctx, c->nfft, &tabs));
@@ -566,7 +625,7 @@ int fir_run(hzsdr_chain *c, const void *in, size_t n_cons, void *out, const EwPr
 #undef HZ_FIR16
 #undef HZ_FIR16_L
 #undef HZ_SYNTH16
-        c->hist_cur ^= 1;  // the kernel wrote the next run's history into nhist
+        c->hist_cur = c->hist_next();  // the kernel wrote the next run's history into nhist
         c->rh_valid = false;  // (the transform kernels keep no raw history)
         c->last_path = HZSDR_FIR_PATH_TRANSFORM;
         break;
@@ -590,6 +649,14 @@ int hzsdr_chain_fir_options(hzsdr_chain *c, int impl, unsigned nfft_min, int loo
     c->fir_impl = impl;
     c->fir_nfft_min = nfft_min;
     c->fir_loop_form = loop_form;
+    return HZSDR_OK;
+}
+
+int hzsdr_chain_pipeline(hzsdr_chain *c, int on) {
+    if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
+    HZ_TRY(hz::enter(c->ctx));
+    if (!on) HZ_TRY(hz::pipeline_drain(c));
+    c->pipelined = on != 0;
     return HZSDR_OK;
 }
 
@@ -626,10 +693,10 @@ int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps, size_t n_taps, u
     // terminal stage (a retry starts clean, nothing leaks)
     auto build = [&]() -> int {
         HZ_HIP(ctx, hipMalloc(&c->hfreq, (size_t)nfft * 8));
-        HZ_HIP(ctx, hipMalloc(&c->hist[0], hb));
-        HZ_HIP(ctx, hipMalloc(&c->hist[1], hb));
-        HZ_HIP(ctx, hipMemsetAsync(c->hist[0], 0, hb, ctx->stream));
-        HZ_HIP(ctx, hipMemsetAsync(c->hist[1], 0, hb, ctx->stream));
+        for (int k = 0; k < hzsdr_chain::kHist; k++) {
+            HZ_HIP(ctx, hipMalloc(&c->hist[k], hb));
+            HZ_HIP(ctx, hipMemsetAsync(c->hist[k], 0, hb, ctx->stream));
+        }
         HZ_TRY(filter_spectrum(c, c->taps_host.data(), c->hfreq));
         if (late_scale(c) != 1.0) {
             HZ_HIP(ctx, hipMalloc(&c->hfreq_late, (size_t)nfft * 8));
@@ -641,8 +708,7 @@ int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps, size_t n_taps, u
             mm_geometry(c);
             std::vector<float> tf(2 * n_taps);
             for (size_t i = 0; i < 2 * n_taps; i++) tf[i] = taps[i];
-            HZ_HIP(ctx, hipMalloc(&c->rhist[0], hb));
-            HZ_HIP(ctx, hipMalloc(&c->rhist[1], hb));
+            for (int k = 0; k < hzsdr_chain::kHist; k++) HZ_HIP(ctx, hipMalloc(&c->rhist[k], hb));
             HZ_HIP(ctx, hipMalloc(&c->taps_dev, 8 * n_taps));
             HZ_HIP(ctx, hipMemcpyAsync(c->taps_dev, tf.data(), 8 * n_taps, hipMemcpyHostToDevice, ctx->stream));
             HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -653,7 +719,8 @@ int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps, size_t n_taps, u
     const int rc = build();
     if (rc != HZSDR_OK) {
         (void)hipStreamSynchronize(ctx->stream);
-        for (void **p : {&c->hfreq, &c->hfreq_late, &c->hist[0], &c->hist[1], &c->taps_dev, &c->rhist[0], &c->rhist[1]}) {
+        for (void **p : {&c->hfreq, &c->hfreq_late, &c->hist[0], &c->hist[1], &c->hist[2], &c->hist[3], &c->taps_dev, &c->rhist[0], &c->rhist[1],
+                         &c->rhist[2], &c->rhist[3]}) {
             if (*p) (void)hipFree(*p);
             *p = nullptr;
         }

@@ -32,8 +32,12 @@ struct hzsdr_chain {
     // fir-decimate
     void *hfreq = nullptr;  // device, nfft bins (FFT(taps)/nfft)
     void *hfreq_late = nullptr;  // the same times late_scale() (chains without a Shift; see late_scale)
-    void *hist[2] = {nullptr, nullptr};
+    // the histories of consecutive calls: a ring of kHist buffers, call k reads hist[hist_cur] and writes
+    // hist[hist_next()] (four, not two: a pipelined chain has two calls in flight -- hzsdr_chain_pipeline)
+    static constexpr int kHist = 4;
+    void *hist[kHist] = {nullptr, nullptr, nullptr, nullptr};
     int hist_cur = 0;
+    int hist_next() const { return (hist_cur + 1) % kHist; }
     size_t ntaps = 0;
     unsigned nfft = 0, hop = 0, off = 0;
     // late mixer (see fir_decimate_kernel16): the taps, and FFT(taps * exp(-i*Omega*k*step))/N
@@ -52,7 +56,7 @@ struct hzsdr_chain {
     std::map<uint64_t, void *> mm_cache;
     // the last `off` RAW samples of the previous call (two buffers, flipped with hist[]): valid
     // after a call on the matrix path; rh_step / rh_len describe the clock run they end in
-    void *rhist[2] = {nullptr, nullptr};
+    void *rhist[kHist] = {nullptr, nullptr, nullptr, nullptr};
     bool rh_valid = false;
     double rh_step = 0.0, rh_next = 0.0;
     uint64_t rh_len = 0;
@@ -63,6 +67,13 @@ struct hzsdr_chain {
     unsigned fir_nfft_min = 0;
     int fir_loop_form = 0;
     int last_path = HZSDR_FIR_PATH_NONE;
+    // hzsdr_chain_pipeline: consecutive calls on the matrix path alternate between two streams of the chain's own
+    // (the next launch's workgroups start as this one's finish), the history of the next call is formed by a small
+    // kernel of its own; `pcall` counts the pipelined calls since the last drain
+    bool pipelined = false;
+    hipStream_t pstream[2] = {nullptr, nullptr};
+    hipEvent_t ev_done[4] = {nullptr, nullptr, nullptr, nullptr}, ev_in = nullptr;
+    uint64_t pcall = 0;
 };
 
 struct hzsdr_conv {
@@ -123,5 +134,8 @@ int prepare_mm_tables(hzsdr_chain *c, double ts0);
 int chain_launch(hzsdr_chain *c, const void *din, size_t cons, void *dout, size_t outn, double *ts_after);
 int upload_filter(hzsdr_ctx *ctx, void *dst, const void *src, size_t bytes);
 int chain_terminal_set(hzsdr_chain *c);
+// hz_chain_fir.hip: the context's stream waits for everything a pipelined chain has in flight (its next call, a
+// reset, a change of the clock and the end of the chain all need that)
+int pipeline_drain(hzsdr_chain *c);
 
 }  // namespace hz

@@ -879,6 +879,8 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
 int launch_fir(hipStream_t stream, int num_cus, int fmt, unsigned D, const void *in, float2 *out, const float2 *hist,
                float2 *new_hist, const uint8_t *rhist, uint8_t *new_rhist, const float2 *taps, size_t n, const Geom &g,
                const Plan &L, const EwProgram &P, const Fix &F, int loop_form = 0);
+// the history tasks alone, as a kernel of their own (n >= off): hz_firmm2.hip
+int launch_history(hipStream_t stream, int fmt, const void *in, float2 *new_hist, uint8_t *new_rhist, size_t n, unsigned off, const EwProgram &P);
 
 }  // namespace mm2
 }  // namespace hz

@@ -48,5 +48,31 @@ int launch_fir(hipStream_t stream, int num_cus, int fmt, unsigned D, const void 
     return HZSDR_ERR_INVALID_ARGUMENT;
 }
 
+// The next call's history as a kernel of its own (a pipelined chain: hz_chain_fir.hip): exactly the history tasks of
+// fir_mm2_kernel -- the last `off` samples of the call, the stages in reference order, and the raw samples -- for a
+// call of at least `off` samples.  One wave per 64 samples.
+template <int FMT>
+__global__ __launch_bounds__(64) void history_kernel(const void *__restrict__ in, float2 *__restrict__ new_hist, uint8_t *__restrict__ new_rhist,
+                                                     size_t n_in, unsigned off, EwProgram P) {
+    using RWT = typename Raw<FMT>::t;
+    const unsigned idx = blockIdx.x * 64u + threadIdx.x;
+    const int64_t h_lo = (int64_t)n_in - (int64_t)off + (int64_t)blockIdx.x * 64;
+    const NcoWin tw = mm::task_window(P, h_lo, h_lo + 63);
+    if (idx < off) {
+        const int64_t p = (int64_t)n_in - (int64_t)off + idx;
+        new_hist[idx] = mm::ordered_sample<FMT>(in, P, p, nullptr, off, tw);
+        reinterpret_cast<RWT *>(new_rhist)[idx] = ((const RWT *)in)[p];
+    }
+}
+
+int launch_history(hipStream_t stream, int fmt, const void *in, float2 *new_hist, uint8_t *new_rhist, size_t n, unsigned off, const EwProgram &P) {
+    if (n < off || off == 0) return HZSDR_ERR_INVALID_ARGUMENT;
+    const dim3 grid((off + 63) / 64), block(64);
+    if (fmt == HZSDR_FMT_U8) hipLaunchKernelGGL(history_kernel<HZSDR_FMT_U8>, grid, block, 0, stream, in, new_hist, new_rhist, n, off, P);
+    else if (fmt == HZSDR_FMT_I8) hipLaunchKernelGGL(history_kernel<HZSDR_FMT_I8>, grid, block, 0, stream, in, new_hist, new_rhist, n, off, P);
+    else return HZSDR_ERR_INVALID_ARGUMENT;
+    return hipGetLastError() == hipSuccess ? HZSDR_OK : HZSDR_ERR_HIP;
+}
+
 }  // namespace mm2
 }  // namespace hz

@@ -262,6 +262,11 @@ func (ch *Chain) FIROptions(impl int, nfftMin uint, loopForm int) error {
 	return toErr(ch.x.c, C.hzsdr_chain_fir_options(ch.c, C.int(impl), C.uint(nfftMin), C.int(loopForm)))
 }
 
+// Pipeline lets consecutive Run calls of a FIR-decimate chain on the int8 matrix path overlap (include/hzsdr.h:
+// hzsdr_chain_pipeline): the input of a call must be complete when Run is called -- the launch is not ordered behind
+// earlier work on the context's stream --, the output stays ordered on that stream, the results are bit-identical.
+func (ch *Chain) Pipeline(on bool) error { return toErr(ch.x.c, C.hzsdr_chain_pipeline(ch.c, cbool(on))) }
+
 // ShiftULP1 opts a terminal-less chain (ShiftReader, ShiftReader -> Gain) in to the Shift whose rotation
 // factor is within one float32 ulp of the reference's instead of bit-identical to it (include/hzsdr.h).
 func (ch *Chain) ShiftULP1(on bool) error { return toErr(ch.x.c, C.hzsdr_chain_shift_ulp1(ch.c, cbool(on))) }

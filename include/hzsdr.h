@@ -376,6 +376,18 @@ int hzsdr_chain_mix_in_order(hzsdr_chain *c, int in_order);
 #define HZSDR_FIR_IMPL_TRANSFORMS 1     /* the overlap-save transform kernels */
 #define HZSDR_FIR_IMPL_MATRIX_CHUNKS 2  /* the int8 matrix form as chunk workgroups (hz_firmm.h), where eligible */
 int hzsdr_chain_fir_options(hzsdr_chain *c, int impl, unsigned nfft_min, int loop_form);
+/* OPT-IN, off by default: consecutive hzsdr_chain_run calls of a FIR-decimate chain on the int8 matrix path OVERLAP.
+ * A stream runs its launches one behind the other -- the next call's workgroups wait for the last workgroup of this
+ * one and then pay the kernel's head in full: ~5 us of 37 per 2^24-sample buffer.  The calls of one chain depend on
+ * each other through the FIR history alone, which is a function of the call's input; a pipelined chain forms it in
+ * a small kernel of its own and alternates its calls between two streams it owns.  What changes for the caller:
+ *   - the INPUT of a call must be complete when hzsdr_chain_run is called (the launch is not ordered behind earlier
+ *     work on the context's stream, e.g. an asynchronous copy that fills the buffer: synchronise that first);
+ *   - the OUTPUT is ordered on the context's stream as always (later work on that stream sees it);
+ *   - results are bit-identical to the unpipelined chain's (the same kernels on the same values).
+ * Calls that do not take the matrix path (too many clock boundaries, other source formats and factors) run as
+ * before, behind everything in flight.  DEVICE-space contexts; a HOST-space call is synchronous either way. */
+int hzsdr_chain_pipeline(hzsdr_chain *c, int on);
 /* OPT-IN, off by default: a chain WITHOUT a terminal (ShiftReader, or ShiftReader -> Gain: BASELINE config 2)
  * whose buffers allow four samples per lane forms the Shift's rotation factor from the phase in turns with
  * float32 polynomials instead of an operation-for-operation math.Sincos in float64.  The float64 product

@@ -242,6 +242,8 @@ static void chain_and_ring(void) { /* go/hip/stream.go Chain, go/hip/ring.go */
     CHECK(hzsdr_chain_fir_options(c, HZSDR_FIR_IMPL_TRANSFORMS, 0, 0) == HZSDR_ERR_INVALID_ARGUMENT); /* in front of it */
     OK(hzsdr_chain_mix_in_order(c, 0));
     OK(hzsdr_chain_shift_ulp1(c, 0));
+    OK(hzsdr_chain_pipeline(c, 1)); /* consecutive calls may overlap (inputs complete at call time: host buffers are) */
+    CHECK(hzsdr_chain_pipeline(NULL, 1) == HZSDR_ERR_INVALID_ARGUMENT);
     size_t cons = 0, outn = 0;
     OK(hzsdr_chain_plan(c, N, &cons, &outn));
     CHECK(cons == N && outn == N / D);

@@ -319,3 +319,43 @@ def test_reset_and_interleaved_chains(hz, ctx, orc):
     assert again.tobytes() == oa[:n // D].tobytes()
     ca.close()
     cb.close()
+
+
+def test_pipelined_chain_is_bit_identical_to_the_plain_one(hz):
+    """hzsdr_chain_pipeline: consecutive calls overlap (two streams of the chain's own, the next call's history from
+    a kernel of its own), the same kernels on the same values -- every output bit as the unpipelined chain gives
+    it, over forty calls across binades of the clock and the 2 pi wrap, with a change of the clock, a call too
+    short for the matrix path (drains the pipeline) and a switch off and on again in between."""
+    import torch
+    n, fs, D = 1 << 20, 20_000_000, 8
+    taps = taps_for(1024, 1 / 16, 0.0)
+    ctxs = [hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.Stream().cuda_stream) for _ in range(2)]
+    xs = [torch.from_numpy(rand_u8(300 + i, n)).cuda() for i in range(5)]
+    torch.cuda.synchronize()
+    outs = []
+    for piped, ctx in zip((False, True), ctxs):
+        ch = ctx.chain(hz.FMT_U8, fs).shift(-fs / 8).fir_decimate(taps, D)
+        if piped:
+            ch.pipeline(True)
+        ch.set_time(TAU - 0.6)
+        # (the outputs exist, zeroed, before the first call: torch fills them on ITS stream, which nothing here waits for)
+        sizes = [2048 if i == 11 else n for i in range(40)]
+        ys = [torch.zeros(m // D, dtype=torch.complex64, device="cuda") for m in sizes]
+        torch.cuda.synchronize()
+        for i in range(40):
+            if i == 17:
+                ch.set_time(0.9)
+            if i == 25 and piped:
+                ch.pipeline(False)
+            if i == 29 and piped:
+                ch.pipeline(True)
+            m = sizes[i]  # (call 11 is short: the transform kernels, behind everything in flight)
+            assert ch.run(xs[i % 5][:m], ys[i]) == (m, m // D)
+        ctx.synchronize()
+        outs.append([torch.view_as_real(y).view(torch.int32).cpu().numpy() for y in ys])
+        assert ch.last_fir_path() == hz.FIR_PATH_MATRIX
+        ch.close()
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert np.array_equal(a, b), "call %d differs" % i
+    for c in ctxs:
+        c.close()

@@ -9,7 +9,8 @@ out=gpurun_out/prof_$tag
 export TMPDIR=/tmp
 mkdir -p $out
 python3 bench.py > $out/bench.json 2> $out/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_trace -- python3 bench.py --no-oracle --no-extra > $out/bench_profiled.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_trace -- python3 bench.py --no-oracle --no-extra --no-pipeline > $out/bench_profiled.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_trace_pipelined -- python3 bench.py --no-oracle --no-extra > $out/bench_profiled_pipelined.json 2> /dev/null
 K="chain chain_fft convert shift_gain conv chain_c64 beamform downsample"
 REPS=6 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 tools/prof_kernels.py $K > /dev/null 2>&1
 REPS=6 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 tools/prof_kernels.py $K > /dev/null 2>&1
