@@ -391,6 +391,10 @@ static int mm2_launch_pipelined(hzsdr_chain *c, const void *in, void *out, size_
         HZ_HIP(ctx, hipStreamWaitEvent(a, c->ev_in, 0));
         HZ_HIP(ctx, hipStreamWaitEvent(b, c->ev_in, 0));
     }
+    if (c->wait_in) {  // (the pinned ring: this call's upload)
+        HZ_HIP(ctx, hipStreamWaitEvent(a, c->wait_in, 0));
+        HZ_HIP(ctx, hipStreamWaitEvent(b, c->wait_in, 0));
+    }
     HZ_TRY(mm2::launch_history(b, c->src_fmt, in, (float2 *)c->hist[c->hist_next()], (uint8_t *)c->rhist[c->hist_next()], n, c->mmg.off, P));
     const int rc = mm2::launch_fir(a, ctx->num_cus, c->src_fmt, c->factor, in, (float2 *)out, (const float2 *)c->hist[c->hist_cur], nullptr,
                                    (const uint8_t *)c->rhist[c->hist_cur], nullptr, (const float2 *)c->taps_dev, n, g2, L, P, F, c->fir_loop_form);
@@ -406,7 +410,9 @@ static int mm2_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const
     mm2::Geom g2{};
     g2.ntaps = c->mmg.ntaps, g2.w0 = c->mmg.w0, g2.ks = c->mmg.ks, g2.ne = c->mmg.ne, g2.e0 = c->mmg.e0, g2.shift = c->mmg.shift,
     g2.off = c->mmg.off;
-    if (c->pipelined && n >= c->mmg.off && c->mmg.off > 0) return mm2_launch_pipelined(c, in, out, n, P, L, F, g2);
+    // (HOST-space calls stage their buffers on the context's stream and are synchronous: nothing to overlap)
+    if (c->pipelined && (c->ctx->memspace == HZSDR_MEM_DEVICE || c->wait_in) && n >= c->mmg.off && c->mmg.off > 0)
+        return mm2_launch_pipelined(c, in, out, n, P, L, F, g2);
     HZ_TRY(pipeline_drain(c));
     return mm2::launch_fir(c->ctx->stream, c->ctx->num_cus, c->src_fmt, c->factor, in, (float2 *)out,
                            (const float2 *)c->hist[c->hist_cur], (float2 *)c->hist[c->hist_next()],

@@ -74,6 +74,7 @@ struct hzsdr_chain {
     hipStream_t pstream[2] = {nullptr, nullptr};
     hipEvent_t ev_done[4] = {nullptr, nullptr, nullptr, nullptr}, ev_in = nullptr;
     uint64_t pcall = 0;
+    hipEvent_t wait_in = nullptr;  // set by a caller inside the library that knows what the input waits for (hz_ring.hip)
 };
 
 struct hzsdr_conv {

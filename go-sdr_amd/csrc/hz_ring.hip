@@ -144,7 +144,10 @@ int hzsdr_ring_submit(hzsdr_ring *r, int slot, size_t n) {
     HZ_HIP(ctx, hipEventRecord(s.up, r->s_up));
     HZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.up, 0));
     double ts;
-    HZ_TRY(chain_launch(r->chain, din, n, dout, outn, &ts));
+    r->chain->wait_in = s.up;  // (a pipelined chain launches on streams of its own: they wait for the upload too)
+    const int rc_launch = chain_launch(r->chain, din, n, dout, outn, &ts);
+    r->chain->wait_in = nullptr;
+    HZ_TRY(rc_launch);
     HZ_HIP(ctx, hipGetLastError());
     r->chain->ts = ts;
     HZ_HIP(ctx, hipEventRecord(s.done, ctx->stream));
