@@ -570,6 +570,8 @@ public:
         check(x_.raw(), hzsdr_chain_fir_decimate(c_, reinterpret_cast<const float *>(taps.data()), taps.size(), d));
         return *this;
     }
+    // hzsdr_chain_pipeline: consecutive Run calls on the matrix path overlap (the input must be complete at call time)
+    Chain &Pipeline(bool on = true) { check(x_.raw(), hzsdr_chain_pipeline(c_, on ? 1 : 0)); return *this; }
     // -> (consumed, produced)
     std::pair<size_t, size_t> Run(Samples in, Samples out) {
         size_t used = 0, made = 0;

@@ -7,6 +7,7 @@ cp $src/bench.json profiles/${tag}_bench.json
 # (a directory collects one file set per profiled process and run: the newest is this collection's)
 newest() { ls -t $1 | head -1; }
 cp $(newest "$src/bench_trace/*/*kernel_stats.csv") profiles/${tag}_bench_kernel_stats.csv
+[ -d $src/bench_trace_pipelined ] && cp $(newest "$src/bench_trace_pipelined/*/*kernel_stats.csv") profiles/${tag}_bench_pipelined_kernel_stats.csv
 cp $(newest "$src/kern_trace/*/*kernel_stats.csv") profiles/${tag}_kernels_kernel_stats.csv
 cp $(newest "$src/fft_trace/*/*kernel_stats.csv") profiles/${tag}_fft_kernel_stats.csv
 cp $src/traffic.json profiles/${tag}_traffic.json
