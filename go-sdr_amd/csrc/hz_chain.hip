@@ -357,6 +357,8 @@ int hzsdr_chain_free(hzsdr_chain *c) {
     for (hipStream_t s : {c->pstream[0], c->pstream[1]})
         if (s) {
             (void)hipStreamSynchronize(s);
+            auto &ss = c->ctx->side_streams;
+            ss.erase(std::remove(ss.begin(), ss.end(), s), ss.end());
             (void)hipStreamDestroy(s);
         }
     for (int k = 0; k < 4; k++)

@@ -362,7 +362,10 @@ static bool mm2_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *i
 static int pipeline_ready(hzsdr_chain *c) {
     hzsdr_ctx *ctx = c->ctx;
     if (c->pstream[0]) return HZSDR_OK;
-    for (hipStream_t *s : {&c->pstream[0], &c->pstream[1]}) HZ_HIP(ctx, hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+    for (hipStream_t *s : {&c->pstream[0], &c->pstream[1]}) {
+        HZ_HIP(ctx, hipStreamCreateWithFlags(s, hipStreamNonBlocking));
+        ctx->side_streams.push_back(*s);
+    }
     for (int k = 0; k < 4; k++) HZ_HIP(ctx, hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
     HZ_HIP(ctx, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     return HZSDR_OK;

@@ -45,6 +45,9 @@ struct hzsdr_ctx {
     std::vector<std::pair<const char *, size_t>> pinned_ranges;
     // FFT twiddle tables exp(-2 pi i m / N), m < N, keyed by N (device memory)
     std::map<size_t, void *> twiddles;
+    // streams that objects of this context own and launch on beside `stream` (pipelined chains: hzsdr_chain_pipeline);
+    // hzsdr_synchronize waits for them as well
+    std::vector<hipStream_t> side_streams;
 };
 
 namespace hz {

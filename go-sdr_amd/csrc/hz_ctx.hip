@@ -227,6 +227,7 @@ void *hzsdr_get_stream(const hzsdr_ctx *ctx) { return ctx ? (void *)ctx->stream 
 int hzsdr_synchronize(hzsdr_ctx *ctx) {
     HZ_TRY(hz::enter(ctx));
     HZ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (hipStream_t s : ctx->side_streams) HZ_HIP(ctx, hipStreamSynchronize(s));  // (a pipelined chain's last history kernel)
     return HZSDR_OK;
 }
 

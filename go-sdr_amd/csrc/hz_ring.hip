@@ -19,6 +19,8 @@ struct hzsdr_ring {
     char *dev_in = nullptr, *dev_out = nullptr;
     struct Slot {
         hipEvent_t up = nullptr, done = nullptr, down = nullptr;
+        hipEvent_t hread = nullptr;  // a pipelined chain: the history kernel that read this slot's device copy
+        bool hread_set = false;
         size_t n_out = 0;
         int state = 0;  // 0 free, 1 acquired, 2 in flight
     };
@@ -41,6 +43,7 @@ int hzsdr_ring_free(hzsdr_ring *r) {
         if (s.up) (void)hipEventDestroy(s.up);
         if (s.done) (void)hipEventDestroy(s.done);
         if (s.down) (void)hipEventDestroy(s.down);
+        if (s.hread) (void)hipEventDestroy(s.hread);
     }
     for (char *p : {r->pin_in, r->pin_out})
         for (size_t i = 0; p && i < r->ctx->pinned_ranges.size(); i++)
@@ -97,6 +100,7 @@ int hzsdr_ring_create(hzsdr_chain *c, size_t slot_length, int slots, hzsdr_ring 
     ctx->pinned_ranges.push_back({r->pin_out, r->out_bytes() * slots});
     for (auto &s : r->slots) {
         HZ_RING(hipEventCreateWithFlags(&s.up, hipEventDisableTiming));
+        HZ_RING(hipEventCreateWithFlags(&s.hread, hipEventDisableTiming));
         HZ_RING(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
         HZ_RING(hipEventCreateWithFlags(&s.down, hipEventDisableTiming));
     }
@@ -140,6 +144,10 @@ int hzsdr_ring_submit(hzsdr_ring *r, int slot, size_t n) {
     const size_t fs = (size_t)format_size(r->chain->src_fmt);
     char *hin = r->pin_in + (size_t)slot * r->in_bytes(), *din = r->dev_in + (size_t)slot * r->in_bytes();
     char *hout = r->pin_out + (size_t)slot * r->out_bytes(), *dout = r->dev_out + (size_t)slot * r->out_bytes();
+    if (s.hread_set) {  // (the slot's previous use: its last samples were read by a history kernel beside the call's own)
+        HZ_HIP(ctx, hipStreamWaitEvent(r->s_up, s.hread, 0));
+        s.hread_set = false;
+    }
     HZ_HIP(ctx, hipMemcpyAsync(din, hin, n * fs, hipMemcpyHostToDevice, r->s_up));
     HZ_HIP(ctx, hipEventRecord(s.up, r->s_up));
     HZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.up, 0));
@@ -148,6 +156,10 @@ int hzsdr_ring_submit(hzsdr_ring *r, int slot, size_t n) {
     const int rc_launch = chain_launch(r->chain, din, n, dout, outn, &ts);
     r->chain->wait_in = nullptr;
     HZ_TRY(rc_launch);
+    if (r->chain->pcall > 0) {  // (this call ran pipelined: its history kernel sits on the NEXT call's stream)
+        HZ_HIP(ctx, hipEventRecord(s.hread, r->chain->pstream[r->chain->pcall & 1]));
+        s.hread_set = true;
+    }
     HZ_HIP(ctx, hipGetLastError());
     r->chain->ts = ts;
     HZ_HIP(ctx, hipEventRecord(s.done, ctx->stream));

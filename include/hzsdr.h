@@ -382,7 +382,10 @@ int hzsdr_chain_fir_options(hzsdr_chain *c, int impl, unsigned nfft_min, int loo
  * each other through the FIR history alone, which is a function of the call's input; a pipelined chain forms it in
  * a small kernel of its own and alternates its calls between two streams it owns.  What changes for the caller:
  *   - the INPUT of a call must be complete when hzsdr_chain_run is called (the launch is not ordered behind earlier
- *     work on the context's stream, e.g. an asynchronous copy that fills the buffer: synchronise that first);
+ *     work on the context's stream, e.g. an asynchronous copy that fills the buffer: synchronise that first), and
+ *     must stay as it is until the NEXT call's output is complete or the context has been synchronised with
+ *     hzsdr_synchronize (the small kernel that forms the next call's history reads its last samples, beside the
+ *     call's own kernel);
  *   - the OUTPUT is ordered on the context's stream as always (later work on that stream sees it);
  *   - results are bit-identical to the unpipelined chain's (the same kernels on the same values).
  * Calls that do not take the matrix path (too many clock boundaries, other source formats and factors) run as
