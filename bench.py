@@ -336,7 +336,10 @@ def main():
             "workload": ("north-star chain: u8->c64->Shift(-fs/8)->1024-tap FIR->decimate-by-8, one "
                          "chain_run per buffer = ONE kernel: the filter over the raw bytes as an int8 "
                          "matrix product with the clock run's modulated taps, the mixer at the decimated "
-                         "rate, outputs across clock boundaries in reference order; input resident in HBM")
+                         "rate, outputs across clock boundaries in reference order; input resident in HBM"
+                         + ("; PIPELINED (hzsdr_chain_pipeline): consecutive calls overlap on two streams of the chain's own, "
+                            "the next call's FIR history formed from the call's input by a 16-wave kernel beside the matrix "
+                            "kernel -- bit-identical outputs, checked pipelined under `parity`" if piped else ""))
                         if matrix else
                         ("north-star chain: u8->c64->Shift(-fs/8)->1024-tap FIR->decimate-by-8, one "
                          "chain_run per buffer = analysis kernel (convert, 4096-point overlap-save "
