@@ -301,7 +301,7 @@ def main():
             },
             "note": "3 B/sample puts the chain far above the HBM ridge (the 50 MB of a buffer are 8 us at 6.3 TB/s): "
                     "what binds is the issue of int8 MFMAs at the clock the chip holds under them (~1.55 GHz: the "
-                    "1088 MFMAs per SIMD of a 2^24-sample buffer are 22.4 us, profiles/r03_mfma_fir2.txt), then the "
+                    "1088 MFMAs per SIMD of a 2^24-sample buffer are 22.4 us, profiles/r04_mfma_fir2.txt), then the "
                     "kernel's first ~5.5 us (cold instruction and scalar caches, the first bytes from HBM) and the "
                     "vector instructions of the epilogues, which run beside the SIMD partner's matrix loop",
         })
@@ -354,7 +354,8 @@ def main():
     chain.close()
     # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc
     # passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_summary.py), not from this process.
-    tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+    tname = next((t for t in ("r04_traffic.json", "r03_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), "r04_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", tname)
     if n == (1 << 24) and os.path.exists(tpath):
         try:
             tk = json.load(open(tpath))["kernels"]
@@ -367,7 +368,7 @@ def main():
                 want = 2
             if len(keys) == want:
                 result["roofline"]["traffic"] = sum(tk[k]["hbm_bytes"] for k in keys)
-                result["roofline"]["traffic_source"] = ("profiles/r03_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + "
+                result["roofline"]["traffic_source"] = ("profiles/" + tname + " (rocprofv3 --pmc FETCH_SIZE x2 + "
                                                         "WRITE_SIZE, the kernel(s) of a chain_run)")
         except (StopIteration, KeyError, ValueError):
             pass
