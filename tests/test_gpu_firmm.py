@@ -359,3 +359,43 @@ def test_pipelined_chain_is_bit_identical_to_the_plain_one(hz):
         assert np.array_equal(a, b), "call %d differs" % i
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_pipelined_chain_random_calls_bit_identical(hz, seed):
+    """Random call lengths (whole tiles and ragged, some below the matrix path's minimum), i8 and u8 sources, random
+    changes of the clock: the pipelined chain's outputs equal the plain chain's bit for bit, and so does its clock."""
+    import torch
+    rng = np.random.default_rng(seed)
+    fs, D = 20_000_000, 8
+    fmt, gen = (hz.FMT_I8, rand_i8) if seed == 2 else (hz.FMT_U8, rand_u8)
+    taps = taps_for(int(rng.choice([256, 640, 1024])), 1 / 16, 0.1)
+    sizes = [int(rng.choice([1 << 18, 1 << 19, 3 * (1 << 17) + 8 * int(rng.integers(0, 4000)), 2048, 40_000])) for _ in range(30)]
+    sizes = [m - m % D for m in sizes]
+    resets = {int(i): float(rng.uniform(0, TAU)) for i in rng.integers(0, 30, 4)}
+    src = torch.from_numpy(gen(500 + seed, 1 << 20)).cuda()
+    ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+    outs, clocks = [], []
+    for piped in (False, True):
+        ch = ctx.chain(fmt, fs).shift(3.1e6).gain(0.7).fir_decimate(taps, D)
+        if piped:
+            ch.pipeline(True)
+        ch.set_time(TAU - 0.05)
+        ys = [torch.zeros(m // D, dtype=torch.complex64, device="cuda") for m in sizes]
+        torch.cuda.synchronize()
+        off = 0
+        for i, m in enumerate(sizes):
+            if i in resets:
+                ch.set_time(resets[i])
+            if off + m > (1 << 20):
+                off = 0
+            assert ch.run(src[off:off + m], ys[i]) == (m, m // D)
+            off += m - m % 16  # (16-byte aligned starts: the matrix path's condition)
+        ctx.synchronize()
+        outs.append([torch.view_as_real(y).view(torch.int32).cpu().numpy() for y in ys])
+        clocks.append(ch.time())
+        ch.close()
+    assert clocks[0] == clocks[1]
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert np.array_equal(a, b), "call %d (%d samples) differs" % (i, sizes[i])
+    ctx.close()
