@@ -361,12 +361,14 @@ static bool mm2_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *i
 // complete when it calls.
 static int pipeline_ready(hzsdr_chain *c) {
     hzsdr_ctx *ctx = c->ctx;
-    if (c->pstream[0]) return HZSDR_OK;
+    if (c->ev_in) return HZSDR_OK;  // (created last: everything else exists)
     for (hipStream_t *s : {&c->pstream[0], &c->pstream[1]}) {
+        if (*s) continue;  // (left by an earlier attempt that failed further down)
         HZ_HIP(ctx, hipStreamCreateWithFlags(s, hipStreamNonBlocking));
         ctx->side_streams.push_back(*s);
     }
-    for (int k = 0; k < 4; k++) HZ_HIP(ctx, hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
+    for (int k = 0; k < 4; k++)
+        if (!c->ev_done[k]) HZ_HIP(ctx, hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
     HZ_HIP(ctx, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     return HZSDR_OK;
 }
