@@ -40,6 +40,7 @@ timeout 600 tools/bin/narrow_check 40 > $out/narrow_check_device.txt 2>&1
 python3 tools/conv_time.py 2>&1 | grep " us" > $out/conv_time.txt
 python3 tools/inplace_test.py 2>&1 | grep " us" > $out/shift_in_place.txt
 timeout 900 python3 tools/repeat_check.py 500 > $out/repeat_check.txt 2>&1
+PIPELINE=1 timeout 900 python3 tools/repeat_check.py 300 > $out/repeat_check_pipelined_run.txt 2>&1
 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" > $out/firmm_probe.txt
 PROBE_IMPL=2 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" >> $out/firmm_probe.txt
 PROBE_IMPL=1 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" >> $out/firmm_probe.txt

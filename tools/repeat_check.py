@@ -20,7 +20,16 @@ outs = []
 for rep in range(R):
     ch = ctx.chain(hz.FMT_U8, fs).shift(-fs / 8).fir_decimate(taps, D)
     out = torch.zeros(2 * n // D, dtype=torch.complex64, device="cuda")
-    ch.run(dx[:n], out[:n // D]); ch.set_time(TAU - 0.4); ch.run(dx[n:], out[n // D:]); ctx.synchronize()
+    torch.cuda.synchronize()
+    if os.environ.get("PIPELINE"):  # hzsdr_chain_pipeline: four calls, the last three overlapping their predecessors
+        ch.pipeline(True)
+        ch.set_time(TAU - 1.2)
+        h = n // 2
+        for j in range(4):
+            ch.run(dx[j * h:(j + 1) * h], out[j * h // D:(j + 1) * h // D])
+        ctx.synchronize()
+    else:
+        ch.run(dx[:n], out[:n // D]); ch.set_time(TAU - 0.4); ch.run(dx[n:], out[n // D:]); ctx.synchronize()
     ch.close()
     outs.append(torch.view_as_real(out).view(torch.int32).clone())
 # majority vote per element is costly; count pairwise differences against the modal run
