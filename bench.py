@@ -466,6 +466,21 @@ def main():
         ch = ctx.chain(hz.FMT_C64, fs).shift(2.5e6).gain(0.5)
         both("shift_gain_c64", lambda i: ch.run(cs[i % kRot], outs[i % kRot]), 16)
         ch.close()
+        # ... and with hzsdr_chain_pipeline (consecutive calls overlap on two streams: rotating buffers only -- the
+        # mode's contract is that a call's buffers are free of pending work)
+        ch = ctx.chain(hz.FMT_C64, fs).shift(2.5e6).gain(0.5).pipeline(True)
+        _, ms = timed_rot(torch, lambda i: ch.run(cs[i % kRot], outs[i % kRot]), k, w)
+        extra["shift_gain_c64"]["hbm_pipelined"] = dict(rate(n, float(np.median(ms)), 16), buffer_pairs=kRot,
+                                                        note="per-call events around OVERLAPPING calls: see wall_ms")
+        torch.cuda.synchronize()
+        t_w = time.perf_counter()
+        for i in range(k):
+            ch.run(cs[i % kRot], outs[i % kRot])
+        torch.cuda.synchronize()
+        wall_ms = (time.perf_counter() - t_w) / k * 1e3
+        extra["shift_gain_c64"]["hbm_pipelined"].update(wall_ms=round(wall_ms, 4), wall_GBps=round(16 * n / (wall_ms * 1e-3) / 1e9, 1),
+                                                        wall_hbm_frac=round(16 * n / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        ch.close()
         # ... and with the opt-in <= 1-ulp rotation factor (hzsdr_chain_shift_ulp1: not bit-identical, not `value`)
         ch = ctx.chain(hz.FMT_C64, fs).shift(2.5e6).gain(0.5).shift_ulp1()
         both("shift_gain_c64_ulp1", lambda i: ch.run(cs[i % kRot], outs[i % kRot]), 16)

@@ -359,7 +359,7 @@ static bool mm2_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *i
 // launches, and the context's stream made to wait for the call's kernel (the caller's later work sees the output).
 // The launches are NOT ordered behind whatever else the context's stream holds: the caller guarantees the input is
 // complete when it calls.
-static int pipeline_ready(hzsdr_chain *c) {
+int pipeline_streams(hzsdr_chain *c) {
     hzsdr_ctx *ctx = c->ctx;
     if (c->ev_in) return HZSDR_OK;  // (created last: everything else exists)
     for (hipStream_t *s : {&c->pstream[0], &c->pstream[1]}) {
@@ -388,7 +388,7 @@ int pipeline_drain(hzsdr_chain *c) {
 static int mm2_launch_pipelined(hzsdr_chain *c, const void *in, void *out, size_t n, const EwProgram &P, const mm2::Plan &L,
                                 const mm2::Fix &F, const mm2::Geom &g2) {
     hzsdr_ctx *ctx = c->ctx;
-    HZ_TRY(pipeline_ready(c));
+    HZ_TRY(pipeline_streams(c));
     const uint64_t k = c->pcall;
     hipStream_t a = c->pstream[k & 1], b = c->pstream[(k + 1) & 1];
     if (k == 0) {  // the first call behind a drain: the history it reads was written on the context's stream

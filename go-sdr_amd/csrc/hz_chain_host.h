@@ -138,5 +138,7 @@ int chain_terminal_set(hzsdr_chain *c);
 // hz_chain_fir.hip: the context's stream waits for everything a pipelined chain has in flight (its next call, a
 // reset, a change of the clock and the end of the chain all need that)
 int pipeline_drain(hzsdr_chain *c);
+// the chain's two streams and events, created on first use
+int pipeline_streams(hzsdr_chain *c);
 
 }  // namespace hz

@@ -376,13 +376,17 @@ int hzsdr_chain_mix_in_order(hzsdr_chain *c, int in_order);
 #define HZSDR_FIR_IMPL_TRANSFORMS 1     /* the overlap-save transform kernels */
 #define HZSDR_FIR_IMPL_MATRIX_CHUNKS 2  /* the int8 matrix form as chunk workgroups (hz_firmm.h), where eligible */
 int hzsdr_chain_fir_options(hzsdr_chain *c, int impl, unsigned nfft_min, int loop_form);
-/* OPT-IN, off by default: consecutive hzsdr_chain_run calls of a FIR-decimate chain on the int8 matrix path OVERLAP.
+/* OPT-IN, off by default: consecutive hzsdr_chain_run calls of a FIR-decimate chain on the int8 matrix path, or of a
+ * chain without a terminal stage (convert / Shift / Gain / Multiply maps), OVERLAP.
  * A stream runs its launches one behind the other -- the next call's workgroups wait for the last workgroup of this
  * one and then pay the kernel's head in full: ~5 us of 37 per 2^24-sample buffer.  The calls of one chain depend on
  * each other through the FIR history alone, which is a function of the call's input; a pipelined chain forms it in
  * a small kernel of its own and alternates its calls between two streams it owns.  What changes for the caller:
- *   - the INPUT of a call must be complete when hzsdr_chain_run is called (the launch is not ordered behind earlier
- *     work on the context's stream, e.g. an asynchronous copy that fills the buffer: synchronise that first), and
+ *   - the buffers of a call must be FREE OF PENDING WORK when hzsdr_chain_run is called: the launch is not ordered
+ *     behind earlier work on the context's stream, so the input must be complete (an asynchronous copy that fills it:
+ *     synchronise that first; the previous call's output is not complete -- consecutive calls use different buffers)
+ *     and the output buffer no longer read by anything still queued (two output buffers used alternately, each
+ *     consumed before its next use is submitted).  The input
  *     must stay as it is until the NEXT call's output is complete or the context has been synchronised with
  *     hzsdr_synchronize (the small kernel that forms the next call's history reads its last samples, beside the
  *     call's own kernel);

@@ -399,3 +399,41 @@ def test_pipelined_chain_random_calls_bit_identical(hz, seed):
     for i, (a, b) in enumerate(zip(*outs)):
         assert np.array_equal(a, b), "call %d (%d samples) differs" % (i, sizes[i])
     ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["c64_shift_gain", "u8_shift", "c64_shift_ulp1"])
+def test_pipelined_map_chain_is_bit_identical(hz, kind):
+    """hzsdr_chain_pipeline on a chain without a terminal: consecutive calls alternate between two streams (nothing on
+    the device carries over; the clock is the host's) -- rotating buffers in, distinct buffers out, every bit as the
+    plain chain's over thirty calls across the 2 pi wrap, with a ragged call and a clock change in between."""
+    import torch
+    from util import rand_c64
+    n, fs = 1 << 19, 20_000_000
+    fmt, gen = (hz.FMT_U8, rand_u8) if kind == "u8_shift" else (hz.FMT_C64, rand_c64)
+    xs = [torch.from_numpy(gen(700 + i, n)).cuda() for i in range(4)]
+    ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+    outs, clocks = [], []
+    for piped in (False, True):
+        ch = ctx.chain(fmt, fs).shift(2.5e6)
+        if kind == "c64_shift_gain":
+            ch = ch.gain(0.5)
+        if kind == "c64_shift_ulp1":
+            ch = ch.shift_ulp1()
+        if piped:
+            ch.pipeline(True)
+        ch.set_time(TAU - 0.3)
+        sizes = [n - 3 if i == 7 else n for i in range(30)]
+        ys = [torch.zeros(m, dtype=torch.complex64, device="cuda") for m in sizes]
+        torch.cuda.synchronize()
+        for i, m in enumerate(sizes):
+            if i == 19:
+                ch.set_time(1.9)
+            assert ch.run(xs[i % 4][:m], ys[i]) == (m, m)
+        ctx.synchronize()
+        outs.append([torch.view_as_real(y).view(torch.int32).cpu().numpy() for y in ys])
+        clocks.append(ch.time())
+        ch.close()
+    assert clocks[0] == clocks[1]
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert np.array_equal(a, b), "call %d differs" % i
+    ctx.close()
