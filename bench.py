@@ -125,6 +125,10 @@ def main():
     ap.add_argument("--no-oracle", action="store_true", help="skip everything that needs oracle/ (profiling runs)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="the headline chain WITHOUT hzsdr_chain_pipeline: one launch behind the other, as rounds 1-3 measured")
+    ap.add_argument("--batch", type=int, default=4,
+                    help="buffers handed to the chain per call (hzsdr_chain_run_batch: ONE launch over `batch` buffers of "
+                         "the stream, the kernel's head, launch and tail paid once per call); 1: one call per buffer as "
+                         "rounds 1-4 measured.  A step stays one 2^log2n-sample buffer")
     ap.add_argument("--buffers", type=int, default=12,
                     help="distinct 2^log2n-sample input buffers the steps rotate through (12 x 32 MiB of u8 "
                          "is more than the 256 MiB Infinity Cache: every step reads its input from HBM)")
@@ -177,33 +181,44 @@ def main():
     # ---- the headline step: fused north-star chain ---------------------------------
     nbuf = max(1, args.buffers)
     xs = [torch.from_numpy(synth_u8(9 + rank + 101 * i, n)).cuda() for i in range(nbuf)]
-    ys = [torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(min(nbuf, 4))]
+    B = max(1, min(8, args.batch, nbuf))
+    # (outputs: two calls' worth in rotation -- an overlapped call must not write what the call before it writes)
+    ys = [torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(max(4, 2 * B))]
     x, y = xs[0], ys[0]
     chain = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D)
-    # hzsdr_chain_pipeline (round 4): consecutive calls of the chain overlap -- the next launch's workgroups start on
-    # the compute units as this one's finish instead of behind its last one; bit-identical results, the inputs are
-    # resident and complete long before the calls (the mode's contract)
+    # hzsdr_chain_pipeline + hzsdr_chain_run(_batch)_after: consecutive calls of the chain overlap -- the next launch's
+    # workgroups start on the compute units as this one's finish instead of behind its last one; bit-identical
+    # results.  The call states what its buffers wait for: nothing -- the inputs are resident and complete long before
+    # the timed region, the outputs rotate
     piped = not args.no_pipeline
     if piped:
         chain.pipeline(True)
     it = [0]
 
-    def step():
-        # one stream: the NCO clock and the FIR history carry on from buffer to buffer
+    def submit(ch, k, after):
+        # one stream: the NCO clock and the FIR history carry on from buffer to buffer; k buffers per call
         i = it[0]
-        it[0] = i + 1
-        chain.run(xs[i % nbuf], ys[i % len(ys)])
+        it[0] = i + k
+        if k == 1:
+            (ch.run_after if after else ch.run)(xs[i % nbuf], ys[i % len(ys)])
+        else:
+            ch.run_batch([xs[(i + j) % nbuf] for j in range(k)], [ys[(i + j) % len(ys)] for j in range(k)], after=after)
+
+    def run_steps(ch, steps, batch, after):
+        full, rem = divmod(steps, batch)
+        for _ in range(full):
+            submit(ch, batch, after)
+        if rem:
+            submit(ch, rem, after)
 
     ramp_steps = 0
     if args.ramp_ms > 0:  # untimed clock ramp (see --ramp-ms), in bursts so the host does not run far ahead
         t_r = time.perf_counter()
         while time.perf_counter() - t_r < args.ramp_ms * 1e-3:
-            for _ in range(50):
-                step()
+            run_steps(chain, 48, B, piped)
             torch.cuda.synchronize()
-            ramp_steps += 50
-    for _ in range(args.warmup):
-        step()
+            ramp_steps += 48
+    run_steps(chain, args.warmup, B, piped)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -213,8 +228,7 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(args.steps):
-        step()
+    run_steps(chain, args.steps, B, piped)
     ev1.record()
     torch.cuda.synchronize()
     if world > 1:
@@ -228,19 +242,23 @@ def main():
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # device time per step, launch gaps included
     # the same chain one launch behind the other, in the same run: what ONE launch takes (and what rocprofv3 lists
     # per launch, `--no-pipeline`), beside the time per step of overlapping launches
-    kernel_ms_plain = None
-    if piped and world == 1:
+    kernel_ms_plain = kernel_ms_batch_plain = None
+    if (piped or B > 1) and world == 1:
         plain = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D)
-        for i in range(150):
-            plain.run(xs[i % nbuf], ys[i % len(ys)])
-        torch.cuda.synchronize()
-        pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        pe0.record()
-        for i in range(300):
-            plain.run(xs[i % nbuf], ys[i % len(ys)])
-        pe1.record()
-        torch.cuda.synchronize()
-        kernel_ms_plain = pe0.elapsed_time(pe1) / 300
+
+        def time_plain(batch):
+            run_steps(plain, 144, batch, False)
+            torch.cuda.synchronize()
+            pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            pe0.record()
+            run_steps(plain, 288, batch, False)
+            pe1.record()
+            torch.cuda.synchronize()
+            return pe0.elapsed_time(pe1) / 288
+
+        kernel_ms_plain = time_plain(1)           # one hzsdr_chain_run per buffer, one launch behind the other
+        if B > 1:
+            kernel_ms_batch_plain = time_plain(B)  # hzsdr_chain_run_batch, ordinary stream order
         plain.close()
     value = world * n * args.steps / elapsed / 1e6  # Msamples/s, whole job
     alg_bytes = (2 + 8 / D) * n                     # 2 B read + 8/D B written per input sample
@@ -281,17 +299,23 @@ def main():
         roof.update({
             "kernel": ("hz::mm2::fir_mm2_kernel<u8, D = 8, 17 groups>" if passes_form else "hz::mm::fir_mm_kernel<u8, D = 8>"),
             "kernel_ms": round(kernel_ms, 4),
-            "kernel_ms_is": ("device time per chain_run (one kernel), one HIP-event pair around the timed loop / steps"
-                             + ("; the chain is PIPELINED (hzsdr_chain_pipeline): consecutive launches overlap on two streams of "
-                                "the chain's own (the context's stream, on which the events sit, waits for every launch), so this "
-                                "is time per step of the overlapped sequence -- ONE launch by itself takes kernel_ms_unpipelined, "
-                                "which is what rocprofv3 lists per launch" if piped else "")),
+            "kernel_ms_is": ("device time per STEP (one 2^%d-sample buffer): one HIP-event pair around the timed loop / steps" % args.log2n
+                             + ("; %d buffers per launch (hzsdr_chain_run_batch): the kernel's head, launch and tail are paid once per "
+                                "call -- a launch lasts kernel_ms x %d" % (B, B) if B > 1 else "")
+                             + ("; the chain is PIPELINED (hzsdr_chain_pipeline, calls through hzsdr_chain_run%s_after with nothing to "
+                                "wait for): consecutive launches overlap on two streams of the chain's own (the context's stream, on "
+                                "which the events sit, waits for every launch), so this is time per step of the overlapped sequence"
+                                % ("_batch" if B > 1 else "") if piped else "")
+                             + " -- ONE single-buffer launch by itself takes kernel_ms_unpipelined, which is what rocprofv3 lists per "
+                               "launch of the `--no-pipeline --batch 1` run"),
             "kernel_ms_unpipelined": (round(kernel_ms_plain, 4) if kernel_ms_plain else None),
-            "algorithmic_bytes_per_launch": int(alg_bytes),
+            "kernel_ms_batch_unpipelined": (round(kernel_ms_batch_plain, 4) if kernel_ms_batch_plain else None),
+            "buffers_per_launch": B,
+            "algorithmic_bytes_per_launch": int(alg_bytes) * B,
             "fp32_vector_frac": round(fp32_vec, 4),
             "mfma_algorithmic_frac": round(alg_ops / t_s / 1e12 / I8_PEAK_TOPS, 4),
             "mfma_issue": {
-                "executed_int8_ops_per_launch": int(exe_ops),
+                "executed_int8_ops_per_launch": int(exe_ops) * B,
                 "ops_are": "int8 multiply-adds x 2 as issued: v_mfma_i32_32x32x32_i8 instructions x 65 536 -- the 4 "
                            "base-256 digit planes of the 32-bit fixed-point taps (two planes share an A fragment "
                            "in the passes form), tiles x window steps, the tile windows' zero padding included -- "
@@ -337,9 +361,11 @@ def main():
                          "chain_run per buffer = ONE kernel: the filter over the raw bytes as an int8 "
                          "matrix product with the clock run's modulated taps, the mixer at the decimated "
                          "rate, outputs across clock boundaries in reference order; input resident in HBM"
-                         + ("; PIPELINED (hzsdr_chain_pipeline): consecutive calls overlap on two streams of the chain's own, "
-                            "the next call's FIR history formed from the call's input by a 16-wave kernel beside the matrix "
-                            "kernel -- bit-identical outputs, checked pipelined under `parity`" if piped else ""))
+                         + ("; %d consecutive buffers per call (hzsdr_chain_run_batch: one launch)" % B if B > 1 else "")
+                         + ("; PIPELINED (hzsdr_chain_pipeline + hzsdr_chain_run%s_after): consecutive calls overlap on two streams "
+                            "of the chain's own, the next call's FIR history formed from the call's input by a 16-wave kernel "
+                            "beside the matrix kernel -- both joined to the context's stream; checked in this form under `parity`"
+                            % ("_batch" if B > 1 else "") if piped else ""))
                         if matrix else
                         ("north-star chain: u8->c64->Shift(-fs/8)->1024-tap FIR->decimate-by-8, one "
                          "chain_run per buffer = analysis kernel (convert, 4096-point overlap-save "
@@ -348,6 +374,7 @@ def main():
             "samples_per_buffer": n, "sample_rate": fs, "taps": ntaps, "decimation": D,
             "parallelism": "1 stream per GPU (replicas)" if world > 1 else "1 GPU",
             "pipelined": piped,
+            "buffers_per_call": B,
         },
         "roofline": roof,
     }
@@ -466,16 +493,16 @@ def main():
         ch = ctx.chain(hz.FMT_C64, fs).shift(2.5e6).gain(0.5)
         both("shift_gain_c64", lambda i: ch.run(cs[i % kRot], outs[i % kRot]), 16)
         ch.close()
-        # ... and with hzsdr_chain_pipeline (consecutive calls overlap on two streams: rotating buffers only -- the
-        # mode's contract is that a call's buffers are free of pending work)
+        # ... and with hzsdr_chain_pipeline through hzsdr_chain_run_after (consecutive calls overlap on two streams;
+        # the buffers rotate, nothing to wait for)
         ch = ctx.chain(hz.FMT_C64, fs).shift(2.5e6).gain(0.5).pipeline(True)
-        _, ms = timed_rot(torch, lambda i: ch.run(cs[i % kRot], outs[i % kRot]), k, w)
+        _, ms = timed_rot(torch, lambda i: ch.run_after(cs[i % kRot], outs[i % kRot]), k, w)
         extra["shift_gain_c64"]["hbm_pipelined"] = dict(rate(n, float(np.median(ms)), 16), buffer_pairs=kRot,
                                                         note="per-call events around OVERLAPPING calls: see wall_ms")
         torch.cuda.synchronize()
         t_w = time.perf_counter()
         for i in range(k):
-            ch.run(cs[i % kRot], outs[i % kRot])
+            ch.run_after(cs[i % kRot], outs[i % kRot])
         torch.cuda.synchronize()
         wall_ms = (time.perf_counter() - t_w) / k * 1e3
         extra["shift_gain_c64"]["hbm_pipelined"].update(wall_ms=round(wall_ms, 4), wall_GBps=round(16 * n / (wall_ms * 1e-3) / 1e9, 1),
@@ -584,10 +611,19 @@ def main():
         yg = torch.zeros(ns // D, dtype=torch.complex64, device="cuda")
         xg = torch.from_numpy(xs0).cuda()
         torch.cuda.synchronize()
-        # (four calls: with the pipeline on, the second to fourth read a history formed by the history kernel and overlap)
-        q = ns // 4
-        for j in range(4):
-            chk.run(xg[j * q:(j + 1) * q], yg[j * q // D:(j + 1) * q // D])
+        # (the benchmarked form: calls of B buffers -- eight pieces of the check's samples -- through the same entry
+        # points; with the pipeline on, the calls behind the first read a history formed by the history kernel and overlap)
+        q = ns // 8
+        pieces_in = [xg[j * q:(j + 1) * q] for j in range(8)]
+        pieces_out = [yg[j * q // D:(j + 1) * q // D] for j in range(8)]
+        j = 0
+        while j < 8:
+            kk = min(B, 8 - j)
+            if kk == 1:
+                (chk.run_after if piped else chk.run)(pieces_in[j], pieces_out[j])
+            else:
+                chk.run_batch(pieces_in[j:j + kk], pieces_out[j:j + kk], after=piped)
+            j += kk
         torch.cuda.synchronize()
         got = yg.cpu().numpy().astype(np.complex128)
         err = float(np.abs(got - want).max())

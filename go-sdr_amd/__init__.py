@@ -140,6 +140,19 @@ def _ptr(x):
     return x.ctypes.data
 
 
+def _event(ev):
+    """A hipEvent_t for the C ABI: None, a raw handle (int), or a torch.cuda.Event that has been recorded (torch
+    creates the underlying event lazily, at its first record)."""
+    if ev is None:
+        return None
+    if isinstance(ev, int):
+        return ev
+    h = getattr(ev, "cuda_event", None)
+    if not h:
+        raise ValueError("run_after: the torch.cuda.Event has not been recorded yet")
+    return int(h)
+
+
 def make_samples(fmt, n, device=None):
     """sdr.MakeSamples(format, n) (iq.go:128-141); device=None -> numpy."""
     if fmt not in (FMT_C64, FMT_U8, FMT_I16, FMT_I8):
@@ -575,9 +588,10 @@ class Chain:
         return self
 
     def pipeline(self, on=True):
-        """Opt in to overlapping consecutive runs of a FIR-decimate chain on the matrix path (include/hzsdr.h:
-        hzsdr_chain_pipeline): the input of a run must be complete when run() is called; outputs stay ordered on the
-        context's stream; results are bit-identical."""
+        """Opt in to overlapping consecutive runs of a FIR-decimate chain on the matrix path or of a map chain
+        (include/hzsdr.h: hzsdr_chain_pipeline).  run() stays an ordinary call on the context's stream; the overlap
+        is taken by run_after() / run_batch_after(), where the caller says what the buffers wait for.  Results are
+        bit-identical."""
         self.ctx._ck(lib.hzsdr_chain_pipeline(self._h, int(on)))
         return self
 
@@ -596,6 +610,31 @@ class Chain:
         n_in = length(inp) if n_in is None else n_in
         self.ctx._ck(lib.hzsdr_chain_run(self._h, _ptr(inp), n_in, _ptr(out), length(out),
                                          C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def run_after(self, inp, out, ready_event=None, n_in=None):
+        """run() whose start is ordered by the caller (hzsdr_chain_run_after): the buffers are ready when
+        `ready_event` (a torch.cuda.Event that has been recorded, a raw hipEvent_t as an int, or None = now) has fired."""
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        n_in = length(inp) if n_in is None else n_in
+        self.ctx._ck(lib.hzsdr_chain_run_after(self._h, _ptr(inp), n_in, _ptr(out), length(out), C.byref(a), C.byref(b),
+                                               _event(ready_event)))
+        return a.value, b.value
+
+    def run_batch(self, inps, outs, ready_event=None, after=False, n_in=None):
+        """len(inps) consecutive buffers of the stream in one call (hzsdr_chain_run_batch; after=True or an event:
+        hzsdr_chain_run_batch_after).  Returns (consumed, produced) per buffer."""
+        k = len(inps)
+        assert k == len(outs) and k >= 1
+        pi = (C.c_void_p * k)(*[_ptr(x) for x in inps])
+        po = (C.c_void_p * k)(*[_ptr(x) for x in outs])
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        n_in = length(inps[0]) if n_in is None else n_in
+        cap = min(length(o) for o in outs)
+        if after or ready_event is not None:
+            self.ctx._ck(lib.hzsdr_chain_run_batch_after(self._h, pi, po, k, n_in, cap, C.byref(a), C.byref(b), _event(ready_event)))
+        else:
+            self.ctx._ck(lib.hzsdr_chain_run_batch(self._h, pi, po, k, n_in, cap, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def reset(self):

@@ -148,6 +148,9 @@ SIGNATURES = {
     "hzsdr_chain_pipeline": (i32, [vp, i32]),
     "hzsdr_chain_plan": (i32, [vp, sz, psz, psz]),
     "hzsdr_chain_run": (i32, [vp, vp, sz, vp, sz, psz, psz]),
+    "hzsdr_chain_run_after": (i32, [vp, vp, sz, vp, sz, psz, psz, vp]),
+    "hzsdr_chain_run_batch": (i32, [vp, vp, vp, sz, sz, sz, psz, psz]),
+    "hzsdr_chain_run_batch_after": (i32, [vp, vp, vp, sz, sz, sz, psz, psz, vp]),
     "hzsdr_mgpu_open": (i32, [C.POINTER(C.c_int), i32, pvp]),
     "hzsdr_mgpu_close": (i32, [vp]),
     "hzsdr_mgpu_shards": (i32, [vp]),

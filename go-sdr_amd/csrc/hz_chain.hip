@@ -108,29 +108,27 @@ static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, cons
 
 template <int FMT>
 static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, size_t n_out,
-                   const EwProgram &P) {
+                   const EwProgram &P, const CallBatch *cb) {
     hzsdr_ctx *ctx = c->ctx;
+    if (cb && cb->nbuf > 1 && c->term != TERM_FIR) return kBatchFallback;
+    if (c->term != TERM_NONE && c->term != TERM_FIR) HZ_TRY(pipeline_drain(c));  // (these run on the context's stream)
     switch (c->term) {
     case TERM_NONE:
-        if (c->pipelined && ctx->memspace == HZSDR_MEM_DEVICE && P.segs.big_n == 0) {  // (the long clock table lives in ONE scratch slot)
-            // hzsdr_chain_pipeline on a chain without a terminal: nothing on the device carries over from call to call
-            // (the clock is the host's), so consecutive calls simply alternate between the chain's two streams and
-            // the context's stream waits for each -- two launches in flight keep the memory system busy through the
-            // tail of one and the head of the next (Shift + Gain from HBM: 45.5 us per 2^24 samples against 50.4)
-            HZ_TRY(pipeline_streams(c));
-            const uint64_t k = c->pcall;
-            hipStream_t a = c->pstream[k & 1], saved = ctx->stream;
-            if (k == 0) {  // (behind whatever the chain did on the context's stream before)
-                HZ_HIP(ctx, hipEventRecord(c->ev_in, saved));
-                HZ_HIP(ctx, hipStreamWaitEvent(a, c->ev_in, 0));
-                HZ_HIP(ctx, hipStreamWaitEvent(c->pstream[1], c->ev_in, 0));
-            }
+        if (c->pipelined && c->relaxed && P.segs.big_n == 0) {  // (the long clock table lives in ONE scratch slot)
+            // hzsdr_chain_pipeline on a chain without a terminal, a call that says what its buffers wait for
+            // (hzsdr_chain_run_after): nothing on the device carries over from call to call (the clock is the host's),
+            // so consecutive calls alternate between the chain's two streams and the context's stream waits for each
+            // -- two launches in flight keep the memory system busy through the tail of one and the head of the next
+            // (Shift + Gain from HBM: 45.5 us per 2^24 samples against 50.4)
+            const void *in1[1] = {in};
+            void *out1[1] = {out};
+            const CallBatch one{in1, out1, 1, n_cons, n_out};
+            hipStream_t a, saved = ctx->stream;
+            HZ_TRY(pipeline_begin(c, one, format_size(FMT), &a, nullptr));
             ctx->stream = a;
             launch_map<FMT>(ctx, in, out, n_cons, P, c->shift_ulp1);
             ctx->stream = saved;
-            HZ_HIP(ctx, hipEventRecord(c->ev_done[k & 3], a));
-            HZ_HIP(ctx, hipStreamWaitEvent(saved, c->ev_done[k & 3], 0));
-            c->pcall = k + 1;
+            HZ_TRY(pipeline_join(c, a, nullptr));
             break;
         }
         HZ_TRY(pipeline_drain(c));
@@ -148,14 +146,17 @@ static int run_fmt(hzsdr_chain *c, const void *in, size_t n_cons, void *out, siz
     case TERM_CONV:
         return conv_blocks_device(ctx, FMT, c->flen, in, out, c->filt, n_cons / c->flen, c->factor,
                                   c->factor > 1 ? kReaderBlock / c->factor : 0, P);
-    case TERM_FIR: return fir_run<FMT>(c, in, n_cons, out, P);
+    case TERM_FIR: return fir_run<FMT>(c, in, n_cons, out, P, cb);
     }
     return HZSDR_OK;
 }
 
 // The chain's kernel(s) over device buffers, enqueued on the context's stream.
 // *ts_after is the NCO clock after `cons` samples; the caller commits it.
-int chain_launch(hzsdr_chain *c, const void *din, size_t cons, void *dout, size_t outn, double *ts_after) {
+// (cb with nbuf > 1: `cons` / `outn` are the whole call's, din / dout its first buffers; kBatchFallback -- nothing
+// launched, nothing committed -- when the chain cannot take the buffers in one launch)
+int chain_launch(hzsdr_chain *c, const void *din, size_t cons, void *dout, size_t outn, double *ts_after, const CallBatch *cb) {
+    if (cb && cb->nbuf > 1 && !(c->term == TERM_FIR && c->mm_ok && c->mm_ver == 2)) return kBatchFallback;
     EwProgram P{};
     P.n = c->n_ops;
     for (int i = 0; i < c->n_ops; i++) P.op[i] = c->ops[i];
@@ -163,12 +164,12 @@ int chain_launch(hzsdr_chain *c, const void *din, size_t cons, void *dout, size_
     if (c->has_shift) HZ_TRY(nco_plan(c->ctx, c->sample_rate, &ts, cons, &P.segs));
     int rc;
     switch (c->src_fmt) {
-    case HZSDR_FMT_C64: rc = run_fmt<HZSDR_FMT_C64>(c, din, cons, dout, outn, P); break;
-    case HZSDR_FMT_U8: rc = run_fmt<HZSDR_FMT_U8>(c, din, cons, dout, outn, P); break;
-    case HZSDR_FMT_I8: rc = run_fmt<HZSDR_FMT_I8>(c, din, cons, dout, outn, P); break;
-    default: rc = run_fmt<HZSDR_FMT_I16>(c, din, cons, dout, outn, P); break;
+    case HZSDR_FMT_C64: rc = run_fmt<HZSDR_FMT_C64>(c, din, cons, dout, outn, P, cb); break;
+    case HZSDR_FMT_U8: rc = run_fmt<HZSDR_FMT_U8>(c, din, cons, dout, outn, P, cb); break;
+    case HZSDR_FMT_I8: rc = run_fmt<HZSDR_FMT_I8>(c, din, cons, dout, outn, P, cb); break;
+    default: rc = run_fmt<HZSDR_FMT_I16>(c, din, cons, dout, outn, P, cb); break;
     }
-    HZ_TRY(rc);
+    if (rc != HZSDR_OK) return rc;
     *ts_after = ts;
     return HZSDR_OK;
 }
@@ -313,31 +314,88 @@ int hzsdr_chain_plan(const hzsdr_chain *c, size_t n_in, size_t *n_consumed, size
     return HZSDR_OK;
 }
 
-int hzsdr_chain_run(hzsdr_chain *c, const void *in, size_t n_in, void *out, size_t out_cap,
-                    size_t *n_consumed, size_t *n_out) {
+// One call of the chain over nbuf buffers of n_in samples each (nbuf = 1: hzsdr_chain_run).  relaxed: the caller says
+// what the buffers wait for (`ready`: an event, null: nothing) instead of "whatever the context's stream holds".
+static int chain_run_impl(hzsdr_chain *c, const void *const *ins, void *const *outs, size_t nbuf, size_t n_in, size_t out_cap,
+                          size_t *n_consumed, size_t *n_out, bool relaxed, hipEvent_t ready) {
     using namespace hz;
     if (n_consumed) *n_consumed = 0;
     if (n_out) *n_out = 0;
     if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
     hzsdr_ctx *ctx = c->ctx;
+    if (nbuf == 0 || nbuf > (size_t)mm2::kMaxBatch || !ins || !outs)
+        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: a call takes 1..8 buffers");
     size_t cons, outn;
     hzsdr_chain_plan(c, n_in, &cons, &outn);
     if (out_cap < outn) return fail(ctx, HZSDR_ERR_DST_TOO_SMALL, "chain: output buffer too small");
-    if (cons && (!in || !out)) return HZSDR_ERR_INVALID_ARGUMENT;
+    for (size_t j = 0; j < nbuf; j++)
+        if (cons && (!ins[j] || !outs[j])) return HZSDR_ERR_INVALID_ARGUMENT;
+    if (nbuf > 1 && cons != n_in) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: the buffers of a batch are consumed whole (a multiple of the chain's block)");
     HZ_TRY(enter(ctx));
     if (cons == 0) return HZSDR_OK;
-    Stage st(ctx);
-    const void *din;
-    void *dout;
-    HZ_TRY(st.in(0, in, cons * format_size(c->src_fmt), &din));
-    HZ_TRY(st.out(1, out, outn * 8, &dout));
-    double ts;
-    HZ_TRY(chain_launch(c, din, cons, dout, outn, &ts));
-    HZ_TRY(st.finish());
-    c->ts = ts;
+    const bool device = ctx->memspace == HZSDR_MEM_DEVICE;
+    if (ready) {
+        // a HOST-space call (synchronous, staged on the context's stream) and a chain that does not overlap its calls
+        // simply wait for the event where every call waits: on the host / on the context's stream
+        if (!device) HZ_HIP(ctx, hipEventSynchronize(ready));
+        else if (!(relaxed && c->pipelined)) HZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ready, 0));
+    }
+    struct Scope {  // (the call's ordering lives in the chain for the launches' duration)
+        hzsdr_chain *c;
+        ~Scope() { c->relaxed = false, c->ready = nullptr; }
+    } scope{c};
+    c->relaxed = relaxed && device && c->pipelined;
+    c->ready = c->relaxed ? ready : nullptr;
+    if (nbuf > 1 && device) {  // the buffers in ONE launch where the chain has such a form
+        const CallBatch cb{ins, outs, nbuf, cons, outn};
+        double ts;
+        const int rc = chain_launch(c, ins[0], cons * nbuf, outs[0], outn * nbuf, &ts, &cb);
+        if (rc == HZSDR_OK) {
+            c->ts = ts;
+            if (n_consumed) *n_consumed = cons;
+            if (n_out) *n_out = outn;
+            return HZSDR_OK;
+        }
+        if (rc != kBatchFallback) return rc;
+    }
+    for (size_t j = 0; j < nbuf; j++) {  // one by one: the same results as nbuf calls
+        Stage st(ctx);
+        const void *din;
+        void *dout;
+        HZ_TRY(st.in(0, ins[j], cons * format_size(c->src_fmt), &din));
+        HZ_TRY(st.out(1, outs[j], outn * 8, &dout));
+        double ts;
+        HZ_TRY(chain_launch(c, din, cons, dout, outn, &ts));
+        HZ_TRY(st.finish());
+        c->ts = ts;
+    }
     if (n_consumed) *n_consumed = cons;
     if (n_out) *n_out = outn;
     return HZSDR_OK;
+}
+
+int hzsdr_chain_run(hzsdr_chain *c, const void *in, size_t n_in, void *out, size_t out_cap,
+                    size_t *n_consumed, size_t *n_out) {
+    const void *ins[1] = {in};
+    void *outs[1] = {out};
+    return chain_run_impl(c, ins, outs, 1, n_in, out_cap, n_consumed, n_out, false, nullptr);
+}
+
+int hzsdr_chain_run_after(hzsdr_chain *c, const void *in, size_t n_in, void *out, size_t out_cap,
+                          size_t *n_consumed, size_t *n_out, void *ready_event) {
+    const void *ins[1] = {in};
+    void *outs[1] = {out};
+    return chain_run_impl(c, ins, outs, 1, n_in, out_cap, n_consumed, n_out, true, (hipEvent_t)ready_event);
+}
+
+int hzsdr_chain_run_batch(hzsdr_chain *c, const void *const *ins, void *const *outs, size_t n_buffers, size_t n_in,
+                          size_t out_cap, size_t *n_consumed, size_t *n_out) {
+    return chain_run_impl(c, ins, outs, n_buffers, n_in, out_cap, n_consumed, n_out, false, nullptr);
+}
+
+int hzsdr_chain_run_batch_after(hzsdr_chain *c, const void *const *ins, void *const *outs, size_t n_buffers, size_t n_in,
+                                size_t out_cap, size_t *n_consumed, size_t *n_out, void *ready_event) {
+    return chain_run_impl(c, ins, outs, n_buffers, n_in, out_cap, n_consumed, n_out, true, (hipEvent_t)ready_event);
 }
 
 int hzsdr_chain_reset(hzsdr_chain *c) {
@@ -385,8 +443,10 @@ int hzsdr_chain_free(hzsdr_chain *c) {
             ss.erase(std::remove(ss.begin(), ss.end(), s), ss.end());
             (void)hipStreamDestroy(s);
         }
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 4; k++) {
         if (c->ev_done[k]) (void)hipEventDestroy(c->ev_done[k]);
+        if (c->ev_hist[k]) (void)hipEventDestroy(c->ev_hist[k]);
+    }
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     (void)hipStreamSynchronize(c->ctx->stream);
     if (c->filt) (void)hipFree(c->filt);

@@ -301,10 +301,15 @@ static int mm_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const 
 // no run holds -- windows that cross a boundary, the stream's start, runs without a table -- are fix-up tasks
 // of 8 outputs.  false: the call stays on the transform kernels.
 static bool mm2_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in, const void *out, mm2::Plan *L,
-                     mm2::Fix *F) {
+                     mm2::Fix *F, const CallBatch *cb = nullptr) {
     memset(L, 0, sizeof *L);
     memset(F, 0, sizeof *F);
     if (!c->mm_ok || c->mix_in_order || P.segs.big_n != 0 || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) return false;
+    if (cb && cb->nbuf > 1) {  // (a call over several buffers: every one aligned, whole passes per buffer, the history in the last)
+        if (!mm2::batch_ok(cb->n_each, c->factor, cb->nbuf) || cb->n_each < c->mmg.off) return false;
+        for (size_t j = 0; j < cb->nbuf; j++)
+            if ((((uintptr_t)cb->ins[j] | (uintptr_t)cb->outs[j]) & 15) != 0) return false;
+    }
     for (int i = 0; i < P.n; i++)
         if (P.op[i].kind == EW_SHIFT && !(fabs(P.op[i].tau_shift) * 6.2832 < 1073741824.0)) return false;
     const int nr = c->has_shift ? P.segs.n : 1;
@@ -355,10 +360,16 @@ static bool mm2_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *i
 //     call k:    history kernel k (writes the history call k+1 reads) on stream (k+1) mod 2,
 //                the call's kernel on stream k mod 2
 // so stream order alone puts kernel k+1 behind history kernel k, and history kernel k behind kernel k-3, the last
-// reader of the buffer it writes (a ring of four histories) -- no event between them, four API calls per call: two
-// launches, and the context's stream made to wait for the call's kernel (the caller's later work sees the output).
-// The launches are NOT ordered behind whatever else the context's stream holds: the caller guarantees the input is
-// complete when it calls.
+// reader of the buffer it writes (a ring of four histories).  BOTH kernels of a call are joined to the context's
+// stream as they are launched (an event each): whatever the caller enqueues there afterwards -- a consumer of the
+// output, a producer that refills the input -- is ordered behind them, as behind any other call.
+//
+// What cannot come from the context's stream is the call's START: that stream has just been made to wait for the
+// previous call, so a launch ordered behind it cannot overlap that call.  Round 4 simply did not order the launch
+// behind anything and said so in the header; a caller that filled its input on the context's stream raced.  Now the
+// overlap is taken ONLY by a call that says what its buffers wait for (hzsdr_chain_run_after: an event, or "nothing");
+// hzsdr_chain_run itself is an ordinary call on the context's stream whatever the mode.  What the library can see
+// itself it orders itself: a call whose buffers overlap those of the two calls before it starts over behind them.
 int pipeline_streams(hzsdr_chain *c) {
     hzsdr_ctx *ctx = c->ctx;
     if (c->ev_in) return HZSDR_OK;  // (created last: everything else exists)
@@ -367,62 +378,116 @@ int pipeline_streams(hzsdr_chain *c) {
         HZ_HIP(ctx, hipStreamCreateWithFlags(s, hipStreamNonBlocking));
         ctx->side_streams.push_back(*s);
     }
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 4; k++) {
         if (!c->ev_done[k]) HZ_HIP(ctx, hipEventCreateWithFlags(&c->ev_done[k], hipEventDisableTiming));
+        if (!c->ev_hist[k]) HZ_HIP(ctx, hipEventCreateWithFlags(&c->ev_hist[k], hipEventDisableTiming));
+    }
     HZ_HIP(ctx, hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     return HZSDR_OK;
 }
 
 int pipeline_drain(hzsdr_chain *c) {
-    if (c->pcall == 0) return HZSDR_OK;
-    hzsdr_ctx *ctx = c->ctx;
-    // (the calls' kernels are joined as they are launched; what is left is the last history kernel, on the stream
-    // of the call that has not come)
-    hipStream_t b = c->pstream[c->pcall & 1];
-    HZ_HIP(ctx, hipEventRecord(c->ev_in, b));
-    HZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->ev_in, 0));
+    // (every overlapped call was joined to the context's stream when it was launched: work enqueued there now is
+    // behind all of them; the chain's streams are re-seeded from it by the next overlapped call)
+    if (c->ready) {  // a call that named an event and runs on the context's stream after all: that stream waits for it
+        HZ_HIP(c->ctx, hipStreamWaitEvent(c->ctx->stream, c->ready, 0));
+        c->ready = nullptr;
+    }
     c->pcall = 0;
+    c->pbufs[0].nb = c->pbufs[1].nb = 0;
+    return HZSDR_OK;
+}
+
+static bool spans_overlap(const hzsdr_chain::Span &x, const hzsdr_chain::Span &y) {
+    return x.n && y.n && x.p < y.p + y.n && y.p < x.p + x.n;
+}
+
+int pipeline_begin(hzsdr_chain *c, const CallBatch &cb, int fmt_size, hipStream_t *a, hipStream_t *b) {
+    hzsdr_ctx *ctx = c->ctx;
+    HZ_TRY(pipeline_streams(c));
+    hzsdr_chain::CallBufs now;
+    now.nb = (int)cb.nbuf;
+    for (size_t j = 0; j < cb.nbuf; j++) {
+        now.in[j] = {(const char *)cb.ins[j], cb.n_each * (size_t)fmt_size};
+        now.out[j] = {(const char *)cb.outs[j], cb.out_each * 8};
+    }
+    // The call before this one runs on the other stream, unordered against this call's kernel: what this call
+    // writes must not be what that one reads or writes, what this call reads not what that one writes.  The call
+    // before that shares this call's stream, but its history kernel (on the other one) read its input.
+    bool clash = false;
+    const hzsdr_chain::CallBufs &p1 = c->pbufs[0], &p2 = c->pbufs[1];
+    for (int i = 0; i < now.nb && !clash; i++) {
+        for (int j = 0; j < p1.nb && !clash; j++)
+            clash = spans_overlap(now.out[i], p1.out[j]) || spans_overlap(now.out[i], p1.in[j]) || spans_overlap(now.in[i], p1.out[j]);
+        for (int j = 0; j < p2.nb && !clash; j++) clash = spans_overlap(now.out[i], p2.in[j]) || spans_overlap(now.in[i], p2.out[j]);
+    }
+    if (clash) HZ_TRY(pipeline_drain(c));
+    const uint64_t k = c->pcall;
+    *a = c->pstream[k & 1];
+    if (b) *b = c->pstream[(k + 1) & 1];
+    if (k == 0) {  // starting over: behind everything the context's stream holds (every earlier call of the chain is)
+        HZ_HIP(ctx, hipEventRecord(c->ev_in, ctx->stream));
+        HZ_HIP(ctx, hipStreamWaitEvent(c->pstream[0], c->ev_in, 0));
+        HZ_HIP(ctx, hipStreamWaitEvent(c->pstream[1], c->ev_in, 0));
+    }
+    if (c->ready) {  // what the caller said the call's buffers wait for
+        HZ_HIP(ctx, hipStreamWaitEvent(*a, c->ready, 0));
+        if (b) HZ_HIP(ctx, hipStreamWaitEvent(*b, c->ready, 0));
+    }
+    c->pbufs[1] = c->pbufs[0];
+    c->pbufs[0] = now;
+    return HZSDR_OK;
+}
+
+int pipeline_join(hzsdr_chain *c, hipStream_t a, hipStream_t b) {
+    hzsdr_ctx *ctx = c->ctx;
+    const uint64_t k = c->pcall;
+    HZ_HIP(ctx, hipEventRecord(c->ev_done[k & 3], a));
+    HZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->ev_done[k & 3], 0));
+    if (b) {
+        HZ_HIP(ctx, hipEventRecord(c->ev_hist[k & 3], b));
+        HZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->ev_hist[k & 3], 0));
+    }
+    c->pcall = k + 1;
     return HZSDR_OK;
 }
 
 static int mm2_launch_pipelined(hzsdr_chain *c, const void *in, void *out, size_t n, const EwProgram &P, const mm2::Plan &L,
-                                const mm2::Fix &F, const mm2::Geom &g2) {
+                                const mm2::Fix &F, const mm2::Geom &g2, const mm2::Batch &B, const CallBatch &cb) {
     hzsdr_ctx *ctx = c->ctx;
-    HZ_TRY(pipeline_streams(c));
-    const uint64_t k = c->pcall;
-    hipStream_t a = c->pstream[k & 1], b = c->pstream[(k + 1) & 1];
-    if (k == 0) {  // the first call behind a drain: the history it reads was written on the context's stream
-        HZ_HIP(ctx, hipEventRecord(c->ev_in, ctx->stream));
-        HZ_HIP(ctx, hipStreamWaitEvent(a, c->ev_in, 0));
-        HZ_HIP(ctx, hipStreamWaitEvent(b, c->ev_in, 0));
-    }
-    if (c->wait_in) {  // (the pinned ring: this call's upload)
-        HZ_HIP(ctx, hipStreamWaitEvent(a, c->wait_in, 0));
-        HZ_HIP(ctx, hipStreamWaitEvent(b, c->wait_in, 0));
-    }
-    HZ_TRY(mm2::launch_history(b, c->src_fmt, in, (float2 *)c->hist[c->hist_next()], (uint8_t *)c->rhist[c->hist_next()], n, c->mmg.off, P));
-    const int rc = mm2::launch_fir(a, ctx->num_cus, c->src_fmt, c->factor, in, (float2 *)out, (const float2 *)c->hist[c->hist_cur], nullptr,
-                                   (const uint8_t *)c->rhist[c->hist_cur], nullptr, (const float2 *)c->taps_dev, n, g2, L, P, F, c->fir_loop_form);
-    // (whatever happened, the streams stay consistent: the call is joined)
-    HZ_HIP(ctx, hipEventRecord(c->ev_done[k & 3], a));
-    HZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->ev_done[k & 3], 0));
-    c->pcall = k + 1;
-    return rc;
+    hipStream_t a, b;
+    HZ_TRY(pipeline_begin(c, cb, format_size(c->src_fmt), &a, &b));
+    // (the history is the call's last `off` samples: of the last buffer, indexed like the whole call)
+    const void *last = (const void *)(uintptr_t)B.vin[B.nbuf - 1];
+    int rc = mm2::launch_history(b, c->src_fmt, last, (float2 *)c->hist[c->hist_next()], (uint8_t *)c->rhist[c->hist_next()], n, c->mmg.off, P);
+    if (rc == HZSDR_OK)
+        rc = mm2::launch_fir(a, ctx->num_cus, c->src_fmt, c->factor, in, (float2 *)out, (const float2 *)c->hist[c->hist_cur], nullptr,
+                             (const uint8_t *)c->rhist[c->hist_cur], nullptr, (const float2 *)c->taps_dev, n, g2, L, P, F, B, c->fir_loop_form);
+    // (whatever happened, what was launched is joined; after a failure the chain starts over: the history ring's
+    // place in the streams' order is no longer what the next call would assume)
+    const int rj = pipeline_join(c, a, b);
+    if (rc != HZSDR_OK || rj != HZSDR_OK) (void)pipeline_drain(c);
+    return rc != HZSDR_OK ? rc : rj;
 }
 
 static int mm2_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const EwProgram &P, const mm2::Plan &L,
-                      const mm2::Fix &F) {
+                      const mm2::Fix &F, const CallBatch *cbp) {
     mm2::Geom g2{};
     g2.ntaps = c->mmg.ntaps, g2.w0 = c->mmg.w0, g2.ks = c->mmg.ks, g2.ne = c->mmg.ne, g2.e0 = c->mmg.e0, g2.shift = c->mmg.shift,
     g2.off = c->mmg.off;
-    // (HOST-space calls stage their buffers on the context's stream and are synchronous: nothing to overlap)
-    if (c->pipelined && (c->ctx->memspace == HZSDR_MEM_DEVICE || c->wait_in) && n >= c->mmg.off && c->mmg.off > 0)
-        return mm2_launch_pipelined(c, in, out, n, P, L, F, g2);
+    const void *in1[1] = {in};
+    void *out1[1] = {out};
+    const CallBatch one{in1, out1, 1, n, n / c->factor};
+    const CallBatch &cb = cbp && cbp->nbuf > 1 ? *cbp : one;
+    const mm2::Batch B = cb.nbuf > 1 ? mm2::make_batch(cb.ins, cb.outs, cb.nbuf, cb.n_each, c->factor) : mm2::one_buffer(in, out, n, c->factor);
+    // (`relaxed`: device buffers whose readiness the caller stated -- hzsdr_chain_run_after in a DEVICE-space context, the ring)
+    if (c->pipelined && c->relaxed && n >= c->mmg.off && c->mmg.off > 0)
+        return mm2_launch_pipelined(c, in, out, n, P, L, F, g2, B, cb);
     HZ_TRY(pipeline_drain(c));
     return mm2::launch_fir(c->ctx->stream, c->ctx->num_cus, c->src_fmt, c->factor, in, (float2 *)out,
                            (const float2 *)c->hist[c->hist_cur], (float2 *)c->hist[c->hist_next()],
                            (const uint8_t *)c->rhist[c->hist_cur], (uint8_t *)c->rhist[c->hist_next()],
-                           (const float2 *)c->taps_dev, n, g2, L, P, F, c->fir_loop_form);
+                           (const float2 *)c->taps_dev, n, g2, L, P, F, B, c->fir_loop_form);
 }
 
 // The modulated filter of every clock run long enough to hold a whole block (lookups only).
@@ -509,8 +574,10 @@ static unsigned fir_grid(size_t nblocks, int xpb, bool late, int n_slow) {
 }
 
 template <int FMT>
-int fir_run(hzsdr_chain *c, const void *in, size_t n_cons, void *out, const EwProgram &P) {
+int fir_run(hzsdr_chain *c, const void *in, size_t n_cons, void *out, const EwProgram &P, const CallBatch *cb) {
     hzsdr_ctx *ctx = c->ctx;
+    const bool batched = cb && cb->nbuf > 1;
+    if (batched && !(c->mm_ok && c->mm_ver == 2)) return kBatchFallback;
     do {
         const size_t nblocks = (n_cons + c->hop - 1) / c->hop;
         const float2 *hist = (const float2 *)c->hist[c->hist_cur];
@@ -525,8 +592,8 @@ int fir_run(hzsdr_chain *c, const void *in, size_t n_cons, void *out, const EwPr
             bool ran = false;
             int cont = 0;
             if (c->mm_ver == 2) {
-                if (mm2_plan(c, P, n_cons, in, out, &L2, &F2)) {
-                    const int rc = mm2_launch(c, in, out, n_cons, P, L2, F2);
+                if (mm2_plan(c, P, n_cons, in, out, &L2, &F2, cb)) {
+                    const int rc = mm2_launch(c, in, out, n_cons, P, L2, F2, cb);
                     if (rc != HZSDR_OK) {  // (nothing was committed: the histories are the previous call's)
                         c->rh_valid = false;
                         return rc;
@@ -562,6 +629,7 @@ int fir_run(hzsdr_chain *c, const void *in, size_t n_cons, void *out, const EwPr
                 break;
             }
         }
+        if (batched) return kBatchFallback;  // (the transform kernels take one buffer at a time)
         if (!fv::ok((int)c->nfft)) return HZSDR_ERR_INVALID_ARGUMENT;
         HZ_TRY(pipeline_drain(c));  // (the transform kernels run on the context's stream)
         FvTabs tabs{}, tabs_m{};
@@ -571,16 +639,16 @@ int fir_run(hzsdr_chain *c, const void *in, size_t n_cons, void *out, const EwPr
         SlowBlocks slow{};
 // packed-math core: fold when D is a power of two <= 16 and N/D is itself a core size
 #define HZ_FIR16_L(N, FOLD, LATE, SPEC)                                                                        \
-    launch_fv(fir_decimate_kernel16<N, FMT, FOLD, LATE>, dim3(fir_grid(nblocks, fv::xpb(N), LATE, slow.n)),      \
+    HZ_TRY(launch_fv(fir_decimate_kernel16<N, FMT, FOLD, LATE>, dim3(fir_grid(nblocks, fv::xpb(N), LATE, slow.n)), \
               dim3(fv::block(N)), fir_lds_bytes(N, FOLD), ctx->stream, in,                                      \
               (float2 *)out, hist, nhist, (const float2 *)c->hfreq, tabs, SPEC, nblocks, n_cons, c->hop, c->off, D, \
-              P, late, ptabs, slow)
+              P, late, ptabs, slow))
 #define HZ_FIR16(N, FOLD) HZ_FIR16_L(N, FOLD, false, (float2 *)nullptr)
 #define HZ_SYNTH16(N, F, LATE)                                                                                 \
-    launch_fv(fir_synth_kernel16<N, F, LATE>,                                                                  \
+    HZ_TRY(launch_fv(fir_synth_kernel16<N, F, LATE>,                                                           \
               dim3((unsigned)((nblocks + SynthGeom<N, F>::XPB - 1) / SynthGeom<N, F>::XPB)),                    \
               dim3(SynthGeom<N, F>::BS), (size_t)SynthGeom<N, F>::XPB * fv::lds_elems(N / F) * sizeof(cf),      \
-              ctx->stream, (const float2 *)spec, (float2 *)out, tabs_m.bwd, nblocks, n_cons, c->hop, c->off, P, late)
+              ctx->stream, (const float2 *)spec, (float2 *)out, tabs_m.bwd, nblocks, n_cons, c->hop, c->off, P, late))
 #define HZ_FIR16_FOLD(N, F)                                                            \
     if (D == F) {                                                                      \
         if constexpr (fv::xpb(N) == 1 && fv::ok(N / F)) {                              \
@@ -643,10 +711,10 @@ int fir_run(hzsdr_chain *c, const void *in, size_t n_cons, void *out, const EwPr
     } while (0);
     return HZSDR_OK;
 }
-template int fir_run<HZSDR_FMT_C64>(hzsdr_chain *, const void *, size_t, void *, const EwProgram &);
-template int fir_run<HZSDR_FMT_U8>(hzsdr_chain *, const void *, size_t, void *, const EwProgram &);
-template int fir_run<HZSDR_FMT_I8>(hzsdr_chain *, const void *, size_t, void *, const EwProgram &);
-template int fir_run<HZSDR_FMT_I16>(hzsdr_chain *, const void *, size_t, void *, const EwProgram &);
+template int fir_run<HZSDR_FMT_C64>(hzsdr_chain *, const void *, size_t, void *, const EwProgram &, const CallBatch *);
+template int fir_run<HZSDR_FMT_U8>(hzsdr_chain *, const void *, size_t, void *, const EwProgram &, const CallBatch *);
+template int fir_run<HZSDR_FMT_I8>(hzsdr_chain *, const void *, size_t, void *, const EwProgram &, const CallBatch *);
+template int fir_run<HZSDR_FMT_I16>(hzsdr_chain *, const void *, size_t, void *, const EwProgram &, const CallBatch *);
 
 }  // namespace hz
 
@@ -666,7 +734,7 @@ int hzsdr_chain_fir_options(hzsdr_chain *c, int impl, unsigned nfft_min, int loo
 int hzsdr_chain_pipeline(hzsdr_chain *c, int on) {
     if (!c) return HZSDR_ERR_INVALID_ARGUMENT;
     HZ_TRY(hz::enter(c->ctx));
-    if (!on) HZ_TRY(hz::pipeline_drain(c));
+    HZ_TRY(hz::pipeline_drain(c));
     c->pipelined = on != 0;
     return HZSDR_OK;
 }

@@ -7,6 +7,7 @@
 #include <algorithm>
 
 #include "hz_chain_dev.h"
+#include "hz_firmm2_plan.h"
 #include "hz_firmm_plan.h"
 #include "hz_fft_api.h"
 
@@ -69,12 +70,25 @@ struct hzsdr_chain {
     int last_path = HZSDR_FIR_PATH_NONE;
     // hzsdr_chain_pipeline: consecutive calls on the matrix path alternate between two streams of the chain's own
     // (the next launch's workgroups start as this one's finish), the history of the next call is formed by a small
-    // kernel of its own; `pcall` counts the pipelined calls since the last drain
+    // kernel of its own; `pcall` counts the overlapped calls since the chain's streams were last re-seeded from the
+    // context's stream.  ONLY a call that states what its buffers wait for overlaps (hzsdr_chain_run_after, the ring:
+    // `relaxed` / `ready` below, set for the duration of that call); hzsdr_chain_run is ordered like any other call.
     bool pipelined = false;
     hipStream_t pstream[2] = {nullptr, nullptr};
-    hipEvent_t ev_done[4] = {nullptr, nullptr, nullptr, nullptr}, ev_in = nullptr;
+    hipEvent_t ev_done[4] = {nullptr, nullptr, nullptr, nullptr}, ev_hist[4] = {nullptr, nullptr, nullptr, nullptr}, ev_in = nullptr;
     uint64_t pcall = 0;
-    hipEvent_t wait_in = nullptr;  // set by a caller inside the library that knows what the input waits for (hz_ring.hip)
+    bool relaxed = false;        // this call: the caller says when its buffers are ready (not: behind the context's stream)
+    hipEvent_t ready = nullptr;  // ... namely when this event has fired (null: now)
+    // the buffers of the last two overlapped calls: a call that touches them is ordered behind those calls
+    struct Span {
+        const char *p;
+        size_t n;
+    };
+    struct CallBufs {
+        int nb = 0;
+        Span in[hz::mm2::kMaxBatch], out[hz::mm2::kMaxBatch];
+    };
+    CallBufs pbufs[2];  // [0]: the previous call, [1]: the one before it
 };
 
 struct hzsdr_conv {
@@ -117,27 +131,42 @@ inline const DiagEnv &diag_env() {
 // Launch with `lds` bytes of dynamic LDS; above the 64 KiB default a kernel needs its limit
 // raised once (160 KiB per CU on gfx950).
 template <class K, class... A>
-inline void launch_fv(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, A... args) {
-    // (a failure here makes the launch below fail, which the stage's hipGetLastError reports)
-    if (lds > 48 * 1024) (void)raise_dynamic_lds((const void *)kernel);
+inline int launch_fv(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, A... args) {
+    if (lds > 48 * 1024) HZ_TRY(raise_dynamic_lds((const void *)kernel));
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
+    return HZSDR_OK;  // (the launch's own status: the caller's hipGetLastError)
 }
 
 // hz_conv.hip: `nblocks` blocks of n samples through forward FFT -> bins *= filter -> backward FFT (-> DecimateReader pick)
 int conv_blocks_device(hzsdr_ctx *ctx, int fmt, size_t n, const void *in, void *out, const void *filt, size_t nblocks,
                        unsigned dec, size_t per, const EwProgram &P);
-// hz_chain_fir.hip: one call of a chain whose terminal is the FIR-decimate stage; the clock's filters / digit tables
-// for a chain whose clock was set by hand
-template <int FMT> int fir_run(hzsdr_chain *c, const void *in, size_t n_cons, void *out, const EwProgram &P);
+// One call's buffers: nbuf inputs of n_each samples and their outputs (hzsdr_chain_run_batch; nbuf = 1: an ordinary call)
+struct CallBatch {
+    const void *const *ins;
+    void *const *outs;
+    size_t nbuf, n_each, out_each;
+};
+// internal status of a batched call that the single-launch form cannot take: the caller runs the buffers one by one
+constexpr int kBatchFallback = -1000;
+// hz_chain_fir.hip: one call of a chain whose terminal is the FIR-decimate stage (n_cons samples in all; `cb` with
+// nbuf > 1: the call's buffers, in / out are its first -- kBatchFallback unless the persistent-pass matrix kernel
+// takes the whole call); the clock's filters / digit tables for a chain whose clock was set by hand
+template <int FMT> int fir_run(hzsdr_chain *c, const void *in, size_t n_cons, void *out, const EwProgram &P, const CallBatch *cb = nullptr);
 int prepare_late_filters(hzsdr_chain *c, double ts0);
 int prepare_mm_tables(hzsdr_chain *c, double ts0);
 // hz_chain.hip
-int chain_launch(hzsdr_chain *c, const void *din, size_t cons, void *dout, size_t outn, double *ts_after);
+int chain_launch(hzsdr_chain *c, const void *din, size_t cons, void *dout, size_t outn, double *ts_after, const CallBatch *cb = nullptr);
 int upload_filter(hzsdr_ctx *ctx, void *dst, const void *src, size_t bytes);
 int chain_terminal_set(hzsdr_chain *c);
-// hz_chain_fir.hip: the context's stream waits for everything a pipelined chain has in flight (its next call, a
-// reset, a change of the clock and the end of the chain all need that)
+// hz_chain_fir.hip: a pipelined chain's next overlapped call starts over from the context's stream (every call is
+// joined to that stream as it is launched, so there is nothing to wait for: a call on the context's stream, a reset,
+// a change of the clock need just this)
 int pipeline_drain(hzsdr_chain *c);
+// the stream and order an overlapped call launches on: `a` for the call's kernel, `b` for the kernel that forms the
+// next call's history (null for chains without one); re-seeds both from the context's stream when the chain starts
+// over or the call's buffers overlap the last two calls'.  pipeline_join: behind the launches.
+int pipeline_begin(hzsdr_chain *c, const CallBatch &cb, int fmt_size, hipStream_t *a, hipStream_t *b);
+int pipeline_join(hzsdr_chain *c, hipStream_t a, hipStream_t b);
 // the chain's two streams and events, created on first use
 int pipeline_streams(hzsdr_chain *c);
 

@@ -6,7 +6,7 @@
 namespace hz {
 
 template <int N, int FMT>
-static void launch_conv_n(hzsdr_ctx *ctx, const void *in, void *out, const void *filt, const float2 *tw,
+static int launch_conv_n(hzsdr_ctx *ctx, const void *in, void *out, const void *filt, const float2 *tw,
                           const FvTabs &tabs, size_t nblocks, unsigned dec, size_t per, const EwProgram &P) {
     const bool direct = FMT == HZSDR_FMT_C64 && P.n == 0;
     if constexpr (fv::ok(N)) {  // packed-math core
@@ -17,12 +17,12 @@ static void launch_conv_n(hzsdr_ctx *ctx, const void *in, void *out, const void 
             // (a grid the chip holds at once: each workgroup walks its blocks with the next one's loads in flight)
             const size_t resident = (size_t)ctx->num_cus * (size_t)(conv_occupancy(N, false) * 4 * 64 / fv::block(N));
             const dim3 grid_p((unsigned)std::min<size_t>(grid.x, std::max<size_t>(resident, 1)));
-            launch_fv(conv_blocks_kernel16<N, FMT, false>, grid_p, block, lds, ctx->stream, in, (float2 *)out,
-                      (const float2 *)filt, tabs, nblocks, dec, per, P);
+            HZ_TRY(launch_fv(conv_blocks_kernel16<N, FMT, false>, grid_p, block, lds, ctx->stream, in, (float2 *)out,
+                             (const float2 *)filt, tabs, nblocks, dec, per, P));
+        } else {
+            HZ_TRY(launch_fv(conv_blocks_kernel16<N, FMT, true>, grid, block, lds, ctx->stream, in, (float2 *)out,
+                             (const float2 *)filt, tabs, nblocks, dec, per, P));
         }
-        else
-            launch_fv(conv_blocks_kernel16<N, FMT, true>, grid, block, lds, ctx->stream, in, (float2 *)out,
-                      (const float2 *)filt, tabs, nblocks, dec, per, P);
     } else {  // radix-4 core: N < 256
         constexpr int XPB = fft_xpb(N);
         const dim3 grid((unsigned)((nblocks + XPB - 1) / XPB)), block(fft_block(N));
@@ -33,6 +33,7 @@ static void launch_conv_n(hzsdr_ctx *ctx, const void *in, void *out, const void 
             hipLaunchKernelGGL((conv_blocks_kernel<N, FMT, true>), grid, block, 0, ctx->stream, in,
                                (float2 *)out, (const float2 *)filt, tw, nblocks, dec, per, P);
     }
+    return HZSDR_OK;
 }
 
 template <int FMT>
@@ -40,18 +41,18 @@ static int launch_conv_fmt(hzsdr_ctx *ctx, size_t n, const void *in, void *out, 
                            const float2 *tw, const FvTabs &tabs, size_t nblocks, unsigned dec, size_t per,
                            const EwProgram &P) {
     switch (n) {
-    case 4: launch_conv_n<4, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 8: launch_conv_n<8, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 16: launch_conv_n<16, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 32: launch_conv_n<32, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 64: launch_conv_n<64, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 128: launch_conv_n<128, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 256: launch_conv_n<256, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 512: launch_conv_n<512, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 1024: launch_conv_n<1024, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 2048: launch_conv_n<2048, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 4096: launch_conv_n<4096, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
-    case 8192: launch_conv_n<8192, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P); break;
+    case 4: return launch_conv_n<4, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P);
+    case 8: return launch_conv_n<8, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P);
+    case 16: return launch_conv_n<16, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P);
+    case 32: return launch_conv_n<32, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P);
+    case 64: return launch_conv_n<64, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P);
+    case 128: return launch_conv_n<128, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P);
+    case 256: return launch_conv_n<256, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P);
+    case 512: return launch_conv_n<512, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P);
+    case 1024: return launch_conv_n<1024, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P);
+    case 2048: return launch_conv_n<2048, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P);
+    case 4096: return launch_conv_n<4096, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P);
+    case 8192: return launch_conv_n<8192, FMT>(ctx, in, out, filt, tw, tabs, nblocks, dec, per, P);
     default: return HZSDR_ERR_INVALID_ARGUMENT;
     }
     return HZSDR_OK;

@@ -208,10 +208,10 @@ __global__ __launch_bounds__(fv::block(N)) void fft_plan_kernel16(const float2 *
 }
 
 template <class K, class... A>
-static void launch_dyn(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, A... args) {
-    // (a failure here makes the launch below fail, which the stage's hipGetLastError reports)
-    if (lds > 48 * 1024) (void)raise_dynamic_lds((const void *)kernel);
+static int launch_dyn(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, A... args) {
+    if (lds > 48 * 1024) HZ_TRY(raise_dynamic_lds((const void *)kernel));
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
+    return HZSDR_OK;  // (the launch's own status: the caller's hipGetLastError)
 }
 
 template <int N>
@@ -223,8 +223,8 @@ static int launch_plan_n(hzsdr_ctx *ctx, const float2 *in, float2 *out, const fl
         constexpr int XPB16 = fv::xpb(N);
         const dim3 grid16((unsigned)((batch + XPB16 - 1) / XPB16)), block16(fv::block(N));
         const size_t lds = (size_t)XPB16 * fv::lds_elems(N) * sizeof(fv::cf);
-        if (fwd) launch_dyn(fft_plan_kernel16<N, true>, grid16, block16, lds, ctx->stream, in, out, tabs, batch);
-        else launch_dyn(fft_plan_kernel16<N, false>, grid16, block16, lds, ctx->stream, in, out, tabs, batch);
+        if (fwd) HZ_TRY(launch_dyn(fft_plan_kernel16<N, true>, grid16, block16, lds, ctx->stream, in, out, tabs, batch));
+        else HZ_TRY(launch_dyn(fft_plan_kernel16<N, false>, grid16, block16, lds, ctx->stream, in, out, tabs, batch));
         return HZSDR_OK;
     } else {
         constexpr int XPB = fft_xpb(N);

@@ -66,6 +66,7 @@ struct KernArgs {
     Plan L;
     EwProgram P;
     Fix F;
+    Batch B;
     unsigned long long *stamps;
 };
 typedef const KernArgs __attribute__((address_space(4))) *KernArgsP;
@@ -83,7 +84,8 @@ typedef const KernArgs __attribute__((address_space(4))) *KernArgsP;
     [[maybe_unused]] const Geom &G = *(const Geom *)&ca_->G;                                                           \
     [[maybe_unused]] const Plan &L = *(const Plan *)&ca_->L;                                                           \
     [[maybe_unused]] const EwProgram &P = *(const EwProgram *)&ca_->P;                                                 \
-    [[maybe_unused]] const Fix &F = *(const Fix *)&ca_->F
+    [[maybe_unused]] const Fix &F = *(const Fix *)&ca_->F;                                                             \
+    [[maybe_unused]] const Batch &B = *(const Batch *)&ca_->B
 
 // A Shift stage of a program with SEVERAL Shift stages (float64 phases, as hz_firmm.h), over a lane's outputs
 // m = mb + 32 kT b + a of a pass: OUT OF LINE.  Inlined, its two float64 Sincos put twenty-two polynomial constants
@@ -121,7 +123,34 @@ __device__ __attribute__((noinline)) void other_shift_stage(float2 *y, double ta
     }
 }
 
-// EXP (tools/mfma_fir2.hip; 0 in the library): 1 = no input loads, 2 = no matrix loop, 4 = no mixer,
+// The mixer's complex products as the packed float32 pipe takes them WITHOUT moves: a complex value is a register
+// pair (re, im); a broadcast of one half (op_sel / op_sel_hi), the exchange of the halves and a negated half (neg_lo)
+// are operand modifiers of v_pk_mul_f32 / v_pk_fma_f32 and cost nothing.  The compiler does not use them for this
+// code -- it builds (-s, c) from (c, s) with a v_xor and two v_mov per product and pads every packed instruction with
+// an s_nop: ~13 vector instructions per output where 6 do (round 5; every vector instruction of an epilogue costs
+// the SIMD partner's matrix loop ~2.5 cycles).  Same operations in the same order as the float expressions they
+// replace: bit-identical results.  None of the forms below is the gfx950 hazard's (op_sel:[0,1] with src0 straight,
+// hz_firmm.h); tools/fix_pk_opsel.py checks the built library all the same.
+typedef float v2f __attribute__((ext_vector_type(2)));
+// (cs, sn) = (c0, s0) turned by w = (cos hi, sin hi, cos lo, sin lo):
+//   cs = fma(c0, w.x, fma(-s0, w.y, fma(c0, w.z, -(s0 w.w)))),  sn = fma(c0, w.y, fma(s0, w.x, fma(c0, w.w, s0 w.z)))
+__device__ __forceinline__ v2f pk_turn(v2f cs0, v2f wxy, v2f wzw) {
+    v2f t;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(cs0), "v"(wzw));      // (-s0 w.w, s0 w.z)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(t) : "v"(cs0), "v"(wzw));                           // + (c0 w.z, c0 w.w)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(t) : "v"(cs0), "v"(wxy));  // + (-s0 w.y, s0 w.x)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(t) : "v"(cs0), "v"(wxy));                           // + (c0 w.x, c0 w.y)
+    return t;
+}
+// y (cs, sn):  re = fma(y.x, cs, -(y.y sn)),  im = fma(y.x, sn, y.y cs)
+__device__ __forceinline__ v2f pk_cmul(v2f y, v2f f) {
+    v2f u, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(u) : "v"(y), "v"(f));           // (-y.y sn, y.y cs)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(y), "v"(f), "v"(u));                       // + (y.x cs, y.x sn)
+    return r;
+}
+
+// EXP (tools/mfma_fir2.hip; kLibExp in the library): 1 = no input loads, 2 = no matrix loop, 4 = no mixer,
 // 8 = no stores, 16 = no stagger, 32 = wave priorities (see the pass loop's end), 64 = stamps, 128 = no explicit vmcnt(0),
 // 256 = accumulator checksums per pass and lane, taken right behind the matrix loop and again behind the landing,
 // stored (first launch) or compared with the stored ones (tools/mm2_glitch.hip: which register, which lanes,
@@ -130,6 +159,16 @@ __device__ __attribute__((noinline)) void other_shift_stage(float2 *y, double ta
 // time from a second, fully waited read and compared with the one the mixer used (records as for 256), 2048 = the
 // constant 0 as the first step's C operand instead of cleared accumulator registers, 4096 = the rare paths read the
 // kernel arguments as the common path does (HZ_COLD_ARGS below switched off: round 3's code shape, for A/B).
+// Round 5, fewer vector instructions per pass (each switchable for A/B; kLibExp = what the library ships):
+// 8192 = the mixer in hand-packed form (pk_turn / pk_cmul above), 16384 = the two top digit planes combined in int32
+// in front of the float64 step (the host bounds the sums: hz_firmm_plan.h, digit_shift), 32768 = a u8 pass image's
+// sign flip by the LDS (ds_xor_b64 behind the landing's writes) instead of 40 v_xor per lane, 65536 = the first
+// step's MFMAs with the constant 0 as C through inline assembly (early-clobber destinations: no clears, no overlap of
+// destinations and sources), 131072 = the cold multi-Shift path waits for its own scratch reloads and is marked
+// unlikely (the compiler otherwise leaves a vmcnt(0) for them at the pass loop's top, behind the prefetch's issue, and
+// eight register moves on the hot path where the two meet), 262144 = a u8 pass image's sign flip among the wave's OWN
+// MFMAs, near the matrix loop's end (straight-line form).  Measured one by one and together, tools/mfma_fir2.hip AB=1:
+// 32768 is 0.8 us SLOWER (LDS atomics), 131072 alone -1.0 us, the rest -0.3 together.
 // NG: the window's groups (ks / GS) when the instantiation is for ONE tap count -- the matrix loop is then
 // straight-line code (a loop header drains the operand pipeline: the compiler cannot count outstanding
 // loads across a back edge); 0: any window, a loop over the groups.
@@ -137,7 +176,7 @@ template <int FMT, int D, int NG = 0, int EXP = 0, int UG = 0>
 __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     const void *__restrict__ in, float2 *__restrict__ out, const float2 *__restrict__ hist,
     float2 *__restrict__ new_hist, const uint8_t *__restrict__ rhist, uint8_t *__restrict__ new_rhist,
-    const float2 *__restrict__ taps, size_t n_in, Geom G, Plan L, EwProgram P, Fix F,
+    const float2 *__restrict__ taps, size_t n_in, Geom G, Plan L, EwProgram P, Fix F, Batch B,
     unsigned long long *stamps = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t mm_lds[];
     constexpr int TB = tile_bytes(D), TS = tile_stride(D), PPT = TB / 16, GS = PPT / 2, NB = blocks_for(D);
@@ -157,6 +196,19 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     const int64_t n_bytes = 2 * (int64_t)n_in;
     const uint8_t *src = (const uint8_t *)in;
     const int pieces = (int)(image_bytes(D, G.ks) / 16);
+    // A call over several buffers (hz_firmm2_plan.h: Batch): `in` / `out` are buffer 0's, buffer j's virtual base is
+    // read when a pass of buffer j comes up; everything is indexed by the position in the concatenation.
+    const int nbuf = B.nbuf;
+    const uint32_t rcp = B.rcp;
+    const int64_t nb = (int64_t)B.nb;
+    // (pass / ppb by the host's reciprocal: one s_mul_hi_u32 -- a chain of comparisons summed as integers became
+    // vector instructions, fifty per pass)
+    auto buf_of = [&](uint32_t pass) -> int { return nbuf > 1 ? (int)__umulhi(pass, rcp) : 0; };
+    // (as integers, used through GLOBAL pointers: a pointer made from an integer is a generic one to the compiler, and
+    // a flat load counts as an LDS operation too -- the matrix loop's first ds_read would wait for the prefetch)
+    auto vin_of = [&](int j) -> uint64_t { return j == 0 ? (uint64_t)(uintptr_t)src : B.vin[j]; };
+    auto vout_of = [&](int j) -> uint64_t { return j == 0 ? (uint64_t)(uintptr_t)out : B.vout[j]; };
+    typedef const v4i __attribute__((address_space(1))) *gload_p;
     // (EXP & 64: s_memrealtime stamps, 10 ns ticks: slot 0 of a wave = its start and end, slots 1 .. 3 its passes)
     int stamp_pass = 0;
     auto stamp = [&](int k) {
@@ -176,7 +228,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         const uint64_t a0 = (uint64_t)(uintptr_t)in, a1 = (uint64_t)n_in, a2 = (uint64_t)(uintptr_t)run0.tab;
         asm volatile("" ::"s"(a0), "s"(a1), "s"(a2), "s"(G.w0), "s"(G.ks), "s"(G.ne), "s"(G.e0), "s"(G.ntaps), "s"(G.off), "s"(L.n),
                      "s"(L.n_pass), "s"(L.grid), "s"(L.n_task), "s"(L.pass_first[0]), "s"(L.pass_end[0]), "s"(L.pass_first[1]),
-                     "s"(L.pass_end[1]), "s"(run0.m_lo), "s"(run0.m_hi));
+                     "s"(L.pass_end[1]), "s"(run0.m_lo), "s"(run0.m_hi), "s"(nbuf), "s"(rcp), "s"(nb));
     }
 
     // ---- this workgroup's passes [pb0, pb1) of the call -------------------------------------------------
@@ -190,18 +242,19 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     // land); the others are brought in piece by piece when their turn comes (land_edge: bytes before the
     // buffer are the previous call's last samples when the clock run continues, zeros otherwise).
     auto pass_p0 = [&](uint32_t pass) { return 2 * ((int64_t)D * ((int64_t)pass * kPassOut) - G.w0); };
-    auto inside = [&](uint32_t pass) {
-        const int64_t p0 = pass_p0(pass);
-        return p0 >= 0 && p0 + 16 * (int64_t)pieces <= n_bytes;
+    auto inside = [&](uint32_t pass) {  // (the image lies in ONE buffer)
+        const int64_t p0 = pass_p0(pass), lo = (int64_t)buf_of(pass) * nb;
+        return p0 >= lo && p0 + 16 * (int64_t)pieces <= lo + nb;
     };
     auto issue = [&](v4i(&x)[KU], uint32_t pass) {
-        const uint8_t *p = src + pass_p0(pass);
+        const gload_p p = (gload_p)(vin_of(buf_of(pass)) + (uint64_t)pass_p0(pass));  // (in pieces of 16 bytes)
+        const gload_p pl = p + l;  // (ONE address per lane, the pieces at immediate offsets)
 #pragma unroll
         for (int u = 0; u < KU; u++) {
             x[u] = v4i{0, 0, 0, 0};  // (pieces past the image: the last piece again, not landed)
             if constexpr ((EXP & 1) != 0) continue;
-            if constexpr (kWhole) x[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p + 16 * l + 1024 * u));
-            else x[u] = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(p + 16 * min(l + u * 64, pieces - 1)));
+            if constexpr (kWhole) x[u] = __builtin_nontemporal_load(pl + 64 * u);
+            else x[u] = __builtin_nontemporal_load(p + min(l + u * 64, pieces - 1));
         }
     };
     // The first pass's bytes, requested before anything else is even fetched: the instruction cache is cold at every
@@ -233,7 +286,14 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     // (the tasks' scratch in LDS behind the slots: the window's samples, the taps beside them)
     auto task_xs = [&](const Geom &G) { return reinterpret_cast<float2 *>(mm_lds + 2 * table_lds(G.ne) + kCtlBytes + (size_t)kWaves * slot_bytes(D, G.ks)); };
     auto tasks_front_cold = [&](int round, const void *in, const float2 *hist, float2 *new_hist, const uint8_t *rhist, uint8_t *new_rhist,
-                                const float2 *taps, size_t n_in, const Geom &G, const Plan &L, const EwProgram &P, const Fix &F) {
+                                const float2 *taps, size_t n_in, const Geom &G, const Plan &L, const EwProgram &P, const Fix &F, const Batch &B) {
+        // (sample pu of the concatenation: its buffer's virtual base)
+        auto vbase = [&](int64_t pu) -> const RWT * {
+            const void *sb = in;
+            for (int i = 1; i < B.nbuf; i++)
+                if (2 * pu >= (int64_t)i * (int64_t)B.nb) sb = (const void *)(uintptr_t)B.vin[i];
+            return (const RWT *)sb;
+        };
         float2 *const xs = task_xs(G);
         float2 *const tl = xs + (G.ntaps + D * (kFixOut - 1));
         const int ftask = (L.grid - 1 - wb) + round * L.grid;  // (from the grid's far end: see the calls)
@@ -254,7 +314,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
 #pragma unroll
                 for (int u = 0; u < W; u++) {
                     const int64_t pu = p_lo + i0 + u * 256;
-                    v[u] = Raw<FMT>::cvt((i0 + u * 256 < n_s && pu >= 0) ? ((const RWT *)in)[pu] : RWT{});
+                    v[u] = Raw<FMT>::cvt((i0 + u * 256 < n_s && pu >= 0) ? vbase(pu)[pu] : RWT{});
                 }
                 ew_apply_n<W, 2>(P, v, (uint64_t)(p_lo + i0), tw, (uint64_t)256);
 #pragma unroll
@@ -273,8 +333,10 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     // 3 had wave 7 of the first sixteen workgroups do them in front of its first pass -- 5 us of exact Sincos that
     // made those waves, and with them the launch, end 2 us late: tools/mfma_fir2.hip lists the workgroups that end
     // last, and they were workgroups 3 and 11 on every box.)
-    auto history_tasks_cold = [&](const void *in, const float2 *hist, float2 *new_hist, const uint8_t *rhist, uint8_t *new_rhist, size_t n_in,
-                                  const Geom &G, const Plan &L, const EwProgram &P) {
+    auto history_tasks_cold = [&](const void *in0, const float2 *hist, float2 *new_hist, const uint8_t *rhist, uint8_t *new_rhist, size_t n_in,
+                                  const Geom &G, const Plan &L, const EwProgram &P, const Batch &B) {
+        // (the call's last samples: the last buffer's, which holds at least `off` samples when there are several)
+        const void *const in = B.nbuf > 1 ? (const void *)(uintptr_t)B.vin[B.nbuf - 1] : in0;
         const int n_hist_tasks = new_hist ? (int)((G.off + kHistPer - 1) / kHistPer) : 0;
         for (int j = wb + L.grid * wave; j < n_hist_tasks; j += (kWaves / 2) * L.grid) {  // (uniform per wave)
             const unsigned idx = (unsigned)j * kHistPer + l;
@@ -290,10 +352,10 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     auto history_tasks = [&]() {
         if (wave >= kWaves / 2 || new_hist == nullptr || wb + L.grid * wave >= (int)((G.off + kHistPer - 1) / kHistPer)) return;
         if constexpr ((EXP & 4096) != 0) {
-            history_tasks_cold(in, hist, new_hist, rhist, new_rhist, n_in, G, L, P);
+            history_tasks_cold(in, hist, new_hist, rhist, new_rhist, n_in, G, L, P, B);
         } else {
             HZ_COLD_ARGS;
-            history_tasks_cold(in, hist, new_hist, rhist, new_rhist, n_in, G, L, P);
+            history_tasks_cold(in, hist, new_hist, rhist, new_rhist, n_in, G, L, P, B);
         }
     };
     // Round r: workgroup wb takes fix-up task wb + r grid.  Round 0 is called ONCE, in front of the run groups, the
@@ -305,13 +367,13 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         if (wave >= kWaves / 2) return;
         if ((L.grid - 1 - wb) + round * L.grid >= L.n_task) return;  // (what most workgroups of most calls find)
         if constexpr ((EXP & 4096) != 0) {
-            tasks_front_cold(round, in, hist, new_hist, rhist, new_rhist, taps, n_in, G, L, P, F);
+            tasks_front_cold(round, in, hist, new_hist, rhist, new_rhist, taps, n_in, G, L, P, F, B);
         } else {
             HZ_COLD_ARGS;
-            tasks_front_cold(round, in, hist, new_hist, rhist, new_rhist, taps, n_in, G, L, P, F);
+            tasks_front_cold(round, in, hist, new_hist, rhist, new_rhist, taps, n_in, G, L, P, F, B);
         }
     };
-    auto tasks_back_cold = [&](float2 *out, const Geom &G) {
+    auto tasks_back_cold = [&](float2 *out0, const Geom &G, const Batch &B) {
         float2 *const xs = task_xs(G);
         float2 *const tl = xs + (G.ntaps + D * (kFixOut - 1));
         const int ct = tid;
@@ -336,16 +398,21 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
             ar += __shfl_xor(ar, d);
             ai += __shfl_xor(ai, d);
         }
-        if (o < fix_cnt && sl == 0) out[fix_m0 + o] = make_float2((float)ar, (float)ai);
+        if (o < fix_cnt && sl == 0) {
+            float2 *ob = out0;  // (output fix_m0 + o of the concatenation: its buffer's virtual base)
+            for (int i = 1; i < B.nbuf; i++)
+                if (fix_m0 + o >= (uint32_t)i * B.out_each) ob = (float2 *)(uintptr_t)B.vout[i];
+            ob[fix_m0 + o] = make_float2((float)ar, (float)ai);
+        }
         fix_cnt = 0;
     };
     auto tasks_back = [&]() {  // behind the barrier that follows tasks_front
         if (wave >= kWaves / 2 || fix_cnt == 0) return;
         if constexpr ((EXP & 4096) != 0) {
-            tasks_back_cold(out, G);
+            tasks_back_cold(out, G, B);
         } else {
             HZ_COLD_ARGS;
-            tasks_back_cold(out, G);
+            tasks_back_cold(out, G, B);
         }
     };
     stamp(9);
@@ -362,19 +429,38 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     auto vm_clear = [&]() {
         if constexpr ((EXP & 128) == 0) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), the other counters untouched
     };
-    auto land = [&](v4i(&x)[KU]) {
+    // (flipped: the u8 sign flip has been applied to the registers already -- among the MFMAs of the matrix loop the
+    // bytes were in flight under, EXP & 262144)
+    auto land = [&](v4i(&x)[KU], bool flipped = false) {
         // piece l + 64 u is piece l % PPT of tile l / PPT + (64 / PPT) u: one address and constants
         uint8_t *lp = slot + TS * (l / PPT) + 16 * (l % PPT);
 #pragma unroll
         for (int u = 0; u < KU; u++)
             if (kWhole || l + u * 64 < pieces) {
-                if constexpr (FMT == HZSDR_FMT_U8) x[u] ^= (int)0x80808080;  // b - 128 as int8
+                if constexpr (FMT == HZSDR_FMT_U8 && (EXP & 32768) == 0) {
+                    if constexpr (STRAIGHT && (EXP & 262144) != 0) {
+                        if (!flipped) x[u] ^= (int)0x80808080;  // (uniform: a wave's first pass, a pass behind an inactive one)
+                    } else {
+                        x[u] ^= (int)0x80808080;  // b - 128 as int8
+                    }
+                }
                 *reinterpret_cast<v4i *>(lp + u * (64 / PPT) * TS) = x[u];
             }
+        if constexpr (FMT == HZSDR_FMT_U8 && (EXP & 32768) != 0) {
+            // the sign flip by the LDS itself: two ds_xor_b64 per piece behind its write (a wave's LDS operations
+            // execute in order) instead of four v_xor_b32 -- no vector instruction, and the LDS is half idle
+#pragma unroll
+            for (int u = 0; u < KU; u++)
+                if (kWhole || l + u * 64 < pieces) {
+                    unsigned long long *q8 = reinterpret_cast<unsigned long long *>(lp + u * (64 / PPT) * TS);
+                    (void)__hip_atomic_fetch_xor(q8, 0x8080808080808080ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    (void)__hip_atomic_fetch_xor(q8 + 1, 0x8080808080808080ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     };
-    auto land_edge_cold = [&](uint32_t pass, const uint8_t *src, const uint8_t *rhist, int64_t n_bytes, const Geom &G, const Plan &L) {
+    auto land_edge_cold = [&](uint32_t pass, const uint8_t *src, const uint8_t *rhist, int64_t n_bytes, const Geom &G, const Plan &L, const Batch &B) {
         const int64_t p0 = 2 * ((int64_t)D * ((int64_t)pass * kPassOut) - G.w0);
         const int pieces = (int)(image_bytes(D, G.ks) / 16);
 #pragma unroll 1
@@ -382,7 +468,11 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
             const int64_t p = p0 + (int64_t)q * 16;
             v4i v{0, 0, 0, 0};
             if (p >= 0 && p + 16 <= n_bytes) {
-                v = *reinterpret_cast<const v4i *>(src + p);
+                // (a piece never straddles two buffers: their length is a multiple of 16 bytes)
+                uint64_t sb = (uint64_t)(uintptr_t)src;
+                for (int i = 1; i < B.nbuf; i++)
+                    if (p >= (int64_t)i * (int64_t)B.nb) sb = B.vin[i];
+                v = *(const v4i __attribute__((address_space(1))) *)(sb + (uint64_t)p);
             } else if (p < 0 && L.cont && p + 2 * (int64_t)G.off >= 0) {
                 v = *reinterpret_cast<const v4i *>(rhist + (p + 2 * (int64_t)G.off));  // (2 off is a multiple of 16)
             } else if (p + 16 > 0 && p < n_bytes) {  // straddles the buffer's end: byte by byte
@@ -403,10 +493,10 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     };
     auto land_edge = [&](uint32_t pass) {  // (the call's first and last passes)
         if constexpr ((EXP & 4096) != 0) {
-            land_edge_cold(pass, src, rhist, n_bytes, G, L);
+            land_edge_cold(pass, src, rhist, n_bytes, G, L, B);
         } else {
             HZ_COLD_ARGS;
-            land_edge_cold(pass, (const uint8_t *)in, rhist, 2 * (int64_t)n_in, G, L);
+            land_edge_cold(pass, (const uint8_t *)in, rhist, 2 * (int64_t)n_in, G, L, B);
         }
     };
 
@@ -434,8 +524,16 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                     const int q = 4 * aa + 2 * pt;
                     double v = __fma_rn((double)acc[1][b][q + 1], k3, pt ? dci : dcr);
                     v = __fma_rn((double)acc[1][b][q], k2, v);
-                    v = __fma_rn((double)acc[0][b][q + 1], k1, v);
-                    v = __fma_rn((double)acc[0][b][q], k0, v);
+                    if constexpr ((EXP & 16384) != 0) {
+                        // planes 0 and 1 meet in int32 (one v_lshl_add_u32 for a conversion and an fma): the host chose
+                        // the taps' scale so that 256 |sum_0| + |sum_1| < 2^31 for every input (digit_shift); every
+                        // partial sum of the chain is exact in float64 either way, so the result is the same bits
+                        const int hi = (int)(((unsigned)acc[0][b][q] << 8) + (unsigned)acc[0][b][q + 1]);
+                        v = __fma_rn((double)hi, k1, v);
+                    } else {
+                        v = __fma_rn((double)acc[0][b][q + 1], k1, v);
+                        v = __fma_rn((double)acc[0][b][q], k0, v);
+                    }
                     c2[pt] = (float)v;
                 }
                 y[b][aa] = make_float2(c2[0], c2[1]);
@@ -478,13 +576,18 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         };
 #pragma unroll 1
         for (int oi = 0; oi < ((EXP & 4) ? 0 : L.n_ops); oi++) {  // uniform
-            if (L.shift_op != oi) {
+            bool other = L.shift_op != oi;
+            if constexpr ((EXP & 131072) != 0) other = __builtin_expect(other, 0);
+            if (other) {
                 if constexpr ((EXP & 4096) != 0) {
                     other_stage(oi, seg, P);
                 } else {
                     HZ_COLD_ARGS;
                     other_stage(oi, seg, P);
                 }
+                // (a multi-Shift stage's outputs come back through scratch memory: waited for HERE -- left pending they
+                // become a vmcnt(0) at the pass loop's top, behind the next pass's prefetch)
+                if constexpr ((EXP & 131072) != 0) __builtin_amdgcn_s_waitcnt(0x0F70);
             } else {
                 // The stage's phase is a 64-bit accumulator in turns (exact increments, no float64).  ONE Sincos per
                 // lane, for its first output; the other seven are that factor turned on by the group's step factors
@@ -504,6 +607,22 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
 #pragma unroll
                     for (int i = 1; i < 4 * NB; i++) asm volatile("" : "+v"(wpin[i].x), "+v"(wpin[i].y), "+v"(wpin[i].z), "+v"(wpin[i].w));
                 }
+                if constexpr ((EXP & 8192) != 0) {
+                    const v2f cs0{c0, s0};
+#pragma unroll
+                    for (int b = 0; b < NB; b++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            v2f f = cs0;
+                            if (b + q > 0) {
+                                typedef float v4f_ __attribute__((ext_vector_type(4)));
+                                const v4f_ w = *reinterpret_cast<const v4f_ *>(wtab + 4 * b + q);  // (cos hi, sin hi, cos lo, sin lo)
+                                f = pk_turn(cs0, w.xy, w.zw);
+                            }
+                            const v2f r = pk_cmul(v2f{y[b][q].x, y[b][q].y}, f);
+                            y[b][q] = make_float2(r.x, r.y);
+                        }
+                } else
 #pragma unroll
                 for (int b = 0; b < NB; b++)
 #pragma unroll
@@ -551,17 +670,19 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
             }
         }
     };
-    auto store_block = [&](float2(&y)[4], uint32_t mo, uint32_t lo, uint32_t hi) {
+    auto store_block = [&](uint64_t outb, float2(&y)[4], uint32_t mo, uint32_t lo, uint32_t hi) {  // (outb: the pass's buffer, virtual base)
         if constexpr ((EXP & 8) != 0) return;
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        typedef float v2f_ __attribute__((ext_vector_type(2)));
         if (mo >= lo && mo + 4 <= hi) {
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            v4f *o4 = reinterpret_cast<v4f *>(out + mo);
+            v4f __attribute__((address_space(1))) *o4 = (v4f __attribute__((address_space(1))) *)(outb + 8 * (uint64_t)mo);
             __builtin_nontemporal_store(v4f{y[0].x, y[0].y, y[1].x, y[1].y}, o4);
             __builtin_nontemporal_store(v4f{y[2].x, y[2].y, y[3].x, y[3].y}, o4 + 1);
         } else {
+            v2f_ __attribute__((address_space(1))) *o2 = (v2f_ __attribute__((address_space(1))) *)(outb + 8 * (uint64_t)mo);
 #pragma unroll
             for (int q = 0; q < 4; q++)
-                if (mo + q >= lo && mo + q < hi) out[mo + q] = y[q];
+                if (mo + q >= lo && mo + q < hi) o2[q] = v2f_{y[q].x, y[q].y};
         }
     };
     // The runs that matter to this workgroup: those with passes in [pb0, pb1).  Two tables fit the LDS: run A of a
@@ -670,19 +791,24 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
             const uint32_t m_start = pass_of(cur) * (uint32_t)kPassOut;
             const uint32_t v_lo = max(m_lo, m_start), v_hi = min(m_hi, m_start + (uint32_t)kPassOut);
             const bool active = v_lo < v_hi;  // uniform
+            // (EXP & 65536, straight-line form: the first step writes the accumulators -- constant 0 as C -- and an
+            // inactive pass never reads them)
+            constexpr bool kFirstC0 = STRAIGHT && (EXP & 65536) != 0;
             v16i acc[2][NB];
+            if constexpr (!kFirstC0) {
 #pragma unroll
-            for (int f = 0; f < 2; f++)
+                for (int f = 0; f < 2; f++)
 #pragma unroll
-                for (int b = 0; b < NB; b++)
+                    for (int b = 0; b < NB; b++)
 #pragma unroll
-                    for (int q = 0; q < 16; q++) acc[f][b][q] = 0;
+                        for (int q = 0; q < 16; q++) acc[f][b][q] = 0;
+            }
             // (the accumulators as opaque registers: the straight-line form then starts them like every other
             // step -- v_mfma acc, a, b, acc -- instead of with the constant 0 as the C operand.  EXP & 2048 lets the
             // compiler use the constant: 64 clears per pass less, exact sums all the same (tools/mm2_glitch.hip; what
             // round 3 saw "lose terms" with the constant was the mixer's packed instruction, hz_firmm.h) -- and 1.8 us
             // per call SLOWER, measured A/B on one box: the first step's destinations then overlap its sources)
-            if constexpr (STRAIGHT && (EXP & 2048) == 0) {
+            if constexpr (STRAIGHT && (EXP & 2048) == 0 && !kFirstC0) {
 #pragma unroll
                 for (int f = 0; f < 2; f++)
 #pragma unroll
@@ -728,8 +854,28 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
 #pragma unroll
                     for (int f = 0; f < 2; f++)
 #pragma unroll
-                        for (int q = 0; q < NB; q++)
-                            acc[f][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[sx % RG][f], b[sx % RG][q], acc[f][q], 0, 0, 0);
+                        for (int q = 0; q < NB; q++) {
+                            if constexpr (kFirstC0 && SC == 0)
+                                asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(acc[f][q]) : "v"(a[sx % RG][f]), "v"(b[sx % RG][q]));
+                            else
+                                acc[f][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[sx % RG][f], b[sx % RG][q], acc[f][q], 0, 0, 0);
+                        }
+                    // (EXP & 262144, u8 sources: the NEXT pass's bytes -- in flight since the loop's first lines, here long
+                    // since -- get their sign flip in the shadow of this wave's own MFMAs, where a vector instruction
+                    // costs 2-3 cycles; left to the landing they are 40 instructions of the epilogue, which runs
+                    // beside the SIMD partner's loop at one instruction per MFMA slot.  Registers without a load in
+                    // flight hold stale values that nobody lands.)
+                    if constexpr (STRAIGHT && FMT == HZSDR_FMT_U8 && (EXP & 262144) != 0 && SC >= 0) {
+                        constexpr int kFlipFirst = KS - 2 - (KU + 1) / 2;  // two registers per step, done two steps before the end
+                        if constexpr (SC == kFlipFirst) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+                        if constexpr (SC >= kFlipFirst && 2 * (SC - kFlipFirst) < KU) {
+#pragma unroll
+                            for (int u = 2 * (SC - kFlipFirst); u < KU && u < 2 * (SC - kFlipFirst) + 2; u++) {
+                                x[u] ^= (int)0x80808080;
+                                asm volatile("" : "+v"(x[u]));  // (here, not at the landing)
+                            }
+                        }
+                    }
                     // the step's loads between its MFMAs, nothing moved across steps
 #pragma unroll
                     for (int q = 0; q < 2 + NB; q++) {
@@ -795,7 +941,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                 asm volatile("" : "+v"(s1), "+v"(s2));
             };
             if constexpr ((EXP & 256) != 0) csum(cs_e1, cs_e2);
-            if (in_next) land(x);
+            if (in_next) land(x, active && (EXP & 2) == 0);  // (the matrix loop ran: it flipped the bytes' signs)
             else if (has_next) land_edge(pass_of(nxt));
             vm_clear();
             stamp(3);
@@ -837,8 +983,9 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                     // (the run's step factors: behind the constant term at the table's end, hz_firmm2_plan.h)
                     program(y, mb, phi_r, dphi, sel ? rv.seg : ru.seg, reinterpret_cast<const float4 *>(dc + 2));
                     stamp(5);
+                    const uint64_t outp = vout_of(buf_of(pass_of(cur)));
 #pragma unroll
-                    for (int b = 0; b < NB; b++) store_block(y[b], mb + (uint32_t)(32 * kT) * b, v_lo, v_hi);
+                    for (int b = 0; b < NB; b++) store_block(outp, y[b], mb + (uint32_t)(32 * kT) * b, v_lo, v_hi);
                 }
             }
             stamp(6);
@@ -878,7 +1025,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
 // hz_firmm2.hip
 int launch_fir(hipStream_t stream, int num_cus, int fmt, unsigned D, const void *in, float2 *out, const float2 *hist,
                float2 *new_hist, const uint8_t *rhist, uint8_t *new_rhist, const float2 *taps, size_t n, const Geom &g,
-               const Plan &L, const EwProgram &P, const Fix &F, int loop_form = 0);
+               const Plan &L, const EwProgram &P, const Fix &F, const Batch &B, int loop_form = 0);
 // the history tasks alone, as a kernel of their own (n >= off): hz_firmm2.hip
 int launch_history(hipStream_t stream, int fmt, const void *in, float2 *new_hist, uint8_t *new_rhist, size_t n, unsigned off, const EwProgram &P);
 

@@ -93,6 +93,52 @@ struct Fix {
     uint32_t m_a[kMaxFix], m_b[kMaxFix];
     int task_first[kMaxFix];
 };
+// A call over SEVERAL buffers of equal length (hzsdr_chain_run_batch): the kernel works on their concatenation -- the
+// planner sees one call of nbuf * n samples -- and finds a sample's (an output's) buffer by its index.  Buffer j's
+// VIRTUAL base is its address minus j buffers' worth of bytes, so that base + (index in the concatenation) is the
+// sample's address; a pass (512 outputs) never straddles two buffers (the host: n / D is a multiple of pass_out), a
+// pass IMAGE does at the first pass of every buffer but the first (its window reaches back into the previous
+// buffer: the edge landing, piece by piece).  An ordinary call is nbuf = 1 with the buffers' own addresses.
+constexpr int kMaxBatch = 8;
+struct Batch {
+    int nbuf;
+    uint32_t ppb;        // passes per buffer
+    uint32_t out_each;   // outputs per buffer
+    uint32_t rcp;        // floor(2^32 / ppb) + 1: a pass's buffer is mulhi(pass, rcp) -- ONE scalar instruction (batch_ok bounds ppb)
+    uint64_t nb;         // bytes per input buffer
+    uint64_t vin[kMaxBatch], vout[kMaxBatch];
+};
+inline Batch one_buffer(const void *in, void *out, uint64_t n_in, unsigned D) {
+    Batch B{};
+    B.nbuf = 1;
+    B.ppb = 0xffffffffu;
+    B.out_each = (uint32_t)(n_in / D);
+    B.nb = 2 * n_in;
+    B.vin[0] = (uint64_t)(uintptr_t)in;
+    B.vout[0] = (uint64_t)(uintptr_t)out;
+    return B;
+}
+// nbuf buffers of n_each samples (n_each / D a multiple of the pass: the caller checks batch_ok)
+inline bool batch_ok(uint64_t n_each, unsigned D, size_t nbuf) {
+    if (!(nbuf >= 1 && nbuf <= (size_t)kMaxBatch && n_each % D == 0 && (n_each / D) % (uint64_t)pass_out((int)D) == 0 && n_each * nbuf / D < (1ull << 31)))
+        return false;
+    // pass / ppb as mulhi(pass, floor(2^32 / ppb) + 1): exact for pass < nbuf ppb as long as nbuf ppb^2 < 2^32
+    const uint64_t ppb = n_each / D / (uint64_t)pass_out((int)D);
+    return ppb >= 1 && nbuf * ppb * ppb < (1ull << 32);
+}
+inline Batch make_batch(const void *const *ins, void *const *outs, size_t nbuf, uint64_t n_each, unsigned D) {
+    Batch B{};
+    B.nbuf = (int)nbuf;
+    B.out_each = (uint32_t)(n_each / D);
+    B.ppb = B.out_each / (uint32_t)pass_out((int)D);
+    B.rcp = (uint32_t)((1ull << 32) / B.ppb) + 1u;
+    B.nb = 2 * n_each;
+    for (size_t j = 0; j < nbuf; j++) {
+        B.vin[j] = (uint64_t)(uintptr_t)ins[j] - (uint64_t)j * B.nb;
+        B.vout[j] = (uint64_t)(uintptr_t)outs[j] - (uint64_t)j * B.out_each * 8;
+    }
+    return B;
+}
 
 // phase accumulator constants of a run (host): frac(tau step / 2 pi) and frac(tau t0 / 2 pi) - first * the increment,
 // in 2^-64 turns.

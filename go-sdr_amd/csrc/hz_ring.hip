@@ -19,8 +19,6 @@ struct hzsdr_ring {
     char *dev_in = nullptr, *dev_out = nullptr;
     struct Slot {
         hipEvent_t up = nullptr, done = nullptr, down = nullptr;
-        hipEvent_t hread = nullptr;  // a pipelined chain: the history kernel that read this slot's device copy
-        bool hread_set = false;
         size_t n_out = 0;
         int state = 0;  // 0 free, 1 acquired, 2 in flight
     };
@@ -43,7 +41,6 @@ int hzsdr_ring_free(hzsdr_ring *r) {
         if (s.up) (void)hipEventDestroy(s.up);
         if (s.done) (void)hipEventDestroy(s.done);
         if (s.down) (void)hipEventDestroy(s.down);
-        if (s.hread) (void)hipEventDestroy(s.hread);
     }
     for (char *p : {r->pin_in, r->pin_out})
         for (size_t i = 0; p && i < r->ctx->pinned_ranges.size(); i++)
@@ -100,7 +97,6 @@ int hzsdr_ring_create(hzsdr_chain *c, size_t slot_length, int slots, hzsdr_ring 
     ctx->pinned_ranges.push_back({r->pin_out, r->out_bytes() * slots});
     for (auto &s : r->slots) {
         HZ_RING(hipEventCreateWithFlags(&s.up, hipEventDisableTiming));
-        HZ_RING(hipEventCreateWithFlags(&s.hread, hipEventDisableTiming));
         HZ_RING(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
         HZ_RING(hipEventCreateWithFlags(&s.down, hipEventDisableTiming));
     }
@@ -144,22 +140,24 @@ int hzsdr_ring_submit(hzsdr_ring *r, int slot, size_t n) {
     const size_t fs = (size_t)format_size(r->chain->src_fmt);
     char *hin = r->pin_in + (size_t)slot * r->in_bytes(), *din = r->dev_in + (size_t)slot * r->in_bytes();
     char *hout = r->pin_out + (size_t)slot * r->out_bytes(), *dout = r->dev_out + (size_t)slot * r->out_bytes();
-    if (s.hread_set) {  // (the slot's previous use: its last samples were read by a history kernel beside the call's own)
-        HZ_HIP(ctx, hipStreamWaitEvent(r->s_up, s.hread, 0));
-        s.hread_set = false;
-    }
+    // (the slot's previous use was popped -- its download, behind every kernel that read or wrote its device copies,
+    // has completed -- before it could be acquired again: the upload stream needs no further wait)
     HZ_HIP(ctx, hipMemcpyAsync(din, hin, n * fs, hipMemcpyHostToDevice, r->s_up));
     HZ_HIP(ctx, hipEventRecord(s.up, r->s_up));
-    HZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.up, 0));
     double ts;
-    r->chain->wait_in = s.up;  // (a pipelined chain launches on streams of its own: they wait for the upload too)
-    const int rc_launch = chain_launch(r->chain, din, n, dout, outn, &ts);
-    r->chain->wait_in = nullptr;
-    HZ_TRY(rc_launch);
-    if (r->chain->pcall > 0) {  // (this call ran pipelined: its history kernel sits on the NEXT call's stream)
-        HZ_HIP(ctx, hipEventRecord(s.hread, r->chain->pstream[r->chain->pcall & 1]));
-        s.hread_set = true;
+    // The ring knows what the call's buffers wait for -- this upload, nothing else: the slot's device copies are its
+    // own -- so a pipelined chain may overlap the call with the one before (hzsdr_chain_run_after's contract); any
+    // other chain's launch waits for the event on the context's stream (pipeline_drain).
+    r->chain->relaxed = r->chain->pipelined;  // (the slot's device copies, whatever the context's memory space)
+    r->chain->ready = s.up;
+    if (!r->chain->relaxed) {
+        r->chain->ready = nullptr;
+        HZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.up, 0));
     }
+    const int rc_launch = chain_launch(r->chain, din, n, dout, outn, &ts);
+    r->chain->relaxed = false;
+    r->chain->ready = nullptr;
+    HZ_TRY(rc_launch);
     HZ_HIP(ctx, hipGetLastError());
     r->chain->ts = ts;
     HZ_HIP(ctx, hipEventRecord(s.done, ctx->stream));

@@ -262,9 +262,9 @@ func (ch *Chain) FIROptions(impl int, nfftMin uint, loopForm int) error {
 	return toErr(ch.x.c, C.hzsdr_chain_fir_options(ch.c, C.int(impl), C.uint(nfftMin), C.int(loopForm)))
 }
 
-// Pipeline lets consecutive Run calls of a FIR-decimate chain on the int8 matrix path overlap (include/hzsdr.h:
-// hzsdr_chain_pipeline): the input of a call must be complete when Run is called -- the launch is not ordered behind
-// earlier work on the context's stream --, the output stays ordered on that stream, the results are bit-identical.
+// Pipeline opts a FIR-decimate chain on the int8 matrix path (or a chain of maps) in to overlapping consecutive calls
+// (include/hzsdr.h: hzsdr_chain_pipeline).  Run stays an ordinary call on the context's stream; the overlap is taken by
+// RunAfter / RunBatchAfter, where the caller states what the call's buffers wait for.  Results are bit-identical.
 func (ch *Chain) Pipeline(on bool) error { return toErr(ch.x.c, C.hzsdr_chain_pipeline(ch.c, cbool(on))) }
 
 // ShiftULP1 opts a terminal-less chain (ShiftReader, ShiftReader -> Gain) in to the Shift whose rotation
@@ -281,6 +281,59 @@ func (ch *Chain) Plan(nIn int) (consumed, out int, err error) {
 func (ch *Chain) Run(in, out sdr.Samples) (int, error) {
 	var cons, n C.size_t
 	rc := C.hzsdr_chain_run(ch.c, base(in), C.size_t(in.Length()), base(out), C.size_t(out.Length()), &cons, &n)
+	return int(n), toErr(ch.x.c, rc)
+}
+
+// RunAfter is Run whose START the caller orders: the buffers are ready when `ready` (a hipEvent_t; nil: now) has
+// fired, not "when the context's stream gets there" (include/hzsdr.h: hzsdr_chain_run_after).  The call's reads and
+// writes are ordered on the context's stream as Run's are.
+func (ch *Chain) RunAfter(in, out sdr.Samples, ready unsafe.Pointer) (int, error) {
+	var cons, n C.size_t
+	rc := C.hzsdr_chain_run_after(ch.c, base(in), C.size_t(in.Length()), base(out), C.size_t(out.Length()), &cons, &n, ready)
+	return int(n), toErr(ch.x.c, rc)
+}
+
+// RunBatch hands len(ins) consecutive buffers of the stream (equal lengths, at most eight) to the chain in one call:
+// the results and the chain's state are those of len(ins) Run calls in a row; a FIR-decimate chain on the
+// persistent-pass matrix kernel takes them in ONE launch (include/hzsdr.h: hzsdr_chain_run_batch).  Returns the
+// samples written per buffer.  The pointer tables live in C memory for the call: cgo may not be handed Go memory
+// that itself holds Go pointers.
+func (ch *Chain) RunBatch(ins, outs []sdr.Samples) (int, error) { return ch.runBatch(ins, outs, false, nil) }
+
+// RunBatchAfter is RunBatch with RunAfter's ordering (every buffer of the batch ready at the event).
+func (ch *Chain) RunBatchAfter(ins, outs []sdr.Samples, ready unsafe.Pointer) (int, error) {
+	return ch.runBatch(ins, outs, true, ready)
+}
+
+func (ch *Chain) runBatch(ins, outs []sdr.Samples, after bool, ready unsafe.Pointer) (int, error) {
+	k := len(ins)
+	if k == 0 || k != len(outs) {
+		return 0, sdr.ErrDstTooSmall
+	}
+	psz := C.size_t(unsafe.Sizeof(unsafe.Pointer(nil)))
+	pi := (*[8]unsafe.Pointer)(C.malloc(C.size_t(k) * psz))
+	po := (*[8]unsafe.Pointer)(C.malloc(C.size_t(k) * psz))
+	defer C.free(unsafe.Pointer(pi))
+	defer C.free(unsafe.Pointer(po))
+	outCap := outs[0].Length()
+	for j := 0; j < k && j < 8; j++ {
+		if ins[j].Length() != ins[0].Length() {
+			return 0, sdr.ErrDstTooSmall
+		}
+		if outs[j].Length() < outCap {
+			outCap = outs[j].Length()
+		}
+		pi[j], po[j] = base(ins[j]), base(outs[j])
+	}
+	var cons, n C.size_t
+	var rc C.int
+	if after {
+		rc = C.hzsdr_chain_run_batch_after(ch.c, (*unsafe.Pointer)(unsafe.Pointer(pi)), (*unsafe.Pointer)(unsafe.Pointer(po)), C.size_t(k),
+			C.size_t(ins[0].Length()), C.size_t(outCap), &cons, &n, ready)
+	} else {
+		rc = C.hzsdr_chain_run_batch(ch.c, (*unsafe.Pointer)(unsafe.Pointer(pi)), (*unsafe.Pointer)(unsafe.Pointer(po)), C.size_t(k),
+			C.size_t(ins[0].Length()), C.size_t(outCap), &cons, &n)
+	}
 	return int(n), toErr(ch.x.c, rc)
 }
 

@@ -376,24 +376,19 @@ int hzsdr_chain_mix_in_order(hzsdr_chain *c, int in_order);
 #define HZSDR_FIR_IMPL_TRANSFORMS 1     /* the overlap-save transform kernels */
 #define HZSDR_FIR_IMPL_MATRIX_CHUNKS 2  /* the int8 matrix form as chunk workgroups (hz_firmm.h), where eligible */
 int hzsdr_chain_fir_options(hzsdr_chain *c, int impl, unsigned nfft_min, int loop_form);
-/* OPT-IN, off by default: consecutive hzsdr_chain_run calls of a FIR-decimate chain on the int8 matrix path, or of a
- * chain without a terminal stage (convert / Shift / Gain / Multiply maps), OVERLAP.
+/* OPT-IN, off by default: consecutive calls of a FIR-decimate chain on the int8 matrix path, or of a chain without a
+ * terminal stage (convert / Shift / Gain / Multiply maps), may OVERLAP on the GPU.
  * A stream runs its launches one behind the other -- the next call's workgroups wait for the last workgroup of this
  * one and then pay the kernel's head in full: ~5 us of 37 per 2^24-sample buffer.  The calls of one chain depend on
  * each other through the FIR history alone, which is a function of the call's input; a pipelined chain forms it in
- * a small kernel of its own and alternates its calls between two streams it owns.  What changes for the caller:
- *   - the buffers of a call must be FREE OF PENDING WORK when hzsdr_chain_run is called: the launch is not ordered
- *     behind earlier work on the context's stream, so the input must be complete (an asynchronous copy that fills it:
- *     synchronise that first; the previous call's output is not complete -- consecutive calls use different buffers)
- *     and the output buffer no longer read by anything still queued (two output buffers used alternately, each
- *     consumed before its next use is submitted).  The input
- *     must stay as it is until the NEXT call's output is complete or the context has been synchronised with
- *     hzsdr_synchronize (the small kernel that forms the next call's history reads its last samples, beside the
- *     call's own kernel);
- *   - the OUTPUT is ordered on the context's stream as always (later work on that stream sees it);
- *   - results are bit-identical to the unpipelined chain's (the same kernels on the same values).
- * Calls that do not take the matrix path (too many clock boundaries, other source formats and factors) run as
- * before, behind everything in flight.  DEVICE-space contexts; a HOST-space call is synchronous either way. */
+ * a small kernel of its own and alternates its calls between two streams it owns.
+ * The mode changes NOTHING about hzsdr_chain_run: that call is ordered on the context's stream like every other call
+ * of this library (behind what the stream holds, in front of what is enqueued later), and so cannot overlap the call
+ * before it -- the stream has just been made to wait for that one.  The overlap is taken by hzsdr_chain_run_after /
+ * hzsdr_chain_run_batch_after (below), where the caller states what the call's buffers wait for instead.  Results are
+ * bit-identical either way (the same kernels on the same values).  Calls that do not take the matrix path (too many
+ * clock boundaries, other source formats and factors) run on the context's stream as before.  (No reference
+ * counterpart: stream.* Readers are synchronous, reader.go:39-51; the single-consumer, in-order contract is kept.) */
 int hzsdr_chain_pipeline(hzsdr_chain *c, int on);
 /* OPT-IN, off by default: a chain WITHOUT a terminal (ShiftReader, or ShiftReader -> Gain: BASELINE config 2)
  * whose buffers allow four samples per lane forms the Shift's rotation factor from the phase in turns with
@@ -433,6 +428,31 @@ int hzsdr_chain_plan(const hzsdr_chain *c, size_t n_in, size_t *n_consumed, size
 /* One buffer through the chain.  out format: c64. */
 int hzsdr_chain_run(hzsdr_chain *c, const void *in, size_t n_in, void *out, size_t out_cap,
                     size_t *n_consumed, size_t *n_out);
+/* hzsdr_chain_run with the call's START ordered by the caller: the call's buffers -- `in` complete, `out` no longer
+ * in use by anyone -- are ready when `ready_event` (a hipEvent_t; NULL: they are ready now) has fired, NOT "when the
+ * context's stream gets there".  Everything else is hzsdr_chain_run's contract: the call's reads of `in` and writes
+ * of `out` are ordered on the context's stream (work enqueued there afterwards may consume `out` and refill `in`),
+ * chain state advances in call order, results are bit-identical.  On a chain in pipelined mode (hzsdr_chain_pipeline)
+ * in a DEVICE-space context this is the call that overlaps with the one before it; buffers that overlap those of the
+ * two calls before are detected and the call ordered behind them.  On any other chain or context the event is simply
+ * waited for where the call runs.  A producer on another stream records the event; a producer on the context's own
+ * stream needs nothing of this -- hzsdr_chain_run is already behind it.  (The pinned ring, hzsdr_ring_*, is built on
+ * this call: its uploads are the events.)  No reference counterpart. */
+int hzsdr_chain_run_after(hzsdr_chain *c, const void *in, size_t n_in, void *out, size_t out_cap,
+                          size_t *n_consumed, size_t *n_out, void *ready_event);
+/* n_buffers (1..8) consecutive buffers of the stream, n_in samples each, in ONE call: the results, the chain's state
+ * and the ordering on the context's stream are those of n_buffers hzsdr_chain_run calls in a row (outs[j]: out_cap
+ * samples each; *n_consumed / *n_out: per buffer; a batch's buffers must be consumed whole).  A FIR-decimate chain
+ * on the persistent-pass matrix kernel (hzsdr_chain_last_fir_kernel) whose buffers hold a whole number of 512-output
+ * passes takes the batch in ONE launch -- the kernel's head, launch and tail are paid once per batch instead of once
+ * per buffer: 2^24-sample buffers by four, ~30 us per buffer where single calls take ~36 -- with the mixer's phase
+ * carried through the batch (outputs may differ from single calls' in the last bit; the FIR's error bound holds).
+ * Every other chain runs the buffers one after the other.  _after: the START as in hzsdr_chain_run_after (all the
+ * batch's buffers ready at the event).  No reference counterpart (a Reader hands over one slice per Read). */
+int hzsdr_chain_run_batch(hzsdr_chain *c, const void *const *ins, void *const *outs, size_t n_buffers, size_t n_in,
+                          size_t out_cap, size_t *n_consumed, size_t *n_out);
+int hzsdr_chain_run_batch_after(hzsdr_chain *c, const void *const *ins, void *const *outs, size_t n_buffers, size_t n_in,
+                                size_t out_cap, size_t *n_consumed, size_t *n_out, void *ready_event);
 /* Forget stream state (NCO time, FIR history). */
 int hzsdr_chain_reset(hzsdr_chain *c);
 /* The Shift closure's clock `ts` (stream/shifter.go:71,77-80), in [0, 2*pi]: read it to

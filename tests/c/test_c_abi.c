@@ -242,7 +242,7 @@ static void chain_and_ring(void) { /* go/hip/stream.go Chain, go/hip/ring.go */
     CHECK(hzsdr_chain_fir_options(c, HZSDR_FIR_IMPL_TRANSFORMS, 0, 0) == HZSDR_ERR_INVALID_ARGUMENT); /* in front of it */
     OK(hzsdr_chain_mix_in_order(c, 0));
     OK(hzsdr_chain_shift_ulp1(c, 0));
-    OK(hzsdr_chain_pipeline(c, 1)); /* consecutive calls may overlap (inputs complete at call time: host buffers are) */
+    OK(hzsdr_chain_pipeline(c, 1)); /* hzsdr_chain_run_after calls may overlap (DEVICE space; a HOST-space call is synchronous) */
     CHECK(hzsdr_chain_pipeline(NULL, 1) == HZSDR_ERR_INVALID_ARGUMENT);
     size_t cons = 0, outn = 0;
     OK(hzsdr_chain_plan(c, N, &cons, &outn));
@@ -259,6 +259,29 @@ static void chain_and_ring(void) { /* go/hip/stream.go Chain, go/hip/ring.go */
     int kern = -1;
     OK(hzsdr_chain_last_fir_kernel(c, &kern));
     CHECK(kern >= HZSDR_FIR_KERNEL_TRANSFORM && kern <= HZSDR_FIR_KERNEL_MATRIX_PASSES);
+    /* the same stream once more in the calls' other forms (go/hip/stream.go RunAfter, RunBatch, RunBatchAfter): a
+       call that states what its buffers wait for (NULL: nothing), and two half buffers handed over together */
+    float *y2 = (float *)malloc(8 * N / D);
+    OK(hzsdr_chain_reset(c));
+    OK(hzsdr_chain_run(c, x, N, y, N / D, &cons, &outn));
+    OK(hzsdr_chain_reset(c));
+    OK(hzsdr_chain_run_after(c, x, N, y2, N / D, &cons, &outn, NULL));
+    CHECK(outn == N / D && memcmp(y, y2, 8 * (N / D)) == 0);
+    {
+        const void *ins[2] = {x, x + N};
+        void *outs[2] = {y2, y2 + N / D};
+        memset(y2, 0, 8 * (N / D));
+        OK(hzsdr_chain_reset(c));
+        CHECK(hzsdr_chain_run_batch(c, ins, outs, 9, N / 2, N / 2 / D, &cons, &outn) == HZSDR_ERR_INVALID_ARGUMENT);
+        OK(hzsdr_chain_run_batch(c, ins, outs, 2, N / 2, N / 2 / D, &cons, &outn));
+        CHECK(cons == N / 2 && outn == N / 2 / D);
+        for (int i = 0; i < 2 * (N / D); i++) CHECK(fabsf(y2[i] - y[i]) <= 2e-6f);
+        OK(hzsdr_chain_reset(c));
+        OK(hzsdr_chain_run_batch_after(c, ins, outs, 2, N / 2, N / 2 / D, &cons, &outn, NULL));
+        CHECK(cons == N / 2 && outn == N / 2 / D);
+        for (int i = 0; i < 2 * (N / D); i++) CHECK(fabsf(y2[i] - y[i]) <= 2e-6f);
+    }
+    free(y2);
     OK(hzsdr_chain_set_time(c, 1.0));
     OK(hzsdr_chain_reset(c));
     /* the ring: ONE pinned region for all slots (IQBufferAllocator), acquire / fill / submit / pop */

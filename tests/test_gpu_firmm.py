@@ -322,8 +322,8 @@ def test_reset_and_interleaved_chains(hz, ctx, orc):
 
 
 def test_pipelined_chain_is_bit_identical_to_the_plain_one(hz):
-    """hzsdr_chain_pipeline: consecutive calls overlap (two streams of the chain's own, the next call's history from
-    a kernel of its own), the same kernels on the same values -- every output bit as the unpipelined chain gives
+    """hzsdr_chain_pipeline + hzsdr_chain_run_after: consecutive calls overlap (two streams of the chain's own, the next
+    call's history from a kernel of its own), the same kernels on the same values -- every output bit as the unpipelined chain gives
     it, over forty calls across binades of the clock and the 2 pi wrap, with a change of the clock, a call too
     short for the matrix path (drains the pipeline) and a switch off and on again in between."""
     import torch
@@ -350,7 +350,8 @@ def test_pipelined_chain_is_bit_identical_to_the_plain_one(hz):
             if i == 29 and piped:
                 ch.pipeline(True)
             m = sizes[i]  # (call 11 is short: the transform kernels, behind everything in flight)
-            assert ch.run(xs[i % 5][:m], ys[i]) == (m, m // D)
+            run = ch.run_after if piped else ch.run  # (the overlap is run_after's: the buffers are ready now)
+            assert run(xs[i % 5][:m], ys[i]) == (m, m // D)
         ctx.synchronize()
         outs.append([torch.view_as_real(y).view(torch.int32).cpu().numpy() for y in ys])
         assert ch.last_fir_path() == hz.FIR_PATH_MATRIX
@@ -389,7 +390,8 @@ def test_pipelined_chain_random_calls_bit_identical(hz, seed):
                 ch.set_time(resets[i])
             if off + m > (1 << 20):
                 off = 0
-            assert ch.run(src[off:off + m], ys[i]) == (m, m // D)
+            run = ch.run_after if piped else ch.run
+            assert run(src[off:off + m], ys[i]) == (m, m // D)
             off += m - m % 16  # (16-byte aligned starts: the matrix path's condition)
         ctx.synchronize()
         outs.append([torch.view_as_real(y).view(torch.int32).cpu().numpy() for y in ys])
@@ -428,7 +430,8 @@ def test_pipelined_map_chain_is_bit_identical(hz, kind):
         for i, m in enumerate(sizes):
             if i == 19:
                 ch.set_time(1.9)
-            assert ch.run(xs[i % 4][:m], ys[i]) == (m, m)
+            run = ch.run_after if piped else ch.run
+            assert run(xs[i % 4][:m], ys[i]) == (m, m)
         ctx.synchronize()
         outs.append([torch.view_as_real(y).view(torch.int32).cpu().numpy() for y in ys])
         clocks.append(ch.time())
@@ -437,3 +440,181 @@ def test_pipelined_map_chain_is_bit_identical(hz, kind):
     for i, (a, b) in enumerate(zip(*outs)):
         assert np.array_equal(a, b), "call %d differs" % i
     ctx.close()
+
+
+# ---- round 5: the ordering contract of the overlapped calls, and calls over several buffers -----------------------
+
+def _north_chain(hz, ctx, taps, fs=20_000_000, D=8, fmt=None):
+    return ctx.chain(hz.FMT_U8 if fmt is None else fmt, fs).shift(-fs / 8).fir_decimate(taps, D)
+
+
+def test_pipelined_chain_keeps_the_context_streams_order(hz):
+    """What round 4's mode got wrong and this round's contract fixes, on ONE input and ONE output buffer used by
+    every call: the input is filled by an asynchronous copy enqueued on the context's stream right in front of each
+    call, the output is copied away on that stream right behind it, nothing synchronises for 40 calls.
+      * run() on a pipelined chain is an ordinary call: behind the copy, in front of the consumer;
+      * run_after(event) with the producer on ANOTHER stream: the call waits for the event, and because it uses the
+        buffers of the call before it the library orders it behind that call by itself;
+      * run_after with three rotating buffer pairs and the consumer on the context's stream: the overlapped form.
+    All three equal the plain chain bit for bit, and the plain chain is held to the oracle."""
+    import torch
+    import oracle as orc
+    n, fs, D, calls = 1 << 19, 20_000_000, 8, 40
+    taps = taps_for(1024, 1 / 16, 0.0)
+    host = [torch.from_numpy(rand_u8(900 + i, n)).pin_memory() for i in range(calls)]
+    s_ctx, s_copy = torch.cuda.Stream(), torch.cuda.Stream()
+    ctx = hz.Context(0, hz.MEM_DEVICE, stream=s_ctx.cuda_stream)
+    results = {}
+    for mode in ("plain", "run_on_stream", "after_same_buffers", "after_rotating"):
+        ch = _north_chain(hz, ctx, taps)
+        if mode != "plain":
+            ch.pipeline(True)
+        ch.set_time(TAU - 0.05)
+        nbuf = 3 if mode == "after_rotating" else 1
+        xin = [torch.zeros((n, 2), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+        yout = [torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(nbuf)]
+        stash = torch.zeros((calls, n // D), dtype=torch.complex64, device="cuda")
+        evs = [torch.cuda.Event() for _ in range(nbuf)]
+        consumed = [torch.cuda.Event() for _ in range(nbuf)]
+        torch.cuda.synchronize()
+        for i in range(calls):
+            b = i % nbuf
+            if mode in ("plain", "run_on_stream"):
+                with torch.cuda.stream(s_ctx):
+                    xin[b].copy_(host[i], non_blocking=True)
+                assert ch.run(xin[b], yout[b]) == (n, n // D)
+            else:
+                with torch.cuda.stream(s_copy):
+                    if i >= nbuf:
+                        s_copy.wait_event(consumed[b])  # (the pair's previous use: read by its call, consumed behind it)
+                    xin[b].copy_(host[i], non_blocking=True)
+                    evs[b].record(s_copy)
+                assert ch.run_after(xin[b], yout[b], evs[b]) == (n, n // D)
+            with torch.cuda.stream(s_ctx):  # the consumer, on the context's stream: behind the call like behind any other
+                stash[i].copy_(yout[b], non_blocking=True)
+                consumed[b].record(s_ctx)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        results[mode] = torch.view_as_real(stash).view(torch.int32).cpu().numpy()
+        assert ch.last_fir_path() == hz.FIR_PATH_MATRIX
+        ch.close()
+    for mode in ("run_on_stream", "after_same_buffers", "after_rotating"):
+        for i in range(calls):
+            assert np.array_equal(results["plain"][i], results[mode][i]), (mode, "call %d differs" % i)
+    x = np.concatenate([h.numpy() for h in host])
+    want, xmax = oracle(orc, x, fs, [("shift", -fs / 8)], taps, D, ts0=TAU - 0.05)
+    got = results["plain"].view(np.float32).view(np.complex64).reshape(-1)
+    assert_fir_close(got, want, taps, xmax, "40 calls behind their copies")
+    ctx.close()
+
+
+@pytest.mark.parametrize("piped", [False, True])
+def test_run_batch_one_launch_equals_the_stream(hz, piped):
+    """hzsdr_chain_run_batch: k buffers of the stream in ONE launch of the persistent-pass kernel (separate
+    allocations, the first pass of every buffer reaching back into the one before) -- against the oracle over the
+    whole stream, within a float32 ulp or two of the same stream through single calls, batches of 4, 3, 1, 8 in a
+    row across the clock's 2 pi wrap; a batch of buffers too short for whole passes runs one by one and equals
+    single calls bit for bit."""
+    import torch
+    import oracle as orc
+    n, fs, D = 1 << 18, 20_000_000, 8
+    taps = taps_for(1024, 1 / 16, 0.0)
+    batches = [4, 3, 1, 8]
+    total = sum(batches)
+    x = rand_u8(77, n * total)
+    xs = [torch.from_numpy(x[j * n:(j + 1) * n]).cuda() for j in range(total)]
+    ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.Stream().cuda_stream)
+    ts0 = TAU - 0.05  # (wraps 10^6 samples in)
+    single = _north_chain(hz, ctx, taps)
+    single.set_time(ts0)
+    ys = [torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(total)]
+    torch.cuda.synchronize()
+    for j in range(total):
+        assert single.run(xs[j], ys[j]) == (n, n // D)
+    ctx.synchronize()
+    ref = np.concatenate([y.cpu().numpy() for y in ys])
+    ch = _north_chain(hz, ctx, taps)
+    if piped:
+        ch.pipeline(True)
+    ch.set_time(ts0)
+    zs = [torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(total)]
+    torch.cuda.synchronize()
+    j = 0
+    for k in batches:
+        assert ch.run_batch(xs[j:j + k], zs[j:j + k], after=piped) == (n, n // D)
+        assert ch.last_fir_kernel() == hz.FIR_KERNEL_MATRIX_PASSES
+        j += k
+    ctx.synchronize()
+    assert ch.time() == single.time()
+    got = np.concatenate([z.cpu().numpy() for z in zs])
+    want, xmax = oracle(orc, x, fs, [("shift", -fs / 8)], taps, D, ts0=ts0)
+    assert_fir_close(got, want, taps, xmax, "batched stream")
+    assert_fir_close(ref, want, taps, xmax, "single calls")
+    scale = float(np.abs(ref).max())
+    assert float(np.abs(got - ref).max()) <= 4e-7 * scale  # (the mixer's phase carried through a batch: last-bit differences)
+    # the stream goes on in single calls from the batched chain's state: the history a batch leaves is the last buffer's
+    tail_in = torch.from_numpy(rand_u8(78, n)).cuda()
+    ya, yb = (torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(2))
+    torch.cuda.synchronize()
+    assert single.run(tail_in, ya) == (n, n // D) and ch.run(tail_in, yb) == (n, n // D)
+    ctx.synchronize()
+    assert float((ya - yb).abs().max()) <= 4e-7 * scale
+    # buffers that do not hold whole passes (n / D not a multiple of 512): one by one, the same bits as single calls
+    m = n - 8 * 24
+    ch.set_time(1.0), single.set_time(1.0)
+    za = [torch.zeros(m // D, dtype=torch.complex64, device="cuda") for _ in range(3)]
+    zb = [torch.zeros(m // D, dtype=torch.complex64, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()
+    assert ch.run_batch([t[:m] for t in xs[:3]], za, after=piped) == (m, m // D)
+    for q in range(3):
+        assert single.run(xs[q][:m], zb[q]) == (m, m // D)
+    ctx.synchronize()
+    for q in range(3):
+        assert torch.equal(torch.view_as_real(za[q]).view(torch.int32), torch.view_as_real(zb[q]).view(torch.int32)), q
+    ch.close(), single.close(), ctx.close()
+
+
+def test_run_batch_other_chains_and_errors(hz):
+    """A chain without a one-launch form takes a batch buffer by buffer: the same bits as single calls (Shift + Gain map,
+    a c64 FIR on the transform kernels, HOST space).  Argument errors: 0 or 9 buffers, a short output, ragged buffers."""
+    import torch
+    from util import rand_c64
+    n, fs = 1 << 16, 20_000_000
+    ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+    xs = [torch.from_numpy(rand_c64(40 + j, n)).cuda() for j in range(3)]
+    for kind in ("map", "fir_c64"):
+        chains = []
+        for _ in range(2):
+            ch = ctx.chain(hz.FMT_C64, fs).shift(1.7e6).gain(0.25)
+            if kind == "fir_c64":
+                ch = ch.fir_decimate(taps_for(256, 1 / 16, 0.0), 4)
+            chains.append(ch)
+        no = n if kind == "map" else n // 4
+        ya = [torch.zeros(no, dtype=torch.complex64, device="cuda") for _ in range(3)]
+        yb = [torch.zeros(no, dtype=torch.complex64, device="cuda") for _ in range(3)]
+        torch.cuda.synchronize()
+        assert chains[0].run_batch(xs, ya) == (n, no)
+        for j in range(3):
+            assert chains[1].run(xs[j], yb[j]) == (n, no)
+        ctx.synchronize()
+        for j in range(3):
+            assert torch.equal(torch.view_as_real(ya[j]).view(torch.int32), torch.view_as_real(yb[j]).view(torch.int32)), (kind, j)
+        assert chains[0].time() == chains[1].time()
+        with pytest.raises(hz.ErrDstTooSmall):
+            chains[0].run_batch(xs, [y[:no - 1] for y in ya])
+        for ch in chains:
+            ch.close()
+    ch = ctx.chain(hz.FMT_C64, fs).gain(2.0)
+    with pytest.raises(Exception):
+        ch.run_batch([xs[0]] * 9, [torch.zeros(n, dtype=torch.complex64, device="cuda") for _ in range(9)])
+    ch.close()
+    ctx.close()
+    hctx = hz.Context(0, hz.MEM_HOST)
+    x = [rand_u8(60 + j, 1 << 15) for j in range(2)]
+    a, b = hctx.chain(hz.FMT_U8, fs).shift(1e6), hctx.chain(hz.FMT_U8, fs).shift(1e6)
+    ya, yb = [zeros("c64", 1 << 15) for _ in range(2)], [zeros("c64", 1 << 15) for _ in range(2)]
+    assert a.run_batch(x, ya) == (1 << 15, 1 << 15)
+    for j in range(2):
+        b.run(x[j], yb[j])
+    assert all(p.tobytes() == q.tobytes() for p, q in zip(ya, yb))
+    a.close(), b.close(), hctx.close()

@@ -24,9 +24,12 @@ static void pct(const char *name, std::vector<double> v) {
            v[v.size() / 2] / 100, v[v.size() * 9 / 10] / 100, v.back() / 100);
 }
 
-template <int EXP, int MIXT = 1, int NGT = 17> static void run(void *const *in, float2 *out, const float2 *taps, const void *tab, size_t n, int ntaps,
+static int g_batch = 1;  // buffers per launch (BATCH=k: the kernel over k of the 12 buffers as one call, hzsdr_chain_run_batch's form)
+
+template <int EXP, int MIXT = 1, int NGT = 17> static void run(void *const *in, float2 *out, const float2 *taps, const void *tab, size_t n_each, int ntaps,
                                    bool shift) {
     constexpr int D = 8;
+    const size_t n = n_each * (size_t)g_batch;
     const unsigned off = (unsigned)((ntaps - 1 + D - 1) / D * D);
     mm2::Geom g = mm2::make_geom(ntaps, D, off, 40);
     EwProgram P{};
@@ -74,9 +77,13 @@ template <int EXP, int MIXT = 1, int NGT = 17> static void run(void *const *in, 
     std::vector<float> all;
     const int reps = getenv("AB") ? 96 : 24;
     for (int r = 0; r < reps + 4; r++) {
+        const void *ins[mm2::kMaxBatch];
+        void *outs[mm2::kMaxBatch];
+        for (int j = 0; j < g_batch; j++) ins[j] = in[getenv("ONEBUF") ? 0 : (r * g_batch + j) % 12], outs[j] = out + (size_t)j * (n_each / D);
+        const mm2::Batch B = g_batch == 1 ? mm2::one_buffer(ins[0], out, n, D) : mm2::make_batch(ins, outs, (size_t)g_batch, n_each, D);
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k, dim3(grid), dim3(mm2::kThreads), lds, 0, (const void *)in[getenv("ONEBUF") ? 0 : r % 12], out, (const float2 *)nullptr,
-                           out + n_out, (const uint8_t *)taps, (uint8_t *)(out + n_out + 4096), taps, n, g, R, P, F, g_stamps);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(mm2::kThreads), lds, 0, ins[0], out, (const float2 *)nullptr,
+                           out + n_out, (const uint8_t *)taps, (uint8_t *)(out + n_out + 4096), taps, n, g, R, P, F, B, g_stamps);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -85,8 +92,8 @@ template <int EXP, int MIXT = 1, int NGT = 17> static void run(void *const *in, 
     }
     CK(hipGetLastError());
     std::sort(all.begin(), all.end());
-    printf("MIX %d EXP %4d%s: grid %u, LDS %zu, ks %d, passes %d: min %.1f us  median %.1f us  avg %.1f us\n", MIXT, EXP, shift ? " +Shift" : "       ", grid, lds,
-           g.ks, R.n_pass, best * 1e3f, all[all.size() / 2] * 1e3f, sum / reps * 1e3f);
+    printf("MIX %d EXP %6d%s: grid %u, LDS %zu, ks %d, passes %d, %d buffer(s) per launch: min %.1f us  median %.1f us  avg %.1f us PER BUFFER\n", MIXT, EXP, shift ? " +Shift" : "       ", grid, lds,
+           g.ks, R.n_pass, g_batch, best * 1e3f / g_batch, all[all.size() / 2] * 1e3f / g_batch, sum / reps * 1e3f / g_batch);
     if (EXP & 64) {
         const size_t nw = (size_t)grid * mm2::kWaves;
         std::vector<unsigned long long> st(nw * 32);
@@ -210,7 +217,9 @@ int main(int argc, char **argv) {
         for (size_t i = 0; i < h.size(); i++) h[i] = (unsigned char)((i + b) * 2654435761u >> 24);
         CK(hipMemcpy(in[b], h.data(), h.size(), hipMemcpyHostToDevice));
     }
-    CK(hipMalloc(&out, (n / 8 + 8192) * 8));
+    if (getenv("BATCH")) g_batch = atoi(getenv("BATCH"));
+    if (g_batch < 1 || g_batch > mm2::kMaxBatch) g_batch = 1;
+    CK(hipMalloc(&out, ((size_t)g_batch * n / 8 + 8192) * 8));
     CK(hipMalloc(&taps, ntaps * 8 + 65536));
     CK(hipMemset(taps, 0, ntaps * 8 + 65536));
     std::vector<unsigned char> t(1 << 20);
@@ -220,14 +229,26 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&g_stamps, 8 * 32 * 8 * 1024));
     CK(hipMemset(g_stamps, 0, 8 * 32 * 8 * 1024));
     printf("fir_mm2_kernel<u8, 8>, 2^24 samples, %d taps; EXP 1 = no input loads, 2 = no matrix loop, 4 = no mixer, 8 = no stores, 32 = wave priorities, 128 = no explicit vmcnt(0)\n", ntaps);
-    if (getenv("AB")) {  // A/B of the build's switches on one box, interleaved: EXP 0, 2048 (accumulator clears), 4 (no mixer)
+    if (getenv("AB")) {  // A/B of the build's switches on one box, interleaved
+        // round 5: the instruction cuts one by one and together (hz_firmm2.h, EXP): 8192 packed mixer, 16384 int32 plane
+        // pair, 32768 sign flip by the LDS, 65536 constant-C first step, 131072 cold path fenced; 4 = no mixer at all
+        constexpr int ALL = 8192 | 16384 | 65536 | 131072 | 262144;  // (kLibExp)
         for (int r = 0; r < 3; r++) {
             run<0, 0>(in, out, taps, tab, n, ntaps, true);
-            run<4096, 0>(in, out, taps, tab, n, ntaps, true);
-            run<4, 0>(in, out, taps, tab, n, ntaps, true);
+            run<131072, 0>(in, out, taps, tab, n, ntaps, true);
+            run<ALL & ~262144, 0>(in, out, taps, tab, n, ntaps, true);
+            run<ALL, 0>(in, out, taps, tab, n, ntaps, true);
+            run<ALL | 4, 0>(in, out, taps, tab, n, ntaps, true);
+            run<ALL | 8, 0>(in, out, taps, tab, n, ntaps, true);
         }
         return 0;
     }
+    if (getenv("BATCH")) {  // the shipped form, k buffers per launch
+        constexpr int ALL = 8192 | 16384 | 65536 | 131072 | 262144;
+        for (int r = 0; r < 3; r++) run<ALL, 0>(in, out, taps, tab, n, ntaps, true);
+        return 0;
+    }
+    run<8192 | 16384 | 65536 | 131072 | 262144, 0>(in, out, taps, tab, n, ntaps, true);  // (what the library ships: kLibExp)
     run<0, 0>(in, out, taps, tab, n, ntaps, true);
     run<128, 0>(in, out, taps, tab, n, ntaps, true);
     run<0, 0>(in, out, taps, tab, n, ntaps, true);
@@ -236,6 +257,6 @@ int main(int argc, char **argv) {
     run<2, 0>(in, out, taps, tab, n, ntaps, true);
     run<8, 0>(in, out, taps, tab, n, ntaps, true);
     run<32, 0>(in, out, taps, tab, n, ntaps, true);
-    run<64, 0>(in, out, taps, tab, n, ntaps, true);
+    run<64 | 8192 | 16384 | 65536 | 131072 | 262144, 0>(in, out, taps, tab, n, ntaps, true);
     return 0;
 }

@@ -84,7 +84,7 @@ static void leg2(const char *name, int launches, void *const *in, float2 *out, c
     for (int r = 0; r < launches; r++) {
         const int b = r % NBUF;
         hipLaunchKernelGGL(k, dim3(R.grid), dim3(mm2::kThreads), lds, 0, (const void *)in[b], out, (const float2 *)nullptr, out + n_out,
-                           (const uint8_t *)taps, (uint8_t *)(out + n_out + 4096), taps, n, g, R, P, F, no_stamps);
+                           (const uint8_t *)taps, (uint8_t *)(out + n_out + 4096), taps, n, g, R, P, F, mm2::one_buffer(in[b], out, n, D), no_stamps);
         if (r < NBUF) CK(hipMemcpyAsync(refo[b], out, (size_t)n_out * 8, hipMemcpyDeviceToDevice, 0));
         else hipLaunchKernelGGL(compare_kernel, dim3(1024), dim3(256), 0, 0, (const uint32_t *)out, (const uint32_t *)refo[b], (size_t)n_out * 2, rec, (unsigned)r);
     }
@@ -233,7 +233,7 @@ int main(int argc, char **argv) {
                 CK(hipEventRecord(e0, 0));
             }
             hipLaunchKernelGGL(k, dim3(R.grid), dim3(mm2::kThreads), lds, 0, (const void *)in[b], out, (const float2 *)nullptr, out + n_out,
-                               (const uint8_t *)taps, (uint8_t *)(out + n_out + 4096), taps, n, g, R, P, F, ctl[b]);
+                               (const uint8_t *)taps, (uint8_t *)(out + n_out + 4096), taps, n, g, R, P, F, mm2::one_buffer(in[b], out, n, D), ctl[b]);
         }
         CK(hipEventRecord(e1, 0));
         CK(hipDeviceSynchronize());
@@ -323,7 +323,7 @@ int main(int argc, char **argv) {
         CK(hipMemset(ctl, 0, ctl_words * 8));
         for (int r = 0; r < launches; r++)
             hipLaunchKernelGGL(k, dim3(R.grid), dim3(mm2::kThreads), lds, 0, (const void *)in[r % NBUF], out, (const float2 *)nullptr, out + n_out,
-                               (const uint8_t *)taps, (uint8_t *)(out + n_out + 4096), taps, n, g, R, P, F, ctl);
+                               (const uint8_t *)taps, (uint8_t *)(out + n_out + 4096), taps, n, g, R, P, F, mm2::one_buffer(in[r % NBUF], out, n, D), ctl);
         CK(hipDeviceSynchronize());
         CK(hipGetLastError());
         std::vector<unsigned long long> c(ctl_words);

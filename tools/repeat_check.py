@@ -26,7 +26,12 @@ for rep in range(R):
         ch.set_time(TAU - 1.2)
         h = n // 2
         for j in range(4):
-            ch.run(dx[j * h:(j + 1) * h], out[j * h // D:(j + 1) * h // D])
+            ch.run_after(dx[j * h:(j + 1) * h], out[j * h // D:(j + 1) * h // D])
+        ctx.synchronize()
+    elif os.environ.get("BATCH"):  # hzsdr_chain_run_batch: the four pieces in one launch
+        ch.set_time(TAU - 1.2)
+        h = n // 2
+        ch.run_batch([dx[j * h:(j + 1) * h] for j in range(4)], [out[j * h // D:(j + 1) * h // D] for j in range(4)])
         ctx.synchronize()
     else:
         ch.run(dx[:n], out[:n // D]); ch.set_time(TAU - 0.4); ch.run(dx[n:], out[n // D:]); ctx.synchronize()
