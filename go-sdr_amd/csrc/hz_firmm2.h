@@ -169,6 +169,13 @@ __device__ __forceinline__ v2f pk_cmul(v2f y, v2f f) {
 // eight register moves on the hot path where the two meet), 262144 = a u8 pass image's sign flip among the wave's OWN
 // MFMAs, near the matrix loop's end (straight-line form).  Measured one by one and together, tools/mfma_fir2.hip AB=1:
 // 32768 is 0.8 us SLOWER (LDS atomics), 131072 alone -1.0 us, the rest -0.3 together.
+// 524288 = a pass's stores among the MFMAs of the wave's NEXT matrix loop (a global store does not issue beside a
+// partner that streams MFMAs, tools/epi_cost.hip: it waits for the partner's loop to end) -- and yet 1 us per buffer
+// SLOWER in a call over four buffers, even single: not shipped.  1 << 22 = the mixer's products as SCALAR float32
+// instructions: a packed float32 instruction does not issue beside a streaming partner either (the mixer beside a
+// partner's loop: 5.6 us packed, 1.2 us scalar -- tools/mfma_fir2.hip BISECT=1, LDS-staged stamps), which pinned the
+// epilogue to the partner's loop in every round so far; -0.6 ... -1.4 us per buffer in a call over four.  (1 << 20,
+// 1 << 21: the bisection's other switches -- no Sincos, no step factors from LDS; neither matters.)
 // NG: the window's groups (ks / GS) when the instantiation is for ONE tap count -- the matrix loop is then
 // straight-line code (a loop header drains the operand pipeline: the compiler cannot count outstanding
 // loads across a back edge); 0: any window, a loop over the groups.
@@ -210,11 +217,20 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     auto vout_of = [&](int j) -> uint64_t { return j == 0 ? (uint64_t)(uintptr_t)out : B.vout[j]; };
     typedef const v4i __attribute__((address_space(1))) *gload_p;
     // (EXP & 64: s_memrealtime stamps, 10 ns ticks: slot 0 of a wave = its start and end, slots 1 .. 3 its passes)
+    // The stamps are kept in LDS (2 KB behind the kernel's own: the harness asks for them) and written out when the wave
+    // ends: a global store does not issue while the SIMD partner's MFMAs are back to back (tools/epi_cost.hip), so a
+    // stamp stored at once pinned the very phases it was to time to the partner's loop (rounds 3-4 read "the epilogue
+    // takes as long as the partner's loop" off such stamps).
     int stamp_pass = 0;
+    [[maybe_unused]] unsigned long long *const lstamp =
+        reinterpret_cast<unsigned long long *>(mm_lds + lds_bytes(D, G.ks, G.ne, G.ntaps)) + (size_t)wave * 32;
+    if constexpr ((EXP & 64) != 0) {
+        if (l < 32) lstamp[l] = 0;
+    }
     auto stamp = [&](int k) {
         if constexpr ((EXP & 64) != 0) {
             if (l == 0 && stamp_pass < 4)
-                stamps[(((size_t)wb * kWaves + wave) * 4 + (k == 0 || k == 7 || (k >= 8 && k < 16) ? 0 : stamp_pass)) * 8 + (k & 7)] = __builtin_amdgcn_s_memrealtime();
+                lstamp[(k == 0 || k == 7 || (k >= 8 && k < 16) ? 0 : stamp_pass) * 8 + (k & 7)] = __builtin_amdgcn_s_memrealtime();
         }
     };
     stamp(0);
@@ -551,7 +567,13 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
 #pragma unroll
                 for (int b = 0; b < NB; b++)
 #pragma unroll
-                    for (int q = 0; q < 4; q++) y[b][q] = make_float2(__fmul_rn(y[b][q].x, o.a), __fmul_rn(y[b][q].y, o.a));
+                    for (int q = 0; q < 4; q++) {
+                        // (scalar products, kept from being paired: a packed float32 instruction waits for the SIMD
+                        // partner's matrix loop -- EXP's 1 << 22)
+                        float gx = __fmul_rn(y[b][q].x, o.a), gy = __fmul_rn(y[b][q].y, o.a);
+                        asm volatile("" : "+v"(gx), "+v"(gy));
+                        y[b][q] = make_float2(gx, gy);
+                    }
             } else if (o.kind == EW_ROTATE) {
 #pragma unroll
                 for (int b = 0; b < NB; b++)
@@ -596,7 +618,10 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                 // instruction here runs beside the SIMD partner's matrix loop and costs both waves).
                 const uint64_t ph0 = phi_r + (uint64_t)D * mb * dphi;
                 float s0, c0;
-                sincos_turns32((uint32_t)(ph0 >> 32), s0, c0);
+                // (tools/mfma_fir2.hip BISECT: 1 << 20 = no Sincos, 1 << 21 = the step factors not read from LDS,
+                // 1 << 22 = the products in scalar float32 instead of packed)
+                if constexpr ((EXP & (1 << 20)) != 0) s0 = __uint_as_float((uint32_t)(ph0 >> 40)), c0 = 1.0f;
+                else sincos_turns32((uint32_t)(ph0 >> 32), s0, c0);
                 [[maybe_unused]] float4 wpin[4 * NB];
                 [[maybe_unused]] float4 chk_w = make_float4(0.f, 0.f, 0.f, 0.f);
                 [[maybe_unused]] float chk_cs = 0.f, chk_sn = 0.f;
@@ -616,11 +641,23 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                             v2f f = cs0;
                             if (b + q > 0) {
                                 typedef float v4f_ __attribute__((ext_vector_type(4)));
-                                const v4f_ w = *reinterpret_cast<const v4f_ *>(wtab + 4 * b + q);  // (cos hi, sin hi, cos lo, sin lo)
+                                v4f_ w;
+                                if constexpr ((EXP & (1 << 21)) != 0) w = v4f_{c0, s0, 1e-8f * (float)(4 * b + q), 1e-9f};
+                                else w = *reinterpret_cast<const v4f_ *>(wtab + 4 * b + q);  // (cos hi, sin hi, cos lo, sin lo)
+                                if constexpr ((EXP & (1 << 22)) != 0) {
+                                    f.x = __fmaf_rn(c0, w.x, __fmaf_rn(-s0, w.y, __fmaf_rn(c0, w.z, -(s0 * w.w))));
+                                    f.y = __fmaf_rn(c0, w.y, __fmaf_rn(s0, w.x, __fmaf_rn(c0, w.w, s0 * w.z)));
+                                } else
                                 f = pk_turn(cs0, w.xy, w.zw);
                             }
+                            if constexpr ((EXP & (1 << 22)) != 0) {
+                                float rx = __fmaf_rn(y[b][q].x, f.x, -(y[b][q].y * f.y)), ry = __fmaf_rn(y[b][q].x, f.y, y[b][q].y * f.x);
+                                asm volatile("" : "+v"(rx), "+v"(ry));  // (kept scalar: no re-vectorisation)
+                                y[b][q] = make_float2(rx, ry);
+                            } else {
                             const v2f r = pk_cmul(v2f{y[b][q].x, y[b][q].y}, f);
                             y[b][q] = make_float2(r.x, r.y);
+                            }
                         }
                 } else
 #pragma unroll
@@ -689,6 +726,28 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     // group and the run B behind it are ONE queue (A's passes, B's passes); the next group slides on by one run (B
     // becomes A, its table stays) behind a barrier.
     auto has_passes = [&](int rr) { return rr < L.n && max(pb0, (uint32_t)L.pass_first[rr]) < min(pb1, (uint32_t)L.pass_end[rr]); };
+    // EXP & 524288 (straight-line form): a pass's STORES wait for the wave's next matrix loop.  Measured
+    // (tools/epi_cost.hip): beside a SIMD partner that issues MFMAs back to back a wave's vector instructions, LDS
+    // reads and writes and global loads go through as if the partner were idle -- but a global STORE does not issue
+    // until the partner's stream of MFMAs pauses (its data leaves the register file by a path the MFMAs' operand reads
+    // hold).  An epilogue that ends in stores therefore ends when the partner's loop ends, whatever its length, and the
+    // wave reaches its next loop -- queue, prefetch, first operands -- only then: a bubble of ~1 us in the matrix pipe
+    // at every change of waves.  Issued among the wave's OWN MFMAs (the partner is in its epilogue by then) the stores
+    // cost a few cycles each.  The last pass of a wave stores behind its loop as before.
+    constexpr bool kDefer = STRAIGHT && (EXP & 524288) != 0;
+    [[maybe_unused]] float2 yd[NB][4];
+    [[maybe_unused]] uint64_t out_d = 0;
+    [[maybe_unused]] uint32_t mb_d = 0, lo_d = 0, hi_d = 0;
+    [[maybe_unused]] bool have_d = false;  // uniform
+    auto flush_deferred = [&]() {
+        if constexpr (kDefer) {
+            if (have_d) {
+#pragma unroll
+                for (int b = 0; b < NB; b++) store_block(out_d, yd[b], mb_d + (uint32_t)(32 * kT) * b, lo_d, hi_d);
+                have_d = false;
+            }
+        }
+    };
     int ra = 0;
     while (ra < L.n && !has_passes(ra)) ra++;
     Run ru = run0, rv = run0;
@@ -814,6 +873,9 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
 #pragma unroll
                     for (int b = 0; b < NB; b++) asm volatile("" : "+v"(acc[f][b]));
             }
+            if constexpr (kDefer) {
+                if (!(active && (EXP & 2) == 0)) flush_deferred();
+            }
             if (active && (EXP & 2) == 0) {
                 // step s = GS g + j of the window: the A entries 2 s below the lane's first, B piece 2 j + h of
                 // tile n + g -- constants off two per-lane addresses (NG > 0) or off two running ones
@@ -860,6 +922,14 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                             else
                                 acc[f][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[sx % RG][f], b[sx % RG][q], acc[f][q], 0, 0, 0);
                         }
+                    // (EXP & 524288: the PREVIOUS pass's stores, one column block each in two early steps)
+                    if constexpr (kDefer && SC >= 0) {
+                        if constexpr (SC >= 3 && (SC - 3) % 4 == 0 && (SC - 3) / 4 < NB) {
+                            constexpr int bq = (SC - 3) / 4;
+                            if (have_d) store_block(out_d, yd[bq], mb_d + (uint32_t)(32 * kT) * bq, lo_d, hi_d);
+                        }
+                        if constexpr (SC == 3 + 4 * (NB - 1)) have_d = false;
+                    }
                     // (EXP & 262144, u8 sources: the NEXT pass's bytes -- in flight since the loop's first lines, here long
                     // since -- get their sign flip in the shadow of this wave's own MFMAs, where a vector instruction
                     // costs 2-3 cycles; left to the landing they are 40 instructions of the epilogue, which runs
@@ -977,6 +1047,12 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                 const double *dc = reinterpret_cast<const double *>(tabp + tab_off + (size_t)G.ne * 128);
                 float2 y[NB][4];
                 planes(acc, y, dc[0] * k3, dc[1] * k3);
+                if constexpr ((EXP & 64) != 0) {  // (the stamp behind the combination, not in the middle of it)
+#pragma unroll
+                    for (int b = 0; b < NB; b++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) asm volatile("" : "+v"(y[b][q].x), "+v"(y[b][q].y));
+                }
                 stamp(4);
                 const uint32_t mb = m_start + (uint32_t)n * kT + 4 * h;
                 {
@@ -984,8 +1060,19 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                     program(y, mb, phi_r, dphi, sel ? rv.seg : ru.seg, reinterpret_cast<const float4 *>(dc + 2));
                     stamp(5);
                     const uint64_t outp = vout_of(buf_of(pass_of(cur)));
+                    if constexpr (kDefer) {
+                        // (kept for the wave's next matrix loop; a wave without one -- no next pass in this group --
+                        // stores now)
 #pragma unroll
-                    for (int b = 0; b < NB; b++) store_block(outp, y[b], mb + (uint32_t)(32 * kT) * b, v_lo, v_hi);
+                        for (int b = 0; b < NB; b++)
+#pragma unroll
+                            for (int q = 0; q < 4; q++) yd[b][q] = y[b][q];
+                        out_d = outp, mb_d = mb, lo_d = v_lo, hi_d = v_hi, have_d = true;
+                        if (!has_next) flush_deferred();
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < NB; b++) store_block(outp, y[b], mb + (uint32_t)(32 * kT) * b, v_lo, v_hi);
+                    }
                 }
             }
             stamp(6);
@@ -1020,6 +1107,9 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
         tasks_back();
     }
     stamp(7);
+    if constexpr ((EXP & 64) != 0) {
+        if (l < 32) stamps[((size_t)wb * kWaves + wave) * 32 + l] = lstamp[l];
+    }
 }
 
 // hz_firmm2.hip

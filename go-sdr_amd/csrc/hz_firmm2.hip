@@ -16,7 +16,7 @@ static int launch(K kernel, dim3 grid, size_t lds, hipStream_t stream, A... args
 }
 
 // What the library ships of the kernel's switches (hz_firmm2.h, EXP): round 5's instruction cuts.
-constexpr int kLibExp = 8192 | 16384 | 65536 | 131072 | 262144;
+constexpr int kLibExp = 8192 | 16384 | 65536 | 131072 | 262144 | (1 << 22);
 
 template <int FMT>
 static int launch_fmt(hipStream_t stream, int num_cus, unsigned D, const void *in, float2 *out, const float2 *hist,

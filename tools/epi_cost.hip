@@ -19,10 +19,10 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-enum Kind { K_FMA32, K_PKFMA32, K_FMA64, K_CVT_F64_I32, K_CVT_F32_F64, K_INT, K_DSREAD, K_MAD64, K_STORE, K_FMA64_CHAIN, K_PKFMA32_CHAIN, K_NKINDS };
+enum Kind { K_FMA32, K_PKFMA32, K_FMA64, K_CVT_F64_I32, K_CVT_F32_F64, K_INT, K_DSREAD, K_MAD64, K_STORE, K_FMA64_CHAIN, K_PKFMA32_CHAIN, K_DSWRITE, K_GLOAD, K_STORE1, K_NKINDS };
 static const char *kKindName[K_NKINDS] = {"v_fma_f32", "v_pk_fma_f32", "v_fma_f64", "v_cvt_f64_i32", "v_cvt_f32_f64", "v_lshl_add_u32",
                                           "ds_read_b128 (waited for in fours)", "v_mad_u64_u32", "global_store_dwordx4 nt", "v_fma_f64, dependent chain",
-                                          "v_pk_fma_f32, dependent chain"};
+                                          "v_pk_fma_f32, dependent chain", "ds_write_b128", "global_load_dwordx4 nt (waited for in fours)", "global_store_dword"};
 
 // A: 0 idle, 1 MFMAs back to back, 2 MFMAs + six ds_read_b128 per four (the kernel's loop)
 // PRIO: s_setprio of wave B (0: as launched, like A); A's loop as straight-line code of 64 MFMAs per trip (no branch
@@ -85,6 +85,9 @@ __global__ __launch_bounds__(512) void epi(int a_trips, int b_reps, float *fsink
         const unsigned char *bp = lds + 16 * l;
         unsigned long long m64 = (unsigned long long)seed * 0x9E3779B97F4A7C15ull + l;
         v4f *gp = reinterpret_cast<v4f *>(gout) + (size_t)blockIdx.x * 512 + threadIdx.x;
+        // (B's own stamps, in line: its set-up and the sums behind the loop are compiler-made instructions beside A too)
+        uint64_t tb0, tb1;
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tb0));
 #pragma unroll 1
         for (int r = 0; r < b_reps; r++) {
 #pragma unroll
@@ -104,11 +107,27 @@ __global__ __launch_bounds__(512) void epi(int a_trips, int b_reps, float *fsink
                     n[q & 15] ^= t[0];
                     if ((q & 3) == 3) asm volatile("s_waitcnt lgkmcnt(0)");
                 }
+                if constexpr (KIND == K_DSWRITE) {
+                    v4i t{n[q & 15], n[(q + 1) & 15], n[(q + 2) & 15], n[(q + 3) & 15]};
+                    *reinterpret_cast<v4i *>(const_cast<unsigned char *>(bp) + (q & 31) * 1024) = t;
+                    asm volatile("" ::: "memory");
+                }
+                if constexpr (KIND == K_GLOAD) {
+                    v4i t = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(gp) + (size_t)((r * 32 + q) & 63) * 131072);
+                    asm volatile("" : "+v"(t));
+                    n[q & 15] ^= t[0];
+                    if ((q & 3) == 3) asm volatile("s_waitcnt vmcnt(0)");
+                }
+                if constexpr (KIND == K_STORE1) {
+                    if ((q & 7) == 0) __builtin_nontemporal_store(f[q & 15], reinterpret_cast<float *>(gp + (size_t)((r * 4 + (q >> 3)) & 63) * 131072));
+                }
                 if constexpr (KIND == K_STORE) {
                     if ((q & 7) == 0) __builtin_nontemporal_store(v4f{f[q & 15], f[(q + 1) & 15], f[2], f[3]}, gp + (size_t)((r * 4 + (q >> 3)) & 63) * 131072);
                 }
             }
         }
+        asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tb1));
+        if (l == 0) cyc[2048 + blockIdx.x * 8 + wave] = tb1 - tb0, cyc[4096 + blockIdx.x * 8 + wave] = tb0 - t0;
         float fs = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; q++) fs += f[q] + (float)n[q];
@@ -125,12 +144,16 @@ template <int KIND, int AMODE, int PRIO = 0> static void run(int a_trips, int b_
     CK(hipFuncSetAttribute((const void *)epi<KIND, AMODE, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     for (int r = 0; r < 2; r++) hipLaunchKernelGGL((epi<KIND, AMODE, PRIO>), dim3(256), dim3(512), 65536, 0, a_trips, b_reps, fsink, sink, cyc, gout, 777 + r);
     CK(hipDeviceSynchronize());
-    unsigned long long c[8];
+    unsigned long long c[8], cb[8], cs[8];
     CK(hipMemcpy(c, cyc + 8 * 100, sizeof c, hipMemcpyDeviceToHost));
-    const double per = (double)c[4] / ((double)b_reps * (KIND == K_STORE ? 4 : 32));
+    CK(hipMemcpy(cb, cyc + 2048 + 8 * 100, sizeof cb, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(cs, cyc + 4096 + 8 * 100, sizeof cs, hipMemcpyDeviceToHost));
+    c[4] = cb[4];  // (the loop alone)
+    const double per = (double)c[4] / ((double)b_reps * (KIND == K_STORE || KIND == K_STORE1 ? 4 : 32));
     printf("  %-36s beside %-34s%s: B %7.2f ticks per instruction (%9.0f in all), A %7.1f ticks per 4 MFMAs\n", kKindName[KIND],
            AMODE == 0 ? "an idle partner" : AMODE == 1 ? "MFMAs back to back" : AMODE == 2 ? "MFMAs + 6 ds_read_b128 per four" : "64 MFMAs per trip, straight-line",
            PRIO ? ", B at s_setprio 3" : "", per, (double)c[4], AMODE ? (double)c[0] / a_trips : 0.0);
+    printf("      (B's set-up in front of its loop: %.0f ticks)\n", (double)cs[4]);
 }
 
 template <int KIND> static void kind(float *fsink, int *sink, unsigned long long *cyc, float *gout) {
@@ -150,7 +173,7 @@ int main() {
     unsigned long long *cyc;
     CK(hipMalloc(&fsink, 4));
     CK(hipMalloc(&sink, 4));
-    CK(hipMalloc(&cyc, 8 * 8 * 256));
+    CK(hipMalloc(&cyc, 8 * 8192));
     CK(hipMalloc(&gout, (size_t)64 * 131072 * 16 + (size_t)256 * 512 * 16));
     printf("ticks: s_memtime (shader clock; an MFMA 32x32x32 i8 is 32) -- an instruction of wave B (second wave of the SIMD) by kind, beside wave A\n");
     kind<K_FMA32>(fsink, sink, cyc, gout);
@@ -164,5 +187,8 @@ int main() {
     kind<K_MAD64>(fsink, sink, cyc, gout);
     kind<K_DSREAD>(fsink, sink, cyc, gout);
     kind<K_STORE>(fsink, sink, cyc, gout);
+    kind<K_STORE1>(fsink, sink, cyc, gout);
+    kind<K_DSWRITE>(fsink, sink, cyc, gout);
+    kind<K_GLOAD>(fsink, sink, cyc, gout);
     return 0;
 }

@@ -66,7 +66,7 @@ template <int EXP, int MIXT = 1, int NGT = 17> static void run(void *const *in, 
         F.m_b[0] = 4096 + mm2::kFixOut * F.n_task;
         R.n_task = F.n_task;
     }
-    const size_t lds = mm2::lds_bytes(D, g.ks, g.ne, g.ntaps);
+    const size_t lds = mm2::lds_bytes(D, g.ks, g.ne, g.ntaps) + ((EXP & 64) ? 2048 : 0);  // (+ the stamps' staging area)
     const unsigned grid = (unsigned)g_grid;
     auto k = mm2::fir_mm2_kernel<HZSDR_FMT_U8, D, NGT, EXP>;
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -232,23 +232,29 @@ int main(int argc, char **argv) {
     if (getenv("AB")) {  // A/B of the build's switches on one box, interleaved
         // round 5: the instruction cuts one by one and together (hz_firmm2.h, EXP): 8192 packed mixer, 16384 int32 plane
         // pair, 32768 sign flip by the LDS, 65536 constant-C first step, 131072 cold path fenced; 4 = no mixer at all
-        constexpr int ALL = 8192 | 16384 | 65536 | 131072 | 262144;  // (kLibExp)
+        constexpr int ALL = 8192 | 16384 | 65536 | 131072 | 262144 | 524288;  // (kLibExp)
         for (int r = 0; r < 3; r++) {
             run<0, 0>(in, out, taps, tab, n, ntaps, true);
-            run<131072, 0>(in, out, taps, tab, n, ntaps, true);
-            run<ALL & ~262144, 0>(in, out, taps, tab, n, ntaps, true);
+            run<ALL & ~524288, 0>(in, out, taps, tab, n, ntaps, true);
             run<ALL, 0>(in, out, taps, tab, n, ntaps, true);
+            run<524288 | 131072, 0>(in, out, taps, tab, n, ntaps, true);
             run<ALL | 4, 0>(in, out, taps, tab, n, ntaps, true);
             run<ALL | 8, 0>(in, out, taps, tab, n, ntaps, true);
         }
         return 0;
     }
     if (getenv("BATCH")) {  // the shipped form, k buffers per launch
-        constexpr int ALL = 8192 | 16384 | 65536 | 131072 | 262144;
-        for (int r = 0; r < 3; r++) run<ALL, 0>(in, out, taps, tab, n, ntaps, true);
+        constexpr int ALL = 8192 | 16384 | 65536 | 131072 | 262144 | 524288;
+        for (int r = 0; r < 3; r++) {
+            run<ALL, 0>(in, out, taps, tab, n, ntaps, true);
+            run<ALL | (1 << 22), 0>(in, out, taps, tab, n, ntaps, true);                // the mixer's products in scalar float32
+            run<(ALL | (1 << 22)) & ~524288, 0>(in, out, taps, tab, n, ntaps, true);   // ... and the stores in the epilogue
+            run<ALL | 4, 0>(in, out, taps, tab, n, ntaps, true);                        // no mixer at all
+            run<0, 0>(in, out, taps, tab, n, ntaps, true);                              // round 4's kernel
+        }
         return 0;
     }
-    run<8192 | 16384 | 65536 | 131072 | 262144, 0>(in, out, taps, tab, n, ntaps, true);  // (what the library ships: kLibExp)
+    run<8192 | 16384 | 65536 | 131072 | 262144 | 524288, 0>(in, out, taps, tab, n, ntaps, true);  // (what the library ships: kLibExp)
     run<0, 0>(in, out, taps, tab, n, ntaps, true);
     run<128, 0>(in, out, taps, tab, n, ntaps, true);
     run<0, 0>(in, out, taps, tab, n, ntaps, true);
@@ -257,6 +263,16 @@ int main(int argc, char **argv) {
     run<2, 0>(in, out, taps, tab, n, ntaps, true);
     run<8, 0>(in, out, taps, tab, n, ntaps, true);
     run<32, 0>(in, out, taps, tab, n, ntaps, true);
-    run<64 | 8192 | 16384 | 65536 | 131072 | 262144, 0>(in, out, taps, tab, n, ntaps, true);
+    run<64 | 8192 | 16384 | 65536 | 131072 | 262144 | 524288, 0>(in, out, taps, tab, n, ntaps, true);
+    if (getenv("BISECT")) {  // which part of the epilogue waits for the partner's loop: without the mixer, without the stores
+        run<64 | 4 | 8192 | 16384 | 65536 | 131072 | 262144 | 524288, 0>(in, out, taps, tab, n, ntaps, true);
+        run<64 | 8 | 8192 | 16384 | 65536 | 131072 | 262144 | 524288, 0>(in, out, taps, tab, n, ntaps, true);
+        run<64 | 4 | 8 | 8192 | 16384 | 65536 | 131072 | 262144 | 524288, 0>(in, out, taps, tab, n, ntaps, true);
+        constexpr int ALLB = 64 | 8192 | 16384 | 65536 | 131072 | 262144 | 524288;
+        run<ALLB | (1 << 20), 0>(in, out, taps, tab, n, ntaps, true);
+        run<ALLB | (1 << 21), 0>(in, out, taps, tab, n, ntaps, true);
+        run<ALLB | (1 << 22), 0>(in, out, taps, tab, n, ntaps, true);
+        run<ALLB | (1 << 20) | (1 << 21), 0>(in, out, taps, tab, n, ntaps, true);
+    }
     return 0;
 }
