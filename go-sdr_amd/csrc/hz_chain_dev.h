@@ -1092,65 +1092,10 @@ __global__ __launch_bounds__(fv::block(N), fir_occupancy(N, FOLD, LATE)) void fi
     }
 }
 
-// BASELINE config 3 as a FIR -- c64 in, no elementwise stage, D = 1 -- over the blocks [b_lo, b_hi) that lie wholly
-// inside the buffer (the stream's first and last blocks stay with fir_decimate_kernel16): a workgroup WALKS `chunk`
-// consecutive blocks.  Consecutive blocks share their N - hop = off samples: with the first pass's register image
-// (element lane + q TPT in slot q) those are the last off / TPT slots of one block and the first of the next, so a
-// block costs hop / TPT loads per lane instead of 16 (read amplification 1.0 instead of N / hop), and they are in
-// flight while the block before is transformed (a block per workgroup waited for its own loads: with three workgroups
-// per CU nothing else covered them once the bytes come from HBM and not from the memory-side cache).  Same
-// transforms, same filter spectrum, same outputs as the late block of fir_decimate_kernel16 with P.n == 0.
-template <int N>
-__global__ __launch_bounds__(fv::block(N), 3) void fir_walk_kernel16(const float2 *__restrict__ in, float2 *__restrict__ out,
-                                                                       const float2 *__restrict__ hf, FvTabs tabs, size_t b_lo, size_t b_hi,
-                                                                       unsigned chunk, unsigned hop, unsigned off) {
-    constexpr int R0 = fv::first_radix(N), TPT = fv::tpt(N);
-    static_assert(fv::xpb(N) == 1 && R0 == 16, "one block per workgroup, radix-16 first pass: slot q holds element lane + q TPT");
-    const int kq = (int)(off / TPT);  // slots two consecutive blocks share (host: off == N - hop, off % TPT == 0)
-    cf *lds = fv_lds();
-    const size_t c0 = b_lo + (size_t)blockIdx.x * chunk, c1 = c0 + chunk < b_hi ? c0 + chunk : b_hi;
-    if (c0 >= c1) return;
-    float2 raw[16];
-    {
-        const float2 *src = in + (c0 * hop - off) + threadIdx.x;
-#pragma unroll
-        for (int q = 0; q < 16; q++) raw[q] = src[q * TPT];
-    }
-#pragma unroll 1
-    for (size_t b = c0; b < c1; b++) {
-        int lane = threadIdx.x;
-        asm volatile("" : "+v"(lane));  // (see conv_blocks_kernel16: keeps the trip's addresses out of the loop's preheader)
-        cf v[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) v[q] = fv::from2(raw[q]);
-        if (b + 1 < c1) {  // (uniform) the next block: its first kq slots are this block's last, the rest is new
-            const float2 *src = in + ((b + 1) * hop - off) + lane;
-            if (kq == 4) {  // (uniform; the BASELINE geometry, with register-to-register moves the compiler can name)
-#pragma unroll
-                for (int q = 0; q < 4; q++) raw[q] = raw[q + 12];
-#pragma unroll
-                for (int q = 4; q < 16; q++) raw[q] = src[q * TPT];
-            } else {
-#pragma unroll
-                for (int q = 0; q < 16; q++) raw[q] = src[q * TPT];
-            }
-        }
-        if (b != c0) __syncthreads();  // the block before may still be read from the LDS by a slower wave
-        fv::forward<N>(v, lds, tabs.fwd, lane);
-        {
-            const cf *hl = (const cf *)hf + lane;
-#pragma unroll
-            for (int q = 0; q < 16; q++) v[q] = fv::cmul(v[q], hl[fv::edge_off<N, 16>(q)]);
-        }
-        fv::backward<N>(v, lds, tabs.bwd, lane);
-        float2 *ob = out + b * hop + lane;
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const unsigned idx = (unsigned)(q * TPT) + (unsigned)lane;
-            if (idx >= off && idx < off + hop) ob[(size_t)(q * TPT) - off] = fv::to2(v[q]);
-        }
-    }
-}
+// (Round 4 measured a workgroup that WALKS consecutive blocks of BASELINE config 3 as a FIR -- c64 in, D = 1, the
+// quarter two neighbours share passed on in registers, the next block's samples in flight under the transforms:
+// 73.3 us against 75-78, the input is not what the kernel waits for.  The kernel, fir_walk_kernel16, was never
+// launched by the library and is gone from this header; DESIGN.md section 8 keeps the measurement.)
 
 // The other half of the folded FIR-decimate: the M-point inverse of every block's folded
 // spectrum -- M/16 lanes per block, 256 / (M/16) blocks per workgroup, every lane busy --

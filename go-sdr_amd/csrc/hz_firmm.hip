@@ -1,6 +1,12 @@
 // hz_firmm.hip -- the instantiations of the int8 matrix FIR kernel (hz_firmm.h) and their launcher,
 // in a translation unit of their own (they compile in parallel with hz_chain_fir.hip, which plans the
 // launch: mm_plan / mm_table_for).
+// make NO_PK_F32=1 (csrc/Makefile), in front of every definition: no packed float32 instruction in this unit's device code -- the gfx950 hazard of
+// hz_firmm.h cannot occur and the link-time rewrite (tools/fix_pk_opsel.py) is not needed for it
+#if defined(HZSDR_NO_PK_F32) && defined(__HIP_DEVICE_COMPILE__)
+#pragma clang attribute push(__attribute__((target("no-packed-fp32-ops"))), apply_to = function)
+#endif
+
 #include <algorithm>
 
 #include "hz_firmm.h"
@@ -52,3 +58,7 @@ int launch_fir(hipStream_t stream, int fmt, unsigned D, const void *in, float2 *
 
 }  // namespace mm
 }  // namespace hz
+
+#if defined(HZSDR_NO_PK_F32) && defined(__HIP_DEVICE_COMPILE__)
+#pragma clang attribute pop
+#endif

@@ -1,4 +1,10 @@
 // hz_firmm2.hip -- the instantiations of the persistent-pass int8 matrix FIR (hz_firmm2.h) and their launcher.
+// make NO_PK_F32=1 (csrc/Makefile), in front of every definition: no packed float32 instruction in this unit's device code -- the gfx950 hazard of
+// hz_firmm.h cannot occur and the link-time rewrite (tools/fix_pk_opsel.py) is not needed for it
+#if defined(HZSDR_NO_PK_F32) && defined(__HIP_DEVICE_COMPILE__)
+#pragma clang attribute push(__attribute__((target("no-packed-fp32-ops"))), apply_to = function)
+#endif
+
 #include <stdlib.h>
 
 #include <algorithm>
@@ -79,3 +85,7 @@ int launch_history(hipStream_t stream, int fmt, const void *in, float2 *new_hist
 
 }  // namespace mm2
 }  // namespace hz
+
+#if defined(HZSDR_NO_PK_F32) && defined(__HIP_DEVICE_COMPILE__)
+#pragma clang attribute pop
+#endif
