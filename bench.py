@@ -484,7 +484,13 @@ def main():
 
         # the same-run device copy (8 B read + 8 B written per sample): the practical HBM
         # ceiling the HBM-bound rows below are also quoted against
-        both("device_copy_c64", lambda i: outs[i % kRot].copy_(cs[i % kRot]), 16)
+        # (the library's own CopySamples -- hzsdr_convert with equal formats: non-temporal, two vectors per lane --
+        # since round 5; torch's copy_, the yardstick of rounds 1-4, beside it)
+        both("device_copy_c64", lambda i: ctx.convert(outs[i % kRot], cs[i % kRot]), 16)
+        both("torch_copy_c64", lambda i: outs[i % kRot].copy_(cs[i % kRot]), 16)
+        # Scale and Rotate in place (internal/simd/mult.go:25-45): 16 B/sample
+        both("scale_c64", lambda i: ctx.scale(cs[i % kRot], 0.999), 16)
+        both("rotate_c64", lambda i: ctx.rotate(cs[i % kRot], complex(0.6, 0.8)), 16)
         copy_gbps = extra["device_copy_c64"]["GBps"]
         copy_hbm_gbps = extra["device_copy_c64"]["hbm"]["GBps"]
         # cfg 1 kernel: u8 -> c64 (10 B/sample)

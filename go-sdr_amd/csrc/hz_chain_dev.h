@@ -45,9 +45,9 @@ __device__ __forceinline__ float2 ew_apply(const EwProgram &P, float2 v, uint64_
                 have_ts = true;
             }
             double ph = __dmul_rn(o.tau_shift, ts);  // stream/shifter.go:81
-            double s, c;
-            go_sincos(ph, s, c);
-            v = go_cmul(v, make_float2((float)c, (float)s));  // :82
+            float s, c;
+            go_sincos32(ph, s, c);  // (complex64(math.Sincos): hz_device.h)
+            v = go_cmul(v, make_float2(c, s));  // :82
         }
     }
     return v;
@@ -82,18 +82,21 @@ __device__ __forceinline__ void ew_apply_n(const EwProgram &P, float2 (&v)[W], u
                 for (int l = 0; l < W; l++) ts[l] = nco_ts(P.segs, w, j0 + l * stride);
                 have_ts = true;
             }
-            double s[W], c[W];
+            float s[W], c[W];
 #pragma unroll
             for (int l = 0; l < W; l++) {
                 if constexpr (LATE == 2) {
-                    float sf, cf;
-                    sincos_turns32(turns32(__dmul_rn(o.tau_shift, ts[l])), sf, cf);
-                    s[l] = sf, c[l] = cf;
-                } else if constexpr (LATE == 1) sincos_late(__dmul_rn(o.tau_shift, ts[l]), s[l], c[l]);
-                else go_sincos(__dmul_rn(o.tau_shift, ts[l]), s[l], c[l]);
+                    sincos_turns32(turns32(__dmul_rn(o.tau_shift, ts[l])), s[l], c[l]);
+                } else if constexpr (LATE == 1) {
+                    double sd, cd;
+                    sincos_late(__dmul_rn(o.tau_shift, ts[l]), sd, cd);
+                    s[l] = (float)sd, c[l] = (float)cd;
+                } else {
+                    go_sincos32(__dmul_rn(o.tau_shift, ts[l]), s[l], c[l]);  // (reference order: bit for bit, hz_device.h)
+                }
             }
 #pragma unroll
-            for (int l = 0; l < W; l++) v[l] = go_cmul(v[l], make_float2((float)c[l], (float)s[l]));
+            for (int l = 0; l < W; l++) v[l] = go_cmul(v[l], make_float2(c[l], s[l]));
         }
     }
 }
@@ -192,12 +195,12 @@ __device__ __forceinline__ void ew_apply_shape(const EwProgram &P, float2 (&v)[W
                 v[l] = make_float2(__fmul_rn(v[l].x, P.op[1].a), __fmul_rn(v[l].y, P.op[1].a));
         }
     } else {
-        double s[W], c[W];
+        float s[W], c[W];
 #pragma unroll
-        for (int l = 0; l < W; l++) go_sincos(__dmul_rn(P.op[0].tau_shift, nco_ts(P.segs, w, j0 + l)), s[l], c[l]);
+        for (int l = 0; l < W; l++) go_sincos32(__dmul_rn(P.op[0].tau_shift, nco_ts(P.segs, w, j0 + l)), s[l], c[l]);
 #pragma unroll
         for (int l = 0; l < W; l++) {
-            v[l] = go_cmul(v[l], make_float2((float)c[l], (float)s[l]));
+            v[l] = go_cmul(v[l], make_float2(c[l], s[l]));
             if constexpr (SHAPE == SHAPE_SHIFT_GAIN)
                 v[l] = make_float2(__fmul_rn(v[l].x, P.op[1].a), __fmul_rn(v[l].y, P.op[1].a));
         }

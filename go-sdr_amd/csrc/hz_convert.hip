@@ -84,7 +84,7 @@ template <int C> struct ConvGeom {
     static constexpr int K = 16 / wide;
 };
 
-template <int C, int SW>
+template <int C, int SW, bool NT = false>
 __global__ __launch_bounds__(kThreads) void convert_vec_kernel(
     const typename ConvTraits<C>::src_t *__restrict__ src,
     typename ConvTraits<C>::dst_t *__restrict__ dst, size_t nvec, int arg) {
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kThreads) void convert_vec_kernel(
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     // 4 independent vectors in flight per lane
     for (; i + 3 * stride < nvec; i += 4 * stride) {
-        SV a0 = s[i], a1 = s[i + stride], a2 = s[i + 2 * stride], a3 = s[i + 3 * stride];
+        SV a0 = ld_stream<NT>(s + i), a1 = ld_stream<NT>(s + i + stride), a2 = ld_stream<NT>(s + i + 2 * stride), a3 = ld_stream<NT>(s + i + 3 * stride);
         DV r0, r1, r2, r3;
 #pragma unroll
         for (int k = 0; k < G::K; k++) {
@@ -106,17 +106,17 @@ __global__ __launch_bounds__(kThreads) void convert_vec_kernel(
             r2.v[k] = conv1s<C, SW>(a2.v[k], arg);
             r3.v[k] = conv1s<C, SW>(a3.v[k], arg);
         }
-        d[i] = r0;
-        d[i + stride] = r1;
-        d[i + 2 * stride] = r2;
-        d[i + 3 * stride] = r3;
+        st_stream<NT>(d + i, r0);
+        st_stream<NT>(d + i + stride, r1);
+        st_stream<NT>(d + i + 2 * stride, r2);
+        st_stream<NT>(d + i + 3 * stride, r3);
     }
     for (; i < nvec; i += stride) {
-        SV a = s[i];
+        SV a = ld_stream<NT>(s + i);
         DV r;
 #pragma unroll
         for (int k = 0; k < G::K; k++) r.v[k] = conv1s<C, SW>(a.v[k], arg);
-        d[i] = r;
+        st_stream<NT>(d + i, r);
     }
 }
 
@@ -144,8 +144,12 @@ static void launch_convert(hzsdr_ctx *ctx, const void *src, void *dst, size_t nc
     if (nvec) {
         // (one vector per lane up to the grid's cap of 128 workgroups per CU, the kernel's four-deep loop only beyond:
         // u8 -> c64 over 2^24 samples 26.7 us instead of 27.5 from the cache, 35.5 instead of 36.7 from HBM)
-        hipLaunchKernelGGL((convert_vec_kernel<C, SW>), dim3(blocks_for(ctx, nvec)), dim3(kThreads),
-                           0, ctx->stream, s, d, nvec, arg);
+        // (a call of 96 MiB or more streams past the memory-side cache: hz_device.h)
+        if (streams_past_cache(ncomp * (sizeof(S) + sizeof(D))))
+            hipLaunchKernelGGL((convert_vec_kernel<C, SW, true>), dim3(blocks_for(ctx, nvec)), dim3(kThreads), 0, ctx->stream, s, d, nvec, arg);
+        else
+            hipLaunchKernelGGL((convert_vec_kernel<C, SW>), dim3(blocks_for(ctx, nvec)), dim3(kThreads),
+                               0, ctx->stream, s, d, nvec, arg);
     }
     size_t done = nvec * G::K;
     if (done < ncomp) {
@@ -183,6 +187,28 @@ int convert_device(hzsdr_ctx *ctx, int dst_fmt, void *dst, int src_fmt, const vo
     default: return HZSDR_ERR_CONVERSION_NOT_IMPLEMENTED;
     }
     return HZSDR_OK;
+}
+
+// ---- CopySamples (copy.go:31-52) between device buffers ------------------------------------
+// A call that streams past the memory-side cache is the library's own copy -- two 16-byte vectors per lane and trip,
+// non-temporal both ways: 6.2 TB/s from HBM where hipMemcpyAsync and torch's copy_ reach 5.0-5.4 (tools/copy_rate.hip)
+// -- and with that the yardstick bench.py quotes the HBM-bound kernels against.
+__global__ __launch_bounds__(kThreads) void copy_stream_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t nvec) {
+    constexpr int U = 2;
+    const size_t tile = (size_t)kThreads * U;
+    for (size_t t0 = (size_t)blockIdx.x * tile; t0 < nvec; t0 += (size_t)gridDim.x * tile) {
+        uint4 a[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t i = t0 + (size_t)u * kThreads + threadIdx.x;
+            if (i < nvec) a[u] = nt_load(src + i);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const size_t i = t0 + (size_t)u * kThreads + threadIdx.x;
+            if (i < nvec) nt_store(dst + i, a[u]);
+        }
+    }
 }
 
 // ---- lookup-table gather ------------------------------------------------------
@@ -290,7 +316,7 @@ template <> struct SrcSample<HZSDR_FMT_C64> {
 // order from +0, divide by float32(factor)  (stream/downsample.go:99-124).
 // W raw samples are fetched per vector load (W * sizeof(raw) = 16 B) when the
 // window geometry allows (factor % W == 0 and 16-B aligned source).
-template <int FMT, int W>
+template <int FMT, int W, bool NT = false>
 __global__ __launch_bounds__(kThreads) void downsample_kernel(
     const typename SrcSample<FMT>::raw_t *__restrict__ from, float2 *to, size_t count,
     unsigned factor) {
@@ -303,7 +329,7 @@ __global__ __launch_bounds__(kThreads) void downsample_kernel(
         if constexpr (W > 1) {
             const Vec<R, W> *wv = reinterpret_cast<const Vec<R, W> *>(w);
             for (unsigned j = 0; j < factor / W; j++) {
-                Vec<R, W> v = wv[j];
+                Vec<R, W> v = ld_stream<NT>(wv + j);
 #pragma unroll
                 for (int k = 0; k < W; k++) {
                     float2 c = SrcSample<FMT>::cvt(v.v[k]);
@@ -318,7 +344,7 @@ __global__ __launch_bounds__(kThreads) void downsample_kernel(
                 si = __fadd_rn(si, c.y);
             }
         }
-        to[i] = make_float2(__fdiv_rn(sr, div), __fdiv_rn(si, div));
+        st_stream<NT>(to + i, make_float2(__fdiv_rn(sr, div), __fdiv_rn(si, div)));
     }
 }
 
@@ -329,7 +355,11 @@ static void launch_downsample(hzsdr_ctx *ctx, const void *from, void *to, size_t
     constexpr int W = 16 / sizeof(R);
     if (count == 0) return;
     dim3 g(blocks_for(ctx, count)), b(kThreads);
-    if (factor % W == 0 && (uintptr_t)from % 16 == 0)
+    // (from 64 MiB on here: a decimating kernel's call is mostly INPUT, and a stream's next buffer of that size has
+    // pushed this one out of the 256 MB cache long before its turn comes again -- 2^24 i16 samples by 8 are 80 MiB)
+    if (factor % W == 0 && (uintptr_t)from % 16 == 0 && count * ((size_t)factor * sizeof(R) + 8) >= ((size_t)64 << 20))
+        hipLaunchKernelGGL((downsample_kernel<FMT, W, true>), g, b, 0, ctx->stream, (const R *)from, (float2 *)to, count, factor);
+    else if (factor % W == 0 && (uintptr_t)from % 16 == 0)
         hipLaunchKernelGGL((downsample_kernel<FMT, W>), g, b, 0, ctx->stream, (const R *)from, (float2 *)to, count, factor);
     else
         hipLaunchKernelGGL((downsample_kernel<FMT, 1>), g, b, 0, ctx->stream, (const R *)from, (float2 *)to, count, factor);
@@ -389,7 +419,21 @@ int hzsdr_convert(hzsdr_ctx *ctx, int dst_format, void *dst, size_t dst_len, int
         if (ctx->memspace == HZSDR_MEM_HOST) {
             memmove(dst, src, n * ss);
         } else {
-            HZ_HIP(ctx, hipMemcpyAsync(dst, src, n * ss, kind, ctx->stream));
+            const size_t bytes = n * (size_t)ss;
+            const char *sb = (const char *)src;
+            char *db = (char *)dst;
+            const bool apart = sb + bytes <= db || db + bytes <= sb;  // (copy() allows overlap: the runtime's copy then)
+            if (apart && streams_past_cache(2 * bytes) && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+                const size_t nvec = bytes / 16;
+                const size_t tiles = (nvec + 2 * kThreads - 1) / (2 * kThreads);
+                hipLaunchKernelGGL(copy_stream_kernel, dim3((unsigned)std::min<size_t>(tiles, (size_t)1 << 20)), dim3(kThreads), 0, ctx->stream,
+                                   (const uint4 *)src, (uint4 *)dst, nvec);
+                if (bytes % 16)
+                    HZ_HIP(ctx, hipMemcpyAsync(db + nvec * 16, sb + nvec * 16, bytes % 16, kind, ctx->stream));
+                HZ_HIP(ctx, hipGetLastError());
+            } else {
+                HZ_HIP(ctx, hipMemcpyAsync(dst, src, bytes, kind, ctx->stream));
+            }
         }
         if (n_out) *n_out = n;
         return HZSDR_OK;

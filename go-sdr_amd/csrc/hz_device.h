@@ -31,6 +31,22 @@ template <class T> __device__ __forceinline__ void nt_store(T *p, const T &v) {
     __builtin_nontemporal_store(__builtin_bit_cast(W, v), reinterpret_cast<W *>(p));
 }
 
+// A kernel's accesses as a template switch: NT = the call streams past the memory-side cache.  A call that touches
+// 96 MiB or more finds nothing of itself in the 256 MB Infinity Cache the next time anyway; measured over rotations of
+// buffers (tools/stream_rate.hip, from HBM both ways, 2^24 samples): Scale in place 48.0 -> 43.2 us (6.2 TB/s), the
+// boxcar Downsample / 8 from i16 17.3 -> 16.1 us (5.2 TB/s), u8 -> c64 36.1 -> 34.5 us (4.9 TB/s: four fifths of its
+// bytes are writes) -- and 20 % SLOWER over one cached buffer pair, hence the threshold.
+constexpr size_t kStreamPastCacheBytes = (size_t)96 << 20;
+inline bool streams_past_cache(size_t bytes) { return bytes >= kStreamPastCacheBytes; }
+template <bool NT, class T> __device__ __forceinline__ T ld_stream(const T *p) {
+    if constexpr (NT) return nt_load(p);
+    else return *p;
+}
+template <bool NT, class T> __device__ __forceinline__ void st_stream(T *p, const T &v) {
+    if constexpr (NT) nt_store(p, v);
+    else *p = v;
+}
+
 // Go complex64 * complex64: cmd/compile widens to float64 ("Compute in
 // Float64 to minimize cancellation error"), forms ar*br - ai*bi and
 // ar*bi + ai*br, narrows each once.  Products of two float32 values are exact
@@ -271,6 +287,28 @@ __device__ __forceinline__ bool sincos_narrow(double x, float &sn, float &cs) {
     sn = __uint_as_float(__float_as_uint(a) ^ (((unsigned)__double2hiint(x) ^ t) & 0x80000000u));
     cs = __uint_as_float(__float_as_uint(b) ^ ((t ^ (t << 1)) & 0x80000000u));
     return ds > 256u && dc > 256u;
+}
+
+// complex64(math.Sincos(x)) for ANY x, bit for bit: sincos_narrow where it is certain (all but 2^-20 of the
+// factors inside its range), the operation-for-operation go_sincos OUT OF LINE for the rest -- a lane that cannot
+// decide calls it, the others wait.  Every reference-order Shift that is not the streaming map (which queues its
+// undecided vectors instead: shift_exact_kernel) takes this: the in-order FIR chain, the chains with Decimate /
+// Downsample / convolution terminals, generic programs, fix-up and history tasks.  Round 5: the in-order north-star
+// chain ran the 45-instruction go_sincos on every input sample, 127.6 us per 2^24 samples.
+__device__ __attribute__((noinline)) void go_sincos_slow32(double x, float &sn, float &cs) {
+    double s, c;
+    go_sincos(x, s, c);
+    sn = (float)s, cs = (float)c;
+}
+__device__ __forceinline__ void go_sincos32(double x, float &sn, float &cs) {
+    const double ax = fabs(x);
+    // (sincos_narrow's range: 2^-60 <= |x| < 2^29, or +-0; NaN and infinities fail the comparison)
+    const bool in_range = ax == 0.0 || (ax >= 8.67361737988403547206e-19 && ax < 536870912.0);
+    float s1 = 0.f, c1 = 0.f;
+    bool ok = in_range;
+    if (in_range) ok = sincos_narrow(x, s1, c1);
+    if (!ok) go_sincos_slow32(x, s1, c1);
+    sn = s1, cs = c1;
 }
 
 // sin and cos of x, |x| < 2^30, for the LATE mixer (hz_chain_dev.h): the same Cephes kernels

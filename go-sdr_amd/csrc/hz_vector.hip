@@ -19,22 +19,22 @@ struct OpRotate {
     __device__ __forceinline__ float2 operator()(float2 v) const { return go_cmul(v, m); }  // mult.go:29-33
 };
 
-template <class Op>
+template <class Op, bool NT = false>
 __global__ __launch_bounds__(kThreads) void map_inplace_vec(float4 *buf, size_t nvec, Op op) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i + 3 * stride < nvec; i += 4 * stride) {
-        float4 a0 = buf[i], a1 = buf[i + stride], a2 = buf[i + 2 * stride], a3 = buf[i + 3 * stride];
+        float4 a0 = ld_stream<NT>(buf + i), a1 = ld_stream<NT>(buf + i + stride), a2 = ld_stream<NT>(buf + i + 2 * stride), a3 = ld_stream<NT>(buf + i + 3 * stride);
         float2 l, h;
-        l = op(make_float2(a0.x, a0.y)); h = op(make_float2(a0.z, a0.w)); buf[i] = make_float4(l.x, l.y, h.x, h.y);
-        l = op(make_float2(a1.x, a1.y)); h = op(make_float2(a1.z, a1.w)); buf[i + stride] = make_float4(l.x, l.y, h.x, h.y);
-        l = op(make_float2(a2.x, a2.y)); h = op(make_float2(a2.z, a2.w)); buf[i + 2 * stride] = make_float4(l.x, l.y, h.x, h.y);
-        l = op(make_float2(a3.x, a3.y)); h = op(make_float2(a3.z, a3.w)); buf[i + 3 * stride] = make_float4(l.x, l.y, h.x, h.y);
+        l = op(make_float2(a0.x, a0.y)); h = op(make_float2(a0.z, a0.w)); st_stream<NT>(buf + i, make_float4(l.x, l.y, h.x, h.y));
+        l = op(make_float2(a1.x, a1.y)); h = op(make_float2(a1.z, a1.w)); st_stream<NT>(buf + i + stride, make_float4(l.x, l.y, h.x, h.y));
+        l = op(make_float2(a2.x, a2.y)); h = op(make_float2(a2.z, a2.w)); st_stream<NT>(buf + i + 2 * stride, make_float4(l.x, l.y, h.x, h.y));
+        l = op(make_float2(a3.x, a3.y)); h = op(make_float2(a3.z, a3.w)); st_stream<NT>(buf + i + 3 * stride, make_float4(l.x, l.y, h.x, h.y));
     }
     for (; i < nvec; i += stride) {
-        float4 a = buf[i];
+        float4 a = ld_stream<NT>(buf + i);
         float2 l = op(make_float2(a.x, a.y)), h = op(make_float2(a.z, a.w));
-        buf[i] = make_float4(l.x, l.y, h.x, h.y);
+        st_stream<NT>(buf + i, make_float4(l.x, l.y, h.x, h.y));
     }
 }
 
@@ -55,7 +55,9 @@ static void launch_map(hzsdr_ctx *ctx, void *buf, size_t n, Op op) {
     size_t nvec = (n - head) / 2;
     size_t tail = n - head - 2 * nvec;
     if (head) hipLaunchKernelGGL(map_inplace_scalar<Op>, dim3(1), dim3(64), 0, ctx->stream, p, head, op);
-    if (nvec)
+    if (nvec && streams_past_cache(nvec * 16))  // (past the memory-side cache: hz_device.h)
+        hipLaunchKernelGGL((map_inplace_vec<Op, true>), dim3(blocks_for(ctx, nvec)), dim3(kThreads), 0, ctx->stream, (float4 *)(p + head), nvec, op);
+    else if (nvec)
         hipLaunchKernelGGL(map_inplace_vec<Op>, dim3(blocks_for(ctx, nvec)), dim3(kThreads), 0,  // (one vector per lane up to the grid cap: hz_convert.hip)
                            ctx->stream, (float4 *)(p + head), nvec, op);
     if (tail)

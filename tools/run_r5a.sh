@@ -1,19 +1,17 @@
 set -u
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r5d
-timeout 900 python -m pytest tests/test_gpu_firmm.py tests/test_gpu_fullsize.py tests/test_gpu_ring.py tests/test_gpu_fir_fuzz.py tests/test_gpu_latemix.py -x -q -m gpu > gpurun_out/r5d/tests.log 2>&1; echo "tests rc $?" >> gpurun_out/r5d/tests.log
-tail -4 gpurun_out/r5d/tests.log
-
-
-
-timeout 600 python bench.py --no-extra --no-cpu-baseline > gpurun_out/r5d/bench_default.json 2> gpurun_out/r5d/bench_default.err
-timeout 600 python bench.py --no-extra --no-oracle --no-pipeline --batch 1 > gpurun_out/r5d/bench_plain.json 2>/dev/null
-
-
-
-python -c "
+mkdir -p gpurun_out/r5e
+timeout 1500 python -m pytest tests -x -q -m gpu > gpurun_out/r5e/tests.log 2>&1; echo "tests rc $?" >> gpurun_out/r5e/tests.log
+tail -6 gpurun_out/r5e/tests.log
+timeout 900 python bench.py > gpurun_out/r5e/bench_full.json 2> gpurun_out/r5e/bench_full.err
+tail -3 gpurun_out/r5e/bench_full.err
+python - <<'PY'
 import json
-for f in ('bench_default','bench_plain'):
-    d=json.load(open('gpurun_out/r5d/%s.json'%f)); r=d['roofline']
-    print(f, d['value'], d['ms_per_step'], r['kernel_ms'], r.get('kernel_ms_unpipelined'), r.get('kernel_ms_batch_unpipelined'), d.get('parity',{}).get('ok'), d.get('parity',{}).get('rel_l2_err'))
-"
+d=json.load(open('gpurun_out/r5e/bench_full.json')); r=d['roofline']
+print('headline', d['value'], d['ms_per_step'], r['kernel_ms'], r.get('kernel_ms_unpipelined'), r.get('kernel_ms_batch_unpipelined'), d.get('parity',{}).get('ok'))
+for k,v in d.get('extra',{}).items():
+    if isinstance(v,dict) and 'kernel_ms' in v:
+        h=v.get('hbm',{})
+        print('%-32s %8.4f ms %7.1f GB/s | hbm %s %s frac_copy %s' % (k, v['kernel_ms'], v.get('GBps',0), h.get('kernel_ms'), h.get('GBps'), h.get('frac_of_device_copy')))
+print(d.get('cpu_baseline',{}).get('value'))
+PY
