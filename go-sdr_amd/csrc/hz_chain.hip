@@ -269,8 +269,8 @@ int hzsdr_chain_convolution(hzsdr_chain *c, const void *filter_freq, size_t filt
     using namespace hz;
     HZ_TRY(chain_terminal_set(c));
     hzsdr_ctx *ctx = c->ctx;
-    if (!filter_freq || !fft_lds_ok(filter_len))
-        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: filter length must be a power of two in 4..8192");
+    if (!filter_freq || !fft_length_ok(filter_len))
+        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: filter length 1 ... 2^24 (a power of two) or 1 ... 2^23 (any other)");
     if (decimate_factor == 0 || decimate_factor > kReaderBlock) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: decimate factor");
     HZ_TRY(enter(ctx));
     void *filt = nullptr;
@@ -299,7 +299,16 @@ int hzsdr_chain_plan(const hzsdr_chain *c, size_t n_in, size_t *n_consumed, size
         break;
     case TERM_CONV: {
         size_t blk = c->flen;
-        if (c->factor > 1 && blk < hz::kReaderBlock) blk = hz::kReaderBlock;
+        if (c->factor > 1) {
+            // (a DecimateReader behind the ConvolutionReader reads 32 Ki-sample blocks of its output: whole blocks of both,
+            // i.e. their least common multiple -- 32 Ki itself for the power-of-two lengths up to it)
+            size_t a = blk, b = hz::kReaderBlock;
+            while (b) {
+                const size_t t = a % b;
+                a = b, b = t;
+            }
+            blk = blk / a * hz::kReaderBlock;
+        }
         cons = n_in / blk * blk;
         outn = c->factor > 1 ? cons / hz::kReaderBlock * (hz::kReaderBlock / c->factor) : cons;
         break;

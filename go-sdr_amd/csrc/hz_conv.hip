@@ -60,10 +60,52 @@ static int launch_conv_fmt(hzsdr_ctx *ctx, size_t n, const void *in, void *out, 
 
 // Block-circular convolution of nblocks blocks of length n from a source of
 // format fmt with elementwise program P (device pointers).
+// Block lengths the fused kernels do not take (anything but a power of two in 4 .. 8192 -- a 1000- or 1200-bin
+// filter, stream/convolution.go:57-61 blocks on len(filter) whatever it is): the reference's three steps as three
+// passes over scratch -- the elementwise stages into complex64, every block's forward transform (fft_device: Bluestein
+// for lengths that are not powers of two), the product with the filter in Go's complex64 arithmetic, the backward
+// transforms, the DecimateReader pick.
+template <int FMT>
+static int conv_blocks_generic_fmt(hzsdr_ctx *ctx, size_t n, const void *in, void *out, const void *filt, size_t nblocks, unsigned dec,
+                                   size_t per, const EwProgram &P) {
+    const size_t total = n * nblocks;
+    const void *src = in;
+    if (FMT != HZSDR_FMT_C64 || P.n != 0) {
+        HZ_TRY(ensure_slot(ctx, 14, total * 8));
+        hipLaunchKernelGGL((chain_map_kernel<FMT, 1>), dim3(blocks_for(ctx, total)), dim3(kThreads), 0, ctx->stream, in, (float2 *)ctx->slots[14].ptr,
+                           total, (uint64_t)0, P);
+        src = ctx->slots[14].ptr;
+    }
+    HZ_TRY(ensure_slot(ctx, 6, total * 8));
+    void *f1 = ctx->slots[6].ptr;
+    HZ_TRY(fft_device(ctx, src, f1, n, nblocks, true));
+    pointwise_mul_blocks_device(ctx, f1, filt, n, nblocks);
+    if (dec <= 1) return fft_device(ctx, f1, out, n, nblocks, false);
+    HZ_TRY(ensure_slot(ctx, 15, total * 8));
+    HZ_TRY(fft_device(ctx, f1, ctx->slots[15].ptr, n, nblocks, false));
+    // (DecimateReader behind the ConvolutionReader: hz_chain.hip hands `per` = outputs per 32 Ki-sample block)
+    const size_t n_out = total / kReaderBlock * per;
+    if (n_out) {
+        EwProgram none{};
+        hipLaunchKernelGGL((chain_decimate_kernel<HZSDR_FMT_C64>), dim3(blocks_for(ctx, n_out)), dim3(kThreads), 0, ctx->stream,
+                           (const void *)ctx->slots[15].ptr, (float2 *)out, n_out, per, (size_t)dec, none);
+    }
+    HZ_HIP(ctx, hipGetLastError());
+    return HZSDR_OK;
+}
+
 int conv_blocks_device(hzsdr_ctx *ctx, int fmt, size_t n, const void *in, void *out,
                               const void *filt, size_t nblocks, unsigned dec, size_t per,
                               const EwProgram &P) {
     if (nblocks == 0) return HZSDR_OK;
+    if (!fft_lds_ok(n)) {
+        switch (fmt) {
+        case HZSDR_FMT_C64: return conv_blocks_generic_fmt<HZSDR_FMT_C64>(ctx, n, in, out, filt, nblocks, dec, per, P);
+        case HZSDR_FMT_U8: return conv_blocks_generic_fmt<HZSDR_FMT_U8>(ctx, n, in, out, filt, nblocks, dec, per, P);
+        case HZSDR_FMT_I8: return conv_blocks_generic_fmt<HZSDR_FMT_I8>(ctx, n, in, out, filt, nblocks, dec, per, P);
+        default: return conv_blocks_generic_fmt<HZSDR_FMT_I16>(ctx, n, in, out, filt, nblocks, dec, per, P);
+        }
+    }
     const float2 *tw = nullptr;
     FvTabs tabs{};
     if (fv::ok((int)n)) HZ_TRY(get_fv_tables(ctx, n, &tabs));
@@ -76,7 +118,7 @@ int conv_blocks_device(hzsdr_ctx *ctx, int fmt, size_t n, const void *in, void *
     }
 }
 
-// Generic (any power of two) single-block path: three steps through scratch.
+// Generic (any length) single-block path: three steps through scratch.
 static int conv_generic_device(hzsdr_ctx *ctx, void *dst, const void *src1, const void *src2_or_filt,
                                size_t n, int kind) {
     HZ_TRY(ensure_slot(ctx, 6, n * 8));
@@ -107,8 +149,8 @@ int hzsdr_convolve_freq_create(hzsdr_ctx *ctx, void *dst, size_t dst_len, const 
     if (src_len != dst_len || src_len != freq_len)  // fft/convolution.go:156-158
         return fail(ctx, HZSDR_ERR_LENGTH_MISMATCH, "sdr/fft.Convolve: Lengths do not match exactly");
     const size_t n = src_len;
-    if (n == 0 || (n & (n - 1)) || !dst || !src || !freq)
-        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "convolve: power-of-two length and non-null buffers");
+    if (n == 0 || !fft_length_ok(n) || !dst || !src || !freq)
+        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "convolve: 1 ... 2^24 samples (a power of two) or 1 ... 2^23 (any other length), non-null buffers");
     HZ_TRY(enter(ctx));
     void *filt = nullptr;
     HZ_HIP(ctx, hipMalloc(&filt, n * 8));
@@ -129,8 +171,8 @@ int hzsdr_convolve_create(hzsdr_ctx *ctx, void *dst, size_t dst_len, const void 
     if (iq1_len != iq2_len || iq1_len != dst_len)  // fft/convolution.go:37-39
         return fail(ctx, HZSDR_ERR_LENGTH_MISMATCH, "sdr/fft: IQ/Dest buffer lengths do not match exactly");
     const size_t n = iq1_len;
-    if (n == 0 || (n & (n - 1)) || !dst || !iq1 || !iq2)
-        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "convolve: power-of-two length and non-null buffers");
+    if (n == 0 || !fft_length_ok(n) || !dst || !iq1 || !iq2)
+        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "convolve: 1 ... 2^24 samples (a power of two) or 1 ... 2^23 (any other length), non-null buffers");
     if (mode != HZSDR_CONV_CONVOLVE && mode != HZSDR_CONV_CROSS_CORRELATE) return HZSDR_ERR_INVALID_ARGUMENT;
     *out = new hzsdr_conv{ctx, mode == HZSDR_CONV_CONVOLVE ? 1 : 2, dst, iq1, iq2, n, nullptr};
     return HZSDR_OK;
@@ -181,8 +223,8 @@ int hzsdr_convolution_blocks(hzsdr_ctx *ctx, void *out, size_t out_len, const vo
     using namespace hz;
     if (n_out) *n_out = 0;
     if (!ctx) return HZSDR_ERR_INVALID_ARGUMENT;
-    if (!fft_lds_ok(filter_len) || !filter_freq)
-        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "convolution: filter length must be a power of two in 4..8192");
+    if (!fft_length_ok(filter_len) || !filter_freq)
+        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "convolution: filter length 1 ... 2^24 (a power of two) or 1 ... 2^23 (any other)");
     const size_t nblocks = in_len / filter_len, n = nblocks * filter_len;
     if (out_len < n) return fail(ctx, HZSDR_ERR_DST_TOO_SMALL, "convolution: output buffer too small");
     if (n && (!in || !out)) return HZSDR_ERR_INVALID_ARGUMENT;

@@ -504,11 +504,159 @@ static int fft_two_step(hzsdr_ctx *ctx, const float2 *in, float2 *out, size_t n,
     return HZSDR_OK;
 }
 
-// Transform `batch` consecutive length-n blocks of device memory.
+// ---- any length: Bluestein's chirp transform over the power-of-two kernels -----------------------------------
+// The reference's Planner takes whatever length its buffers have (fft/fft.go:45-48), and stream.ConvolutionReader
+// blocks on len(filter), whatever it is (stream/convolution.go:57-61): a 1000-tap or 1200-bin filter is ordinary.
+// With n k = (n^2 + k^2 - (k - n)^2) / 2:
+//     X[k] = c[k] sum_n (x[n] c[n]) b[k - n],   c[n] = exp(-+ i pi n^2 / N),  b = conj(c)
+// -- a circular convolution of length M = the power of two >= 2 N - 1: two M-point transforms of the library's own
+// plus three elementwise passes.  The chirp is formed from n^2 mod 2 N (exact integers) in float64; the chirp filter's
+// spectrum B = FFT_M(b) / M is computed in float64 on the host once per (context, N) and rounded once.  Backward
+// (unnormalised, like the power-of-two plans) = the same with every chirp conjugated; b is even, so its spectrum
+// then is conj(B).  Accuracy: about that of two M-point transforms in a row (tests: <= 3e-7 log2 N relative L2).
+constexpr size_t kBluesteinMax = (size_t)1 << 23;  // (M = 2^24, the largest power-of-two plan)
+struct Bluestein {
+    const float2 *c;  // N chirp values (forward)
+    const float2 *B;  // M spectrum values of the chirp filter, / M
+    size_t m;
+};
+
+static void host_fft64(std::vector<double> &re, std::vector<double> &im, size_t n) {  // radix-2, forward, in place
+    for (size_t i = 1, j = 0; i < n; i++) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(re[i], re[j]), std::swap(im[i], im[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const size_t half = len / 2;
+        for (size_t k = 0; k < half; k++) {
+            const double a = -2.0 * M_PI * (double)k / (double)len, wr = cos(a), wi = sin(a);
+            for (size_t i = k; i < n; i += len) {
+                const size_t u = i, v = i + half;
+                const double tr = re[v] * wr - im[v] * wi, ti = re[v] * wi + im[v] * wr;
+                re[v] = re[u] - tr, im[v] = im[u] - ti;
+                re[u] += tr, im[u] += ti;
+            }
+        }
+    }
+}
+
+static int get_bluestein(hzsdr_ctx *ctx, size_t n, Bluestein *out) {
+    size_t m = 1;
+    while (m < 2 * n - 1) m <<= 1;
+    out->m = m;
+    // (keys: the plain tables use n, the big twiddles 2 n + 1, the packed core's tables their own high bits)
+    const size_t key = ((size_t)0xB1 << 48) | n;
+    auto it = ctx->twiddles.find(key);
+    if (it != ctx->twiddles.end()) {
+        out->c = (const float2 *)it->second;
+        out->B = out->c + n;
+        return HZSDR_OK;
+    }
+    std::vector<double> br(m, 0.0), bi(m, 0.0);
+    std::vector<float2> h(n + m);
+    for (size_t i = 0; i < n; i++) {
+        const unsigned long long q = ((unsigned long long)i * (unsigned long long)i) % (2ull * n);  // i^2 mod 2N: exact
+        const double ang = M_PI * (double)q / (double)n;
+        const double cr = cos(ang), ci = sin(ang);
+        h[i] = make_float2((float)cr, (float)-ci);  // c[i] = exp(-i pi i^2 / N)
+        br[i] = cr, bi[i] = ci;                     // b[i] = conj(c[i]), and b[M - i] = b[i]
+        if (i) br[m - i] = cr, bi[m - i] = ci;
+    }
+    host_fft64(br, bi, m);
+    const double inv = 1.0 / (double)m;
+    for (size_t k = 0; k < m; k++) h[n + k] = make_float2((float)(br[k] * inv), (float)(bi[k] * inv));
+    void *d = nullptr;
+    HZ_HIP(ctx, hipMalloc(&d, h.size() * sizeof(float2)));
+    hipError_t e = hipMemcpy(d, h.data(), h.size() * sizeof(float2), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return hip_fail(ctx, e, "chirp upload", __FILE__, __LINE__);
+    }
+    ctx->twiddles[key] = d;
+    out->c = (const float2 *)d;
+    out->B = out->c + n;
+    return HZSDR_OK;
+}
+
+// a[b m + i] = x[b n + i] c[i] (i < n), 0 (n <= i < m); CONJ: the backward transform's chirp
+template <bool CONJ>
+__global__ __launch_bounds__(kThreads) void blue_pre_kernel(const float2 *__restrict__ x, float2 *__restrict__ a, const float2 *__restrict__ c,
+                                                            uint32_t n, uint32_t m, size_t total) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const size_t b = g / m;
+        const uint32_t i = (uint32_t)(g - b * m);
+        float2 v = make_float2(0.f, 0.f);
+        if (i < n) {
+            float2 w = c[i];
+            if (CONJ) w.y = -w.y;
+            v = cmulf(x[b * n + i], w);
+        }
+        a[g] = v;
+    }
+}
+// A[b m + k] *= B[k] (or conj(B[k]))
+template <bool CONJ>
+__global__ __launch_bounds__(kThreads) void blue_mul_kernel(float2 *__restrict__ a, const float2 *__restrict__ B, uint32_t m, size_t total) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        float2 w = B[g & (m - 1)];
+        if (CONJ) w.y = -w.y;
+        a[g] = cmulf(a[g], w);
+    }
+}
+// X[b n + k] = p[b m + k] c[k]
+template <bool CONJ>
+__global__ __launch_bounds__(kThreads) void blue_post_kernel(const float2 *__restrict__ p, float2 *__restrict__ out, const float2 *__restrict__ c,
+                                                             uint32_t n, uint32_t m, size_t total) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += stride) {
+        const size_t b = g / n;
+        const uint32_t k = (uint32_t)(g - b * n);
+        float2 w = c[k];
+        if (CONJ) w.y = -w.y;
+        out[g] = cmulf(p[b * m + k], w);
+    }
+}
+
+int fft_device(hzsdr_ctx *ctx, const void *in, void *out, size_t n, size_t batch, bool fwd);
+
+static int fft_bluestein(hzsdr_ctx *ctx, const float2 *in, float2 *out, size_t n, size_t batch, bool fwd) {
+    if (n > kBluesteinMax) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "fft: a length that is not a power of two must be <= 2^23");
+    Bluestein bl{};
+    HZ_TRY(get_bluestein(ctx, n, &bl));
+    const size_t m = bl.m;
+    // (in pieces of at most 2^25 points of scratch per buffer: a large batch does not need batch * M of it)
+    const size_t per = std::max<size_t>(1, ((size_t)1 << 25) / m);
+    HZ_TRY(ensure_slot(ctx, 12, std::min(batch, per) * m * sizeof(float2)));
+    HZ_TRY(ensure_slot(ctx, 13, std::min(batch, per) * m * sizeof(float2)));
+    float2 *a = (float2 *)ctx->slots[12].ptr, *A = (float2 *)ctx->slots[13].ptr;
+    for (size_t b0 = 0; b0 < batch; b0 += per) {
+        const size_t nb = std::min(per, batch - b0);
+        const float2 *x = in + b0 * n;
+        float2 *y = out + b0 * n;
+        const dim3 gm(blocks_for(ctx, nb * m)), gn(blocks_for(ctx, nb * n)), blk(kThreads);
+        if (fwd) hipLaunchKernelGGL(blue_pre_kernel<false>, gm, blk, 0, ctx->stream, x, a, bl.c, (uint32_t)n, (uint32_t)m, nb * m);
+        else hipLaunchKernelGGL(blue_pre_kernel<true>, gm, blk, 0, ctx->stream, x, a, bl.c, (uint32_t)n, (uint32_t)m, nb * m);
+        HZ_TRY(fft_device(ctx, a, A, m, nb, true));
+        if (fwd) hipLaunchKernelGGL(blue_mul_kernel<false>, gm, blk, 0, ctx->stream, A, bl.B, (uint32_t)m, nb * m);
+        else hipLaunchKernelGGL(blue_mul_kernel<true>, gm, blk, 0, ctx->stream, A, bl.B, (uint32_t)m, nb * m);
+        HZ_TRY(fft_device(ctx, A, a, m, nb, false));
+        if (fwd) hipLaunchKernelGGL(blue_post_kernel<false>, gn, blk, 0, ctx->stream, (const float2 *)a, y, bl.c, (uint32_t)n, (uint32_t)m, nb * n);
+        else hipLaunchKernelGGL(blue_post_kernel<true>, gn, blk, 0, ctx->stream, (const float2 *)a, y, bl.c, (uint32_t)n, (uint32_t)m, nb * n);
+    }
+    HZ_HIP(ctx, hipGetLastError());
+    return HZSDR_OK;
+}
+
+// Transform `batch` consecutive length-n blocks of device memory (any length: see above).
 int fft_device(hzsdr_ctx *ctx, const void *in, void *out, size_t n, size_t batch, bool fwd) {
     if (batch == 0 || n == 0) return HZSDR_OK;
     const float2 *i = (const float2 *)in;
     float2 *o = (float2 *)out;
+    if ((n & (n - 1)) != 0) return fft_bluestein(ctx, i, o, n, batch, fwd);
     if (fft_two_step_ok(n)) return fft_two_step(ctx, i, o, n, batch, fwd);
     if (!fft_lds_ok(n)) return fft_global(ctx, i, o, n, batch, fwd);
     const float2 *tw = nullptr;
@@ -541,6 +689,16 @@ __global__ void pointwise_mul_kernel(float2 *f1, const float2 *__restrict__ f2, 
     }
 }
 
+__global__ void pointwise_mul_blocks_kernel(float2 *f1, const float2 *__restrict__ f2, size_t period, size_t total) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) f1[i] = go_cmul(f1[i], f2[i % period]);
+}
+void pointwise_mul_blocks_device(hzsdr_ctx *ctx, void *f1, const void *f2, size_t period, size_t nblocks) {
+    if (period == 0 || nblocks == 0) return;
+    hipLaunchKernelGGL(pointwise_mul_blocks_kernel, dim3(blocks_for(ctx, period * nblocks)), dim3(kThreads), 0, ctx->stream, (float2 *)f1,
+                       (const float2 *)f2, period, period * nblocks);
+}
+
 void pointwise_mul_device(hzsdr_ctx *ctx, void *f1, const void *f2, size_t n, bool conj) {
     if (n == 0) return;
     hipLaunchKernelGGL(pointwise_mul_kernel, dim3(blocks_for(ctx, n)), dim3(kThreads), 0, ctx->stream,
@@ -563,15 +721,18 @@ int hzsdr_fft_plan_batch(hzsdr_ctx *ctx, void *iq, void *freq, size_t n, size_t 
     using namespace hz;
     if (!ctx || !out) return HZSDR_ERR_INVALID_ARGUMENT;
     *out = nullptr;
-    if (n == 0 || (n & (n - 1)) != 0 || n > ((size_t)1 << 24))
-        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "fft: length must be a power of two <= 2^24");
+    const bool pow2 = (n & (n - 1)) == 0;
+    if (n == 0 || (pow2 && n > ((size_t)1 << 24)) || (!pow2 && n > kBluesteinMax))
+        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "fft: length must be 1 ... 2^24 (a power of two) or 1 ... 2^23 (any other)");
     if (batch == 0 || !iq || !freq) return HZSDR_ERR_INVALID_ARGUMENT;
     if (direction != HZSDR_FFT_FORWARD && direction != HZSDR_FFT_BACKWARD) return HZSDR_ERR_INVALID_ARGUMENT;
     HZ_TRY(enter(ctx));
     if (n > 1) {  // plan-time cost, like any planner
         const float2 *tw;
         fv::FvTabs tabs{};
-        if (fv::ok((int)n)) HZ_TRY(get_fv_tables(ctx, n, &tabs));
+        Bluestein bl{};
+        if (!pow2) HZ_TRY(get_bluestein(ctx, n, &bl));  // (the chirp and its spectrum: formed once per context and length)
+        else if (fv::ok((int)n)) HZ_TRY(get_fv_tables(ctx, n, &tabs));
         else if (n <= 128) HZ_TRY(get_twiddles(ctx, n, &tw));
     }
     *out = new hzsdr_fft{ctx, iq, freq, n, batch, direction == HZSDR_FFT_FORWARD};

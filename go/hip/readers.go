@@ -304,12 +304,12 @@ func (s Readers) ConvolutionReader(r sdr.Reader, planner fft.Planner, filter []c
 		return nil, sdr.ErrSampleFormatUnknown
 	}
 	fftLength := len(filter)
-	// hzsdr_convolution_blocks takes power-of-two blocks of 4 ... 8192 bins; the reference fails at
-	// construction too when its planner refuses a length (fft.ConvolveFreq, fft/convolution.go:150-170),
-	// so an unsupported length is an error HERE, not at the first Read. (Other lengths: the reference's
-	// own stream.ConvolutionReader over ctx.Planner.)
-	if fftLength < 4 || fftLength > 8192 || fftLength&(fftLength-1) != 0 {
-		return nil, fmt.Errorf("hip.ConvolutionReader: filter length %d is not a power of two in 4..8192", fftLength)
+	// hzsdr_convolution_blocks takes any block length the Planner takes -- powers of two up to 2^24 on the
+	// power-of-two kernels (4 ... 8192 bins: forward transform, product and backward transform in ONE kernel), any
+	// other length up to 2^23 by Bluestein's chirp transform over them.  The reference fails at construction when its
+	// planner refuses a length (fft.ConvolveFreq, fft/convolution.go:150-170); so does this.
+	if fftLength < 1 || (fftLength&(fftLength-1) == 0 && fftLength > 1<<24) || (fftLength&(fftLength-1) != 0 && fftLength > 1<<23) {
+		return nil, fmt.Errorf("hip.ConvolutionReader: filter length %d: 1 ... 2^24 (a power of two) or 1 ... 2^23 (any other)", fftLength)
 	}
 	return stream.ReadTransformer(r, stream.ReadTransformerConfig{
 		InputBufferLength:  fftLength,

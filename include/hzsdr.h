@@ -218,7 +218,10 @@ int hzsdr_downsample(hzsdr_ctx *ctx, int to_format, void *to, size_t to_len, int
 /* fft.Planner(iq, frequency, direction), fft/fft.go:45-48: binds the two
  * buffers for the life of the plan.  iq_len != freq_len -> DST_TOO_SMALL
  * (testutils/fft.go:127-137).  Forward = exp(-j 2 pi k n / N), natural bin
- * order, backward unnormalised.  Lengths must be a power of two. */
+ * order, backward unnormalised.  ANY length, as the reference's Planner (fft/fft.go:45-48): powers of two up to
+ * 2^24 on the power-of-two kernels, every other length up to 2^23 by Bluestein's chirp transform over them (two
+ * transforms of the next power of two >= 2 N - 1 and three elementwise passes; the chirp and its spectrum are formed
+ * in float64 once per context and length, at plan time). */
 int hzsdr_fft_plan(hzsdr_ctx *ctx, void *iq_c64, size_t iq_len, void *freq_c64, size_t freq_len,
                    int direction, hzsdr_fft **out);
 /* `batch` independent transforms over consecutive length-n blocks of both buffers. */
@@ -254,7 +257,9 @@ int hzsdr_conv_set_filter(hzsdr_conv *conv, const void *freq, size_t freq_len);
 int hzsdr_conv_free(hzsdr_conv *conv);
 /* The whole-buffer form of stream.ConvolutionReader, stream/convolution.go:36-82:
  * block-circular filtering of consecutive len(filter)-sample blocks; a
- * trailing partial block is not produced.  *n_out = blocks * filter_len. */
+ * trailing partial block is not produced.  *n_out = blocks * filter_len.
+ * Any filter length a plan takes (stream/convolution.go:57-61 blocks on len(filter), whatever it is): powers of two
+ * in 4 ... 8192 run as ONE kernel per launch, every other length as batched transforms through scratch. */
 int hzsdr_convolution_blocks(hzsdr_ctx *ctx, void *out, size_t out_len, const void *in,
                              size_t in_len, const void *filter_freq, size_t filter_len,
                              size_t *n_out);
@@ -344,7 +349,8 @@ int hzsdr_chain_decimate(hzsdr_chain *c, unsigned factor);
 /* Terminal: stream.DownsampleReader(r, factor), stream/downsample.go:47-64. */
 int hzsdr_chain_downsample(hzsdr_chain *c, unsigned factor);
 /* Terminal: stream.ConvolutionReader(r, planner, filter), stream/convolution.go:36-82,
- * optionally followed by DecimateReader(factor) (factor 1 = none). */
+ * optionally followed by DecimateReader(factor) (factor 1 = none).  Any filter length a plan takes; with a
+ * DecimateReader behind it the chain consumes whole multiples of lcm(filter_len, 32 Ki) samples. */
 int hzsdr_chain_convolution(hzsdr_chain *c, const void *filter_freq, size_t filter_len,
                             unsigned decimate_factor);
 /* Terminal: the north-star FIR-decimate (BASELINE.json north_star; not a

@@ -689,13 +689,45 @@ int orc_fft(const float *in, long n_in, float *out, long n_out, int forward) {
     if (n_in != n_out)
         return ORC_ERR_DST_TOO_SMALL;
     long n = n_in;
-    if (n <= 0 || (n & (n - 1)))
+    if (n <= 0)
         return ORC_ERR_LENGTH;
     double *re = malloc(sizeof(double) * n), *im = malloc(sizeof(double) * n);
     for (long i = 0; i < n; i++) {
         re[i] = in[2 * i];
         im[i] = in[2 * i + 1];
     }
+    if (n & (n - 1)) {
+        /* a length that is not a power of two (the reference's Planner takes any: fft/fft.go:45-48): the DFT
+         * as it is written, O(n^2), float64, the twiddle of n k taken from a table at (n k) mod N -- exact
+         * index arithmetic, so the only errors are the table's and the sums' roundings.  Test sizes only. */
+        double *wr = malloc(sizeof(double) * n), *wi = malloc(sizeof(double) * n);
+        double *xr = malloc(sizeof(double) * n), *xi = malloc(sizeof(double) * n);
+        const double sgn = forward ? -1.0 : 1.0;
+        for (long m = 0; m < n; m++) {
+            const double a = sgn * 6.283185307179586476925286766559 * (double)m / (double)n;
+            wr[m] = cos(a);
+            wi[m] = sin(a);
+            xr[m] = re[m];
+            xi[m] = im[m];
+        }
+        for (long k = 0; k < n; k++) {
+            double sr = 0, si = 0;
+            long idx = 0;
+            for (long m = 0; m < n; m++) {
+                sr += xr[m] * wr[idx] - xi[m] * wi[idx];
+                si += xr[m] * wi[idx] + xi[m] * wr[idx];
+                idx += k;
+                if (idx >= n)
+                    idx -= n;
+            }
+            re[k] = sr;
+            im[k] = si;
+        }
+        free(wr);
+        free(wi);
+        free(xr);
+        free(xi);
+    } else
     fft64(re, im, n, forward);
     for (long i = 0; i < n; i++) {
         out[2 * i] = (float)re[i];

@@ -621,6 +621,58 @@ def test_fft_against_float64(env, n):
     p.close()
 
 
+@pytest.mark.parametrize("n", [3, 5, 12, 1000, 1200, 1536, 4099, 3 << 10, 3 << 15, 100_003, (1 << 20) + 7])
+def test_fft_any_length_against_float64(env, n):
+    """fft.Planner takes whatever length its buffers have (fft/fft.go:45-48): lengths that are not powers of two run as
+    Bluestein's chirp transform over the power-of-two kernels.  Same tolerance as the power-of-two plans -- relative L2
+    <= 3e-7 * log2(N) + 1e-7 against numpy's float64 transform -- forward and (unnormalised) backward, batched."""
+    tol = 3e-7 * max(1, math.log2(n)) + 1e-7
+    batch = 3 if n <= 8192 else (2 if n <= (1 << 17) else 1)
+    x = rand_c64(n, n * batch)
+    X = np.fft.fft(x.astype(np.complex128).reshape(batch, n), axis=1).reshape(-1)
+    iq, fr = env.put(x), env.zeros("c64", n * batch)
+    p = env.ctx.fft_plan(iq, fr, env.hz.FFT_FORWARD, batch=batch)
+    p.transform()
+    p.transform()  # (a plan is used many times: the chirp tables and the scratch are the context's)
+    assert _rel_l2(env.get(fr), X) < tol
+    p.close()
+    Y = np.fft.ifft(x.astype(np.complex128).reshape(batch, n), axis=1).reshape(-1) * n  # unnormalised
+    fr, iq = env.put(x), env.zeros("c64", n * batch)
+    p = env.ctx.fft_plan(iq, fr, env.hz.FFT_BACKWARD, batch=batch)
+    p.transform()
+    assert _rel_l2(env.get(iq), Y) < tol
+    p.close()
+
+
+def test_fft_conformance_at_a_length_that_is_not_a_power_of_two(env, orc):
+    """testutils/fft.go:54-138 at N = 1000: a CW tone lands in its bin (forward), a single bin comes back as that bin
+    (backward then forward), mismatched lengths are refused."""
+    hz = env.hz
+    n, rate = 1000, 1000.0
+    for freq, idx in ((0.0, 0), (10.0, 10), (125.0, 125), (-10.0, 990), (499.0, 499)):
+        iq, out = env.put(orc.cw(n, freq, rate, 0.0)), env.zeros("c64", n)
+        p = env.ctx.fft_plan(iq, out, hz.FFT_FORWARD)
+        p.transform()
+        p.close()
+        assert int(np.argmax(np.abs(env.get(out).astype(np.complex128)))) == idx, freq
+    for b in (0, 1, 333, 999):
+        f = zeros("c64", n)
+        f[b] = 1 + 1j
+        fr, iq = env.put(f), env.zeros("c64", n)
+        p = env.ctx.fft_plan(iq, fr, hz.FFT_BACKWARD)
+        p.transform()
+        p.close()
+        fr2 = env.zeros("c64", n)
+        p = env.ctx.fft_plan(iq, fr2, hz.FFT_FORWARD)
+        p.transform()
+        p.close()
+        got = env.get(fr2).astype(np.complex128)
+        assert int(np.argmax(np.abs(got))) == b
+        assert abs(got[b] - n * (1 + 1j)) <= 2e-5 * n  # backward is unnormalised: the round trip scales by N
+    with pytest.raises(hz.ErrDstTooSmall):
+        env.ctx.fft_plan(env.zeros("c64", 1000), env.zeros("c64", 1001), hz.FFT_FORWARD)
+
+
 def test_fft_conformance_kats(env, orc, kats):
     """testutils/fft.go:54-138, the suite any Planner must pass."""
     hz = env.hz
@@ -656,7 +708,7 @@ def _lowpass_bins(n, taps=None):
     return np.fft.fft(h.astype(np.complex128) / n).astype(np.complex64)
 
 
-@pytest.mark.parametrize("flen", [4, 64, 1024, 2048, 8192])
+@pytest.mark.parametrize("flen", [4, 64, 1024, 2048, 8192, 1, 2, 3, 1000, 1200, 1536, 4099, 16384])
 def test_convolution_blocks_reference_semantics(env, orc, flen):
     """stream.ConvolutionReader: block-circular, no overlap; vs the oracle's
     float64-FFT restatement.  Tolerance: relative L2 <= 2e-6."""
@@ -696,7 +748,7 @@ def test_convolution_blocks_walk_far_more_blocks_than_the_grid_holds(env, orc, f
         assert _rel_l2(got[b * flen:(b + 1) * flen], want[i * flen:(i + 1) * flen]) < 2e-6, (flen, b)
 
 
-@pytest.mark.parametrize("n", [8, 1024, 32768])
+@pytest.mark.parametrize("n", [8, 1024, 32768, 1000, 4099])
 def test_convolve_closures(env, orc, n):
     hz = env.hz
     a, b = rand_c64(5, n), rand_c64(6, n)
@@ -954,6 +1006,40 @@ def test_chain_reference_convolution_then_decimate(env, orc):
     ch = env.ctx.chain(env.hz.FMT_U8, rate).shift(shift).convolution(env.put(H), decimate=D)
     out = env.zeros("c64", n // D)
     assert ch.run(env.put(x), out) == (n, n // D)
+    assert _rel_l2(env.get(out), want) < 2e-6
+    ch.close()
+
+
+@pytest.mark.parametrize("flen,D", [(1000, 8), (1200, 1), (4099, 4)])
+def test_chain_convolution_of_any_length_then_decimate(env, orc, flen, D):
+    """The same chain with a filter whose length is not a power of two (stream/convolution.go:57-61 blocks on
+    len(filter), whatever it is): i16 -> c64 -> Shift -> Gain -> ConvolutionReader(flen bins) [-> DecimateReader(D)].
+    With a DecimateReader behind it the chain consumes whole multiples of lcm(flen, 32 Ki) samples; a ragged tail is
+    left unconsumed.  Tolerance as above: relative L2 <= 2e-6 (the elementwise stages are bit-exact)."""
+    from math import gcd
+    rate, shift = 2_400_000, 3.1e5
+    blk = flen if D == 1 else flen * 32768 // gcd(flen, 32768)
+    n = blk + blk // 3
+    x = rand_i16(19, n)
+    H = _lowpass_bins(flen)
+    xc = zeros("c64", n)
+    orc.convert(xc, x)
+    ch = env.ctx.chain(env.hz.FMT_I16, rate).shift(shift).gain(0.5).convolution(env.put(H), decimate=D)
+    cons, outn = ch.plan(n)
+    assert cons == n // blk * blk and outn == (cons if D == 1 else cons // 32768 * (32768 // D))
+    orc.Shifter(rate)(shift, xc[:cons])
+    orc.scale(xc[:cons], 0.5)
+    conv = zeros("c64", cons)
+    assert orc.convolution_reader(conv, xc[:cons], H) == cons
+    if D == 1:
+        want = conv
+    else:
+        per = 32768 // D
+        want = zeros("c64", outn)
+        for b in range(cons // 32768):
+            orc.decimate(want[b * per:(b + 1) * per], conv[b * 32768:(b + 1) * 32768], D)
+    out = env.zeros("c64", outn)
+    assert ch.run(env.put(x), out) == (cons, outn)
     assert _rel_l2(env.get(out), want) < 2e-6
     ch.close()
 
