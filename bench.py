@@ -779,6 +779,34 @@ def small_buffers_gpu(hz, dctx, torch, device):
         torch.cuda.synchronize()
         row["device_us"] = round(e0.elapsed_time(e1) / 200 * 1e3, 2)
         rows[f"{name}_{n // 1024}Ki"] = row
+    # A Reader PIPELINE at the reference's block size: Gain(ShiftReader(ConvertReader(u8 source))), 2^22 samples read in
+    # 32 Ki-sample blocks through (a) the reference's own structure -- a ReadTransformer and two wrappers, three GPU calls
+    # per block -- and (b) the fusing constructors (go/hip/fused.go, stream.ChainReader): one chain, one launch per 2^20
+    # samples, the pinned ring reading ahead.  us per 32 Ki block, by the wall clock, Python's share included.
+    S = importlib.import_module("go-sdr_amd.stream")
+    nrd, blk = 1 << 22, 32 * 1024
+    xr = synth_u8(5, nrd)
+    row = {"samples": blk, "stream_samples": nrd}
+    for label, fuse in (("host_us", False), ("fused_us", True)):
+        best = None
+        for _ in range(3):
+            st = S.Stream(hctx, fuse=fuse)
+            r = st.gain(st.shift_reader(st.convert_reader(S.BufferReader(xr, 2_400_000), hz.FMT_C64), 3.1e5), 0.5)
+            buf = np.zeros(blk, np.complex64)
+            t0 = time.perf_counter()
+            got = 0
+            try:
+                while True:
+                    got += r.read(buf)
+            except S.EOF:
+                pass
+            dt = time.perf_counter() - t0
+            assert got == nrd, got
+            if hasattr(r, "close"):
+                r.close()
+            best = dt if best is None or dt < best else best
+        row[label] = round(best / (nrd // blk) * 1e6, 2)
+    rows["reader_chain_32Ki"] = row
     hctx.close()
     rows["note"] = ("us per call: host = HZSDR_MEM_HOST on pageable numpy buffers (copy in, kernel over the pinned "
                     "staging area, copy out; what a cgo caller with Go slices pays, plus ~2 us of ctypes), "
@@ -820,6 +848,17 @@ def small_buffers_cpu(orc, table):
             fn()
             t.append(time.perf_counter() - t0)
         table[f"{name}_{n // 1024}Ki"]["cpu_us"] = round(float(np.median(t)) * 1e6, 2)
+    if "reader_chain_32Ki" in table:  # the same pipeline's arithmetic on one core: convert, Shift, Gain over a 32 Ki block
+        blk = 32 * 1024
+        src, buf, sh = synth_u8(5, blk), np.zeros(blk, np.complex64), o.Shifter(2_400_000)
+        t = []
+        for _ in range(30):
+            t0 = time.perf_counter()
+            o.convert(buf, src)
+            sh(3.1e5, buf)
+            o.scale(buf, 0.5)
+            t.append(time.perf_counter() - t0)
+        table["reader_chain_32Ki"]["cpu_us"] = round(float(np.median(t)) * 1e6, 2)
 
 
 if __name__ == "__main__":

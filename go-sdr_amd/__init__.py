@@ -252,6 +252,12 @@ class Context:
     def synchronize(self):
         self._ck(lib.hzsdr_synchronize(self._h))
 
+    def call_count(self):
+        """hzsdr_call_count: library calls made on this context so far (Reader tests count calls per sample)."""
+        n = C.c_ulonglong(0)
+        self._ck(lib.hzsdr_call_count(self._h, C.byref(n)))
+        return n.value
+
     # -- sdr.ConvertBuffer (conv.go:55) --
     def convert(self, dst, src):
         n = C.c_size_t(0)
@@ -760,6 +766,10 @@ class Ring:
 
     def submit(self, slot, n=None):
         self.ctx._ck(lib.hzsdr_ring_submit(self._h, slot, self.slot_length if n is None else n))
+
+    def release(self, slot):
+        """The acquired slot, unused (hzsdr_ring_release)."""
+        self.ctx._ck(lib.hzsdr_ring_release(self._h, slot))
 
     def pop(self):
         p, n = C.c_void_p(), C.c_size_t(0)

@@ -84,6 +84,7 @@ SIGNATURES = {
     "hzsdr_use_own_stream": (i32, [vp]),
     "hzsdr_get_stream": (vp, [vp]),
     "hzsdr_synchronize": (i32, [vp]),
+    "hzsdr_call_count": (i32, [vp, C.POINTER(C.c_ulonglong)]),
     "hzsdr_malloc_device": (i32, [vp, sz, pvp]),
     "hzsdr_free_device": (i32, [vp, vp]),
     "hzsdr_malloc_pinned": (i32, [vp, sz, pvp]),
@@ -169,6 +170,7 @@ SIGNATURES = {
     "hzsdr_ring_iq_buffer": (i32, [vp, pvp, psz, psz]),
     "hzsdr_ring_acquire": (i32, [vp, C.POINTER(i32), pvp]),
     "hzsdr_ring_submit": (i32, [vp, i32, sz]),
+    "hzsdr_ring_release": (i32, [vp, i32]),
     "hzsdr_ring_pop": (i32, [vp, pvp, psz]),
     "hzsdr_ring_in_flight": (i32, [vp]),
     "hzsdr_ring_free": (i32, [vp]),

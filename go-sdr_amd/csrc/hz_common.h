@@ -25,6 +25,7 @@ struct hzsdr_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     int num_cus = 256;
+    unsigned long long calls = 0;  // hzsdr_call_count
     std::string last_error;
     // grow-only device scratch slots used to stage host buffers
     struct Slot {
@@ -93,6 +94,7 @@ inline int format_size(int f) {
 // between OS threads and HIP's current device is thread-local).
 inline int enter(hzsdr_ctx *ctx) {
     if (!ctx) return HZSDR_ERR_INVALID_ARGUMENT;
+    ctx->calls++;
     HZ_HIP(ctx, hipSetDevice(ctx->device));
     return HZSDR_OK;
 }

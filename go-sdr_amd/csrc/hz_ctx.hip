@@ -231,6 +231,12 @@ int hzsdr_synchronize(hzsdr_ctx *ctx) {
     return HZSDR_OK;
 }
 
+int hzsdr_call_count(const hzsdr_ctx *ctx, unsigned long long *calls) {
+    if (!ctx || !calls) return HZSDR_ERR_INVALID_ARGUMENT;
+    *calls = ctx->calls;
+    return HZSDR_OK;
+}
+
 int hzsdr_malloc_device(hzsdr_ctx *ctx, size_t bytes, void **out) {
     HZ_TRY(hz::enter(ctx));
     if (!out) return HZSDR_ERR_INVALID_ARGUMENT;

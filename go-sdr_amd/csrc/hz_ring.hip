@@ -171,6 +171,16 @@ int hzsdr_ring_submit(hzsdr_ring *r, int slot, size_t n) {
     return HZSDR_OK;
 }
 
+int hzsdr_ring_release(hzsdr_ring *r, int slot) {
+    using namespace hz;
+    if (!r || slot < 0 || slot >= r->nslots) return HZSDR_ERR_INVALID_ARGUMENT;
+    auto &s = r->slots[slot];
+    if (s.state != 1 || slot != (int)(r->widx % (size_t)r->nslots))
+        return fail(r->ctx, HZSDR_ERR_INVALID_ARGUMENT, "ring: release of a slot that is not the acquired one");
+    s.state = 0;
+    return HZSDR_OK;
+}
+
 int hzsdr_ring_pop(hzsdr_ring *r, const void **out, size_t *n_out) {
     using namespace hz;
     if (!r) return HZSDR_ERR_INVALID_ARGUMENT;

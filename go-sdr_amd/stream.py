@@ -21,7 +21,7 @@ import sys
 
 import numpy as np
 
-from . import (FMT_C64, FMT_I8, FMT_I16, FMT_U8, FFT_BACKWARD, FFT_FORWARD, Context,
+from . import (FMT_C64, FMT_I8, FMT_I16, FMT_U8, FFT_BACKWARD, FFT_FORWARD, Context, Ring,
                ErrDstTooSmall, ErrSampleFormatMismatch, ErrSampleFormatUnknown, HzsdrError,
                beamform_angles, beamform_angles_2d, fmt_of, format_size, length, make_samples)
 
@@ -278,15 +278,203 @@ class ByteWriter:
         return length(samples)
 
 
+class ChainReader(Reader):
+    """Nested stream.* Readers of this package as ONE Reader: the constructors below do not wrap a Reader that is
+    already one of ours -- they extend its chain (ConvertReader -> ShiftReader -> Gain -> Multiply -> DecimateReader /
+    DownsampleReader / ConvolutionReader collapse into one hzsdr_chain: one launch per slot) -- and the Reader reads
+    AHEAD: `readahead` Reader blocks of 32 Ki samples per slot of a pinned ring (hzsdr_ring_*: the source reads
+    straight into pinned memory, upload, kernel and download of neighbouring slots overlap).  The reference's
+    Readers make one call per 32 Ki-sample block (stream/convert.go:43-44, decimate.go:41-42); a GPU call of that size
+    is all latency (bench.py `small_buffers`: no faster than one CPU core).
+
+    What the reference's nesting means is kept (go/hip/readers.go has the same rules):
+      * the samples are those of the nested Readers bit for bit: the chain's stages are the reference's operations in
+        the reference's order, the block-structured stages (ConvertReader, DecimateReader, DownsampleReader: 32 Ki
+        blocks; ConvolutionReader: len(filter)) see the same blocks of the same stream, whatever the slot size is;
+      * a block-structured stage hands out whole blocks only: a source that ends inside a block loses that partial
+        block, as ReadFull's ErrUnexpectedEOF does in read_transformer.go:120-135; pass-through stages (ShiftReader,
+        Gain, Multiply over a c64 source) hand out whatever the source delivered;
+      * an error of the source is sticky and surfaces when everything read before it has been handed out.
+    What differs: the source is read up to `readahead` blocks ahead of the consumer (the reference reads one), and a
+    Multiply's SetMultiplier takes effect from the next slot, not the next Read."""
+
+    def __init__(self, stream, src, readahead=32, slots=3):
+        self.stream, self.ctx, self.src = stream, stream.ctx, src
+        self.src_fmt, self.rate = src.sample_format(), int(src.sample_rate())
+        self.stages = []        # ("shift", hz) | ("gain", v) | ("rotate", m)
+        self.terminal = None    # ("decimate", f) | ("downsample", f) | ("convolution", bins, decimate)
+        self.block = 1          # the stream is consumed in whole multiples of this many samples (1: any)
+        self.readahead, self.nslots = int(readahead), int(slots)
+        self.chain = self.ring = None
+        self.pending, self.off, self.err, self.inflight = None, 0, None, 0
+        self.converted = False
+        self.queue = []  # outputs drained from a ring that a changed multiplier made us rebuild
+
+    # ---- construction: each returns the Reader to use (self, extended) or None if the stage does not fit ----
+    def _open(self):
+        return self.chain is None and self.terminal is None
+
+    def extend_convert(self, to):
+        # ConvertReader(r, c64): the chain converts on its way in; it makes the stream block-structured
+        if not self._open() or to != FMT_C64 or self.stages or self.src_fmt == FMT_C64:
+            return None
+        self.block = max(self.block, READER_BLOCK)
+        self.converted = True
+        return self
+
+    def _c64_here(self):
+        return self.src_fmt == FMT_C64 or self.converted
+
+    def extend_op(self, op):
+        if not self._open() or not self._c64_here():
+            return None
+        self.stages.append(op)
+        return self
+
+    def extend_terminal(self, term, block):
+        if not self._open() or not self._c64_here():
+            return None
+        self.terminal, self.block = term, _lcm(self.block, block)
+        if term[0] in ("decimate", "downsample"):
+            self.rate //= term[1]
+        return self
+
+    def extend_decimate_after_convolution(self, factor):
+        if self.chain is not None or self.terminal is None or self.terminal[0] != "convolution" or self.terminal[2] != 1:
+            return None
+        # (only where the filter's blocks tile the DecimateReader's: the nest hands out floor(n / 32 Ki) blocks then, as
+        # the fused chain does; any other length would make the chain consume whole multiples of lcm(len, 32 Ki) and
+        # drop more of a stream's tail than the nest -- such a DecimateReader becomes a second chain behind this one)
+        if READER_BLOCK % len(self.terminal[1]) != 0:
+            return None
+        self.terminal = ("convolution", self.terminal[1], factor)
+        self.block = _lcm(self.block, READER_BLOCK)
+        self.rate //= factor
+        return self
+
+    def sample_format(self):
+        return FMT_C64 if self._c64_here() else self.src_fmt
+
+    def sample_rate(self):
+        return self.rate
+
+    def set_multiplier(self, m):
+        """stream/multiply.go:34-36 for the chain's (last) Multiply stage.  What has been read ahead keeps the old
+        multiplier; the slots filled from now on take the new one: the chain is rebuilt at the clock it has reached."""
+        idx = [i for i, st in enumerate(self.stages) if st[0] == "rotate"]
+        if not idx:
+            raise HzsdrError("ChainReader.set_multiplier: the chain has no Multiply stage")
+        self.stages[idx[-1]] = ("rotate", complex(m))
+        if self.chain is None:
+            return
+        while self.inflight:  # what is in flight was multiplied by the old value: keep it, in order
+            self.queue.append(np.array(self.ring.pop(), copy=True))
+            self.inflight -= 1
+        if self.pending is not None and self.off < len(self.pending):
+            self.queue.insert(0, np.array(self.pending[self.off:], copy=True))
+        self.pending, self.off = None, 0
+        ts = self.chain.time()
+        self.ring.close()
+        self.chain.close()
+        self.chain = self.ring = None
+        self._build()
+        self.chain.set_time(ts)
+
+    # ---- the data path ----
+    def _build(self):
+        ch = self.ctx.chain(self.src_fmt, self.src.sample_rate())
+        for kind, v in self.stages:
+            ch = ch.shift(v) if kind == "shift" else ch.gain(v) if kind == "gain" else ch.rotate(v)
+        t = self.terminal
+        if t is not None:
+            ch = ch.decimate(t[1]) if t[0] == "decimate" else ch.downsample(t[1]) if t[0] == "downsample" else ch.convolution(t[1], decimate=t[2])
+        self.chain = ch
+        unit = self.block if self.block > 1 else READER_BLOCK
+        per = max(1, self.readahead * READER_BLOCK // unit) * unit  # a slot: whole blocks, about `readahead` Reader blocks
+        cons, _ = ch.plan(per)
+        assert cons == per, (cons, per)
+        self.slot_len = per
+        self.ring = Ring(ch, per, self.nslots)
+
+    def _fill_one(self):
+        """Read the source into the next pinned slot and submit it.  False: nothing more comes."""
+        if self.err is not None:
+            return False
+        slot, iq = self.ring.acquire()
+        n = 0
+        try:
+            while n < self.slot_len:
+                n += self.src.read(iq[n:])
+        except (EOF, HzsdrError) as e:
+            self.err = e
+        n = n // self.block * self.block  # a block-structured stage: whole blocks only
+        if n == 0:
+            self.ring.release(slot)
+            return False
+        self.ring.submit(slot, n)
+        self.inflight += 1
+        return True
+
+    def read(self, samples):
+        if fmt_of(samples) != self.sample_format():
+            raise ErrSampleFormatMismatch("sdr: iq sample formats do not match")
+        if self.chain is None:
+            self._build()
+        if (self.pending is None or self.off >= len(self.pending)) and self.queue:
+            self.pending, self.off = self.queue.pop(0), 0
+        if self.pending is None or self.off >= len(self.pending):
+            # keep the ring busy: everything but the slot being consumed is in flight
+            while self.inflight < self.nslots - 1 and self._fill_one():
+                pass
+            if self.inflight == 0:
+                raise self.err if self.err is not None else EOF()
+            self.pending, self.off = self.ring.pop(), 0
+            self.inflight -= 1
+            if len(self.pending) == 0:
+                return 0
+        n = min(len(self.pending) - self.off, length(samples))
+        samples[:n] = self.pending[self.off:self.off + n]
+        self.off += n
+        return n
+
+    def close(self):
+        if self.ring is not None:
+            self.ring.close()
+        if self.chain is not None:
+            self.chain.close()
+        self.ring = self.chain = None
+
+
+def _lcm(a, b):
+    from math import gcd
+    return a // gcd(a, b) * b
+
+
 class Stream:
     """The operators, bound to one GPU context (the reference's package-level
     functions take no context; a cgo shim would hold a package-level one)."""
 
-    def __init__(self, ctx: Context):
-        self.ctx = ctx
+    def __init__(self, ctx: Context, fuse=False, readahead=32):
+        # fuse: nested Readers collapse into one ChainReader that reads `readahead` Reader blocks ahead through a pinned
+        # ring (what go/hip/readers.go does by default); off, every constructor is the reference's own structure -- a
+        # ReadTransformer per block-structured stage, a wrapper per pass-through stage, one call per 32 Ki block
+        self.ctx, self.fuse, self.readahead = ctx, bool(fuse), int(readahead)
+
+    def _fused(self, r, how):
+        """r as a ChainReader extended by `how(chain_reader)`, or None when the stage cannot join a chain."""
+        if not self.fuse:
+            return None
+        cr = r if isinstance(r, ChainReader) else ChainReader(self, r, self.readahead)
+        got = how(cr)
+        if got is None and cr is r:  # r's chain is closed (it has its terminal, or has run): a new chain behind it
+            got = how(ChainReader(self, r, self.readahead))
+        return got
 
     # stream.ConvertReader, stream/convert.go:37-51
     def convert_reader(self, inp, to):
+        f = self._fused(inp, lambda c: c.extend_convert(to))
+        if f is not None:
+            return f
         return ReadTransformer(inp, READER_BLOCK, READER_BLOCK, to, inp.sample_rate(),
                                lambda i, o: self.ctx.convert(o, i))
 
@@ -296,6 +484,14 @@ class Stream:
 
     # stream.DecimateReader, stream/decimate.go:34-55
     def decimate_reader(self, inp, factor):
+        if self.fuse and isinstance(inp, ChainReader):
+            f = inp.extend_decimate_after_convolution(factor) or inp.extend_terminal(("decimate", factor), READER_BLOCK)
+            if f is not None:
+                return f
+        elif inp.sample_format() == FMT_C64:
+            f = self._fused(inp, lambda c: c.extend_terminal(("decimate", factor), READER_BLOCK))
+            if f is not None:
+                return f
         state = {"offset": 0}
 
         def proc(i, o):
@@ -307,6 +503,15 @@ class Stream:
 
     # stream.DownsampleReader, stream/downsample.go:47-64
     def downsample_reader(self, inp, factor):
+        # (a raw u8 / i16 source: DownsampleReader converts by itself -- the chain does the same on its way in)
+        if self.fuse and (isinstance(inp, ChainReader) or inp.sample_format() in (FMT_C64, FMT_U8, FMT_I16)):
+            def how(c):
+                if not c._c64_here():
+                    c.converted = True  # DownsampleBuffer's own conversion (stream/downsample.go:99-124)
+                return c.extend_terminal(("downsample", factor), READER_BLOCK)
+            f = self._fused(inp, how)
+            if f is not None:
+                return f
         state = {"offset": 0}
 
         def proc(i, o):
@@ -320,16 +525,26 @@ class Stream:
     def shift_reader(self, r, shift_hz):
         if r.sample_format() != FMT_C64:
             raise ErrSampleFormatUnknown("sdr: iq sample format is not understood")
+        f = self._fused(r, lambda c: c.extend_op(("shift", float(shift_hz))))
+        if f is not None:
+            return f
         return _ShiftReader(self.ctx, r, shift_hz)
 
     # stream.Gain, stream/gain.go:30-57
     def gain(self, r, v):
+        if r.sample_format() == FMT_C64:
+            f = self._fused(r, lambda c: c.extend_op(("gain", float(v))))
+            if f is not None:
+                return f
         return _GainReader(self.ctx, r, v)
 
     # stream.Multiply, stream/multiply.go:74-89
     def multiply(self, r, m):
         f = r.sample_format()
         if f == FMT_C64:
+            fr = self._fused(r, lambda c: c.extend_op(("rotate", complex(m)))) if complex(m) != 1 else None
+            if fr is not None:
+                return fr
             return _MultiplyReader(self.ctx, r, m)
         if f in (FMT_U8, FMT_I8):
             return _TableMultiplyReader(self.ctx, r, m)
@@ -357,6 +572,9 @@ class Stream:
             raise ErrSampleFormatUnknown("sdr: iq sample format is not understood")
         flen = len(filter_bins)
         filt = np.ascontiguousarray(filter_bins, np.complex64)
+        f = self._fused(r, lambda c: c.extend_terminal(("convolution", filt, 1), flen))
+        if f is not None:
+            return f
         iq = make_samples(FMT_C64, flen)
         conv = self.ctx.convolve_freq(iq, iq, filt)  # fft.ConvolveFreq(planner, iq, iq, filter)
 
@@ -524,6 +742,6 @@ class Beamform(Reader):
         return length(s)
 
 
-__all__ = ["Reader", "BufferReader", "ReadTransformer", "Stream", "Beamform", "read_full",
+__all__ = ["Reader", "BufferReader", "ReadTransformer", "Stream", "Beamform", "ChainReader", "read_full",
            "read_at_least", "EOF", "ErrShortBuffer", "ErrUnexpectedEOF", "READER_BLOCK",
            "beamform_angles", "beamform_angles_2d"]

@@ -92,6 +92,14 @@ func (x *Context) UseOwnStream() error { return toErr(x.c, C.hzsdr_use_own_strea
 func (x *Context) Stream() unsafe.Pointer { return C.hzsdr_get_stream(x.c) }
 
 // Synchronize waits for everything enqueued so far.
+// CallCount reports how many calls of the library have run on this context so far (hzsdr_call_count): tests and logs
+// count the calls a Reader pipeline makes per sample with it.
+func (x *Context) CallCount() (uint64, error) {
+	var n C.ulonglong
+	rc := C.hzsdr_call_count(x.c, &n)
+	return uint64(n), toErr(x.c, rc)
+}
+
 func (x *Context) Synchronize() error { return toErr(x.c, C.hzsdr_synchronize(x.c)) }
 
 // MallocDevice / FreeDevice: device memory for MemDevice contexts.

@@ -7,11 +7,13 @@ import "C"
 
 import (
 	"fmt"
+	"unsafe"
 
 	"hz.tools/rf"
 	"hz.tools/sdr"
 	"hz.tools/sdr/fft"
 	"hz.tools/sdr/stream"
+	"hz.tools/sdr/yikes"
 )
 
 // Readers has the reference's stream.* Reader constructors, name for name and argument for
@@ -26,12 +28,39 @@ import (
 // pull-style Read for Shift / Gain / Multiply / Add, the same ReadTransformer scaffold with
 // 32 Ki-sample blocks for Decimate / Downsample and filter-length blocks for Convolution);
 // only the buffer arithmetic runs on the GPU. A 32 Ki block is launch-bound (INTEGRATION.md,
-// "What the drop-in costs"): pipelines that care about throughput fuse their stages with
-// Context.NewChain and feed it blocks of 2^20 samples or the pinned ring.
-type Readers struct{ x *Context }
+// "What the drop-in costs"), so by default the constructors FUSE: handed a Reader that one of them made, they extend
+// its chain instead of wrapping it, and the resulting Reader reads ahead through a pinned ring -- one launch per
+// ReadAhead x 32 Ki samples for the whole nest (fused.go: what is kept of the reference's semantics, what differs).
+// ReadersUnfused keeps the reference's own structure, one call per block and stage.
+type Readers struct {
+	x         *Context
+	fuse      bool
+	readAhead int // Reader blocks of 32 Ki samples per slot of a fused Reader's ring
+}
 
-// Readers returns the constructor set bound to this context.
-func (x *Context) Readers() Readers { return Readers{x} }
+// Readers returns the constructor set bound to this context: nested Readers fuse and read 32 blocks (2^20 samples) ahead.
+func (x *Context) Readers() Readers { return Readers{x: x, fuse: true, readAhead: 32} }
+
+// ReadersUnfused returns the constructors in the reference's own structure: a ReadTransformer per block-structured
+// stage, a wrapper per pass-through stage, one GPU call per 32 Ki-sample block and stage.
+func (x *Context) ReadersUnfused() Readers { return Readers{x: x} }
+
+// ReadAhead sets how many 32 Ki-sample Reader blocks a fused Reader reads ahead of its consumer (at least 1).
+func (s Readers) ReadAhead(blocks int) Readers {
+	if blocks < 1 {
+		blocks = 1
+	}
+	s.readAhead = blocks
+	return s
+}
+
+// ConvertReader is stream.ConvertReader (stream/convert.go:30-57); to c64 it opens (or joins) a fused chain.
+func (s Readers) ConvertReader(in sdr.Reader, to sdr.SampleFormat) (sdr.Reader, error) {
+	if cr := s.fused(in, func(c *chainReader) bool { return c.extendConvert(to) }); cr != nil {
+		return cr, nil
+	}
+	return s.x.ConvertReader(in, to)
+}
 
 // ---- stream.ShiftReader (stream/shifter.go:89-102) ----------------------------------------
 
@@ -65,6 +94,9 @@ func (sr *shiftReader) Close() error { return sr.sh.Close() }
 func (s Readers) ShiftReader(r sdr.Reader, shift rf.Hz) (sdr.Reader, error) {
 	if r.SampleFormat() != sdr.SampleFormatC64 {
 		return nil, sdr.ErrSampleFormatUnknown
+	}
+	if cr := s.fused(r, func(c *chainReader) bool { return c.extendStage(chainStage{kind: 0, shift: shift}) }); cr != nil {
+		return cr, nil
 	}
 	sh, err := s.x.NewShifter(r.SampleRate())
 	if err != nil {
@@ -102,7 +134,14 @@ func (g *gain) Read(s sdr.Samples) (int, error) {
 }
 
 // Gain is stream.Gain (stream/gain.go:30).
-func (s Readers) Gain(r sdr.Reader, v float32) sdr.Reader { return &gain{x: s.x, v: v, r: r} }
+func (s Readers) Gain(r sdr.Reader, v float32) sdr.Reader {
+	if r.SampleFormat() == sdr.SampleFormatC64 {
+		if cr := s.fused(r, func(c *chainReader) bool { return c.extendStage(chainStage{kind: 1, gain: v}) }); cr != nil {
+			return cr
+		}
+	}
+	return &gain{x: s.x, v: v, r: r}
+}
 
 // ---- stream.Multiply (stream/multiply.go:27-238) ------------------------------------------
 
@@ -178,6 +217,13 @@ func (s Readers) Multiply(r sdr.Reader, m complex64) (sdr.Reader, error) {
 		}
 		return &tableMultiplyReader{t: t, r: r}, nil
 	case sdr.SampleFormatC64:
+		// (a multiplier of exactly 1 is the reference's short cut, stream/multiply.go:59-62 -- and ReadBeamform's
+		// first weight: such a Reader stays a wrapper, it has nothing to launch)
+		if m != 1 {
+			if cr := s.fused(r, func(c *chainReader) bool { return c.extendStage(chainStage{kind: 2, mult: m}) }); cr != nil {
+				return cr, nil
+			}
+		}
 		return &multiplyReader{x: s.x, r: r, m: m}, nil
 	default:
 		return nil, sdr.ErrSampleFormatUnknown
@@ -192,6 +238,21 @@ type addReader struct {
 	sampleRate   uint
 	readers      []sdr.Reader
 	err          error
+	// The K temporaries of a Read: the reference allocates them anew with sdr.MakeSamples on every call
+	// (stream/add.go:133-141) -- pageable memory, so each costs the GPU path a staging copy as well.  Here they are
+	// allocated ONCE, pinned (hzsdr_malloc_pinned: the kernel reads them in place), and grow with the largest Read.
+	buffers []sdr.Samples
+	pinned  []unsafe.Pointer
+	bufLen  int
+}
+
+// Close releases the pinned temporaries (the reference's are garbage collected).
+func (ar *addReader) Close() error {
+	for _, p := range ar.pinned {
+		_ = ar.x.FreePinned(p)
+	}
+	ar.pinned, ar.buffers, ar.bufLen = nil, nil, 0
+	return nil
 }
 
 func (ar *addReader) SampleFormat() sdr.SampleFormat { return ar.sampleFormat }
@@ -208,15 +269,29 @@ func (ar *addReader) Read(s sdr.Samples) (int, error) {
 	default:
 		return 0, sdr.ErrSampleFormatUnknown
 	}
+	if ar.buffers == nil || ar.bufLen < s.Length() {
+		_ = ar.Close()
+		ar.buffers = make([]sdr.Samples, len(ar.readers))
+		for i := range ar.readers {
+			p, err := ar.x.MallocPinned(s.Format().Size() * s.Length())
+			if err != nil {
+				ar.err = err
+				return 0, err
+			}
+			ar.pinned = append(ar.pinned, p)
+			b, err := yikes.Samples(uintptr(p), s.Length(), s.Format()) // yikes/bytes.go:50-71: C-owned memory as sdr.Samples
+			if err != nil {
+				ar.err = err
+				return 0, err
+			}
+			ar.buffers[i] = b
+		}
+		ar.bufLen = s.Length()
+	}
 	buffers := make([]sdr.Samples, len(ar.readers))
 	for i, reader := range ar.readers {
-		var err error
-		buffers[i], err = sdr.MakeSamples(s.Format(), s.Length())
-		if err != nil {
-			ar.err = err
-			return 0, err
-		}
-		if _, err = sdr.ReadFull(reader, buffers[i]); err != nil {
+		buffers[i] = ar.buffers[i].Slice(0, s.Length())
+		if _, err := sdr.ReadFull(reader, buffers[i]); err != nil {
 			ar.err = err
 			return 0, err
 		}
@@ -262,6 +337,12 @@ func (s Readers) Add(readers ...sdr.Reader) (sdr.Reader, error) {
 // DecimateReader is stream.DecimateReader: 32 Ki-sample blocks, the offset counted (and, as in
 // the reference, ignored by DecimateBuffer: the phase restarts with every block).
 func (s Readers) DecimateReader(in sdr.Reader, factor uint) (sdr.Reader, error) {
+	// (the chain's stream is c64: DecimateReader keeps its input's format, so only a c64 stream joins a chain)
+	if in.SampleFormat() == sdr.SampleFormatC64 && factor > 0 {
+		if cr := s.fused(in, func(c *chainReader) bool { return c.extendTerminal(chainTerm{kind: 1, factor: factor}, readerBlock) }); cr != nil {
+			return cr, nil
+		}
+	}
 	offset := 0
 	return stream.ReadTransformer(in, stream.ReadTransformerConfig{
 		InputBufferLength:  32 * 1024,
@@ -278,6 +359,19 @@ func (s Readers) DecimateReader(in sdr.Reader, factor uint) (sdr.Reader, error) 
 
 // DownsampleReader is stream.DownsampleReader: the boxcar mean of `factor` samples, c64 out.
 func (s Readers) DownsampleReader(in sdr.Reader, factor uint) (sdr.Reader, error) {
+	switch in.SampleFormat() {
+	case sdr.SampleFormatC64, sdr.SampleFormatU8, sdr.SampleFormatI16:
+		if factor > 0 {
+			if cr := s.fused(in, func(c *chainReader) bool {
+				if !c.c64Here() && c.open() && len(c.stages) == 0 {
+					c.converted = true // DownsampleBuffer converts by itself (stream/downsample.go:99-124): so does the chain
+				}
+				return c.extendTerminal(chainTerm{kind: 2, factor: factor}, readerBlock)
+			}); cr != nil {
+				return cr, nil
+			}
+		}
+	}
 	offset := 0
 	return stream.ReadTransformer(in, stream.ReadTransformerConfig{
 		InputBufferLength:  32 * 1024,
@@ -311,6 +405,11 @@ func (s Readers) ConvolutionReader(r sdr.Reader, planner fft.Planner, filter []c
 	if fftLength < 1 || (fftLength&(fftLength-1) == 0 && fftLength > 1<<24) || (fftLength&(fftLength-1) != 0 && fftLength > 1<<23) {
 		return nil, fmt.Errorf("hip.ConvolutionReader: filter length %d: 1 ... 2^24 (a power of two) or 1 ... 2^23 (any other)", fftLength)
 	}
+	if cr := s.fused(r, func(c *chainReader) bool {
+		return c.extendTerminal(chainTerm{kind: 3, filter: append([]complex64(nil), filter...), decimate: 1}, fftLength)
+	}); cr != nil {
+		return cr, nil
+	}
 	return stream.ReadTransformer(r, stream.ReadTransformerConfig{
 		InputBufferLength:  fftLength,
 		OutputBufferLength: fftLength,
@@ -329,6 +428,10 @@ func (s Readers) ConvolutionReader(r sdr.Reader, planner fft.Planner, filter []c
 		},
 	})
 }
+
+// ReadersUnfusedHere: the same context's constructors without fusion (ReadBeamform composes ConvertReader -> Multiply ->
+// Add per channel and SetPhaseAngles must take effect at the next Read: stream/beamform.go:131-139).
+func (s Readers) ReadersUnfusedHere() Readers { return Readers{x: s.x} }
 
 // ---- stream.ReadBeamform (stream/beamform.go:131-171) -------------------------------------
 
@@ -357,11 +460,11 @@ func (b *Beamform) SetPhaseAngles(angles []complex64) error {
 func (s Readers) ReadBeamform(rs sdr.Readers, cfg stream.BeamformConfig) (*Beamform, error) {
 	multReaders := make(sdr.Readers, len(rs))
 	for i := range rs {
-		reader, err := s.x.ConvertReader(rs[i], sdr.SampleFormatC64)
+		reader, err := s.ReadersUnfusedHere().ConvertReader(rs[i], sdr.SampleFormatC64)
 		if err != nil {
 			return nil, err
 		}
-		multReaders[i], err = s.Multiply(reader, 1)
+		multReaders[i], err = s.ReadersUnfusedHere().Multiply(reader, 1)
 		if err != nil {
 			return nil, err
 		}

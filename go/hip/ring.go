@@ -62,6 +62,9 @@ func (g *Ring) Submit(slot, n int) error {
 	return toErr(g.ch.x.c, C.hzsdr_ring_submit(g.r, C.int(slot), C.size_t(n)))
 }
 
+// Release gives the acquired slot back unused: the source had nothing for it (hzsdr_ring_release).
+func (g *Ring) Release(slot int) error { return toErr(g.ch.x.c, C.hzsdr_ring_release(g.r, C.int(slot))) }
+
 // Pop waits for the oldest slot in flight; the returned samples are pinned memory, valid
 // until that slot is submitted again.
 func (g *Ring) Pop() (sdr.SamplesC64, error) {

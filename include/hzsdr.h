@@ -92,6 +92,11 @@ int hzsdr_use_own_stream(hzsdr_ctx *ctx);
 void *hzsdr_get_stream(const hzsdr_ctx *ctx);
 /* Block until everything enqueued on the context's stream has finished. */
 int hzsdr_synchronize(hzsdr_ctx *ctx);
+/* How many calls of this library have selected the context's device so far -- every entry point that runs or
+ * enqueues GPU work, allocates or synchronises does, once -- for tests and logs that count how many calls a Reader
+ * pipeline makes per sample (go/hip/readers.go: nested Readers fuse into one chain and read ahead; a pipeline that
+ * makes one call per 32 Ki-sample block is bound by the call's latency, not by the GPU).  No reference counterpart. */
+int hzsdr_call_count(const hzsdr_ctx *ctx, unsigned long long *calls);
 
 /* C-owned buffers for Go to wrap with yikes.Samples (yikes/bytes.go:50-71) or
  * to hand out from RingBufferOptions.IQBufferAllocator (stream/ring.go:60-68). */
@@ -526,6 +531,10 @@ int hzsdr_ring_acquire(hzsdr_ring *r, int *slot, void **iq);
 /* The acquired slot holds n samples: enqueue its upload, kernel and download.
  * Returns without waiting. */
 int hzsdr_ring_submit(hzsdr_ring *r, int slot, size_t n);
+/* Give the acquired slot back unused (the source had nothing for it: the end of a stream): the next
+ * hzsdr_ring_acquire hands out the same slot.  No reference counterpart (stream.RingBuffer's writer simply does not
+ * advance: stream/ring.go:337-392). */
+int hzsdr_ring_release(hzsdr_ring *r, int slot);
 /* Read cursor: wait for the oldest submitted slot; *out (pinned, complex64,
  * *n_out samples) stays valid until that slot is submitted again.
  * INVALID_ARGUMENT when nothing is in flight (the underrun case). */

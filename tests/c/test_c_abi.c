@@ -282,6 +282,14 @@ static void chain_and_ring(void) { /* go/hip/stream.go Chain, go/hip/ring.go */
         for (int i = 0; i < 2 * (N / D); i++) CHECK(fabsf(y2[i] - y[i]) <= 2e-6f);
     }
     free(y2);
+    {
+        unsigned long long before = 0, after = 0;
+        OK(hzsdr_call_count(ctx, &before));
+        OK(hzsdr_chain_reset(c));
+        OK(hzsdr_call_count(ctx, &after));
+        CHECK(after == before + 1);
+        CHECK(hzsdr_call_count(ctx, NULL) == HZSDR_ERR_INVALID_ARGUMENT);
+    }
     OK(hzsdr_chain_set_time(c, 1.0));
     OK(hzsdr_chain_reset(c));
     /* the ring: ONE pinned region for all slots (IQBufferAllocator), acquire / fill / submit / pop */
@@ -300,6 +308,12 @@ static void chain_and_ring(void) { /* go/hip/stream.go Chain, go/hip/ring.go */
         OK(hzsdr_ring_submit(r, slot, slot_len));
     }
     CHECK(hzsdr_ring_in_flight(r) == 4);
+    {   /* every slot in flight: nothing to acquire, nothing to release */
+        int slot = -1;
+        void *iq = NULL;
+        CHECK(hzsdr_ring_acquire(r, &slot, &iq) == HZSDR_ERR_DST_TOO_SMALL);
+        CHECK(hzsdr_ring_release(r, 0) == HZSDR_ERR_INVALID_ARGUMENT);
+    }
     for (int k = 0; k < 4; k++) {
         const void *o = NULL;
         size_t no = 0;
@@ -307,6 +321,15 @@ static void chain_and_ring(void) { /* go/hip/stream.go Chain, go/hip/ring.go */
         CHECK(no == slot_len / D);
         /* the stream through the ring equals the synchronous run of the same samples */
         if (k == 0) CHECK(memcmp(o, y, 64) != 0 || 1);
+    }
+    {   /* a slot acquired and given back unused: the next acquire hands out the same one */
+        int slot = -1, again = -2;
+        void *iq = NULL;
+        OK(hzsdr_ring_acquire(r, &slot, &iq));
+        OK(hzsdr_ring_release(r, slot));
+        OK(hzsdr_ring_acquire(r, &again, &iq));
+        CHECK(again == slot);
+        OK(hzsdr_ring_release(r, again));
     }
     OK(hzsdr_ring_free(r));
     OK(hzsdr_chain_free(c));
@@ -379,8 +402,14 @@ static void readers(void) {
     OK(hzsdr_convolution_blocks(ctx, fout, 1024, blk, 1024, filt, 1024, &n));
     CHECK(n == 1024);
     for (int i = 0; i < 2048; i++) CHECK(fabsf(fout[i] - blk[i]) < 1e-4f);
+    /* a filter whose length is not a power of two (stream/convolution.go:57-61 blocks on len(filter), whatever it is:
+     * Bluestein's chirp transform over the power-of-two kernels): an all-pass filter of 1000 bins gives the block back */
+    for (int i = 0; i < 1000; i++) filt[2 * i] = 1.0f / 1000.0f;
+    OK(hzsdr_convolution_blocks(ctx, fout, 1000, blk, 1000, filt, 1000, &n));
+    CHECK(n == 1000);
+    for (int i = 0; i < 2000; i++) CHECK(fabsf(fout[i] - blk[i]) < 1e-4f);
     /* the lengths hip.ConvolutionReader refuses at construction (go/hip/readers.go) are the ones the C call refuses */
-    CHECK(hzsdr_convolution_blocks(ctx, fout, 1000, blk, 1000, filt, 1000, &n) == HZSDR_ERR_INVALID_ARGUMENT);
+    CHECK(hzsdr_convolution_blocks(ctx, fout, 0, blk, 0, filt, 0, &n) == HZSDR_ERR_INVALID_ARGUMENT);
     /* ConvertWriter.Write (stream/convert.go:84-113, go/hip/stream.go): a Write of 2 B + 5 c64 samples into a u8
      * Writer is three ConvertBuffer calls of at most 32 Ki samples into the writer's buffer, each handed on
      * whole; a Write of another format is ErrSampleFormatMismatch before anything is converted */

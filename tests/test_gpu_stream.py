@@ -308,3 +308,130 @@ def test_plain_c_abi_walkthrough():
     p = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "c-abi ok" in p.stdout
+
+
+# ---- round 5: nested Readers that fuse into one chain and read ahead (go/hip/fused.go, stream.ChainReader) ---------
+
+@pytest.fixture(scope="module")
+def fst(hz, S):
+    ctx = hz.Context(0, hz.MEM_HOST)
+    yield S.Stream(ctx, fuse=True, readahead=32)
+    ctx.close()
+
+
+def _drain(S, r, chunk, hz):
+    """Read r to its end in chunks of `chunk` samples -> (all the samples, the error that ended it)."""
+    got = []
+    buf = hz.make_samples(r.sample_format(), chunk)
+    while True:
+        try:
+            n = r.read(buf)
+        except (S.EOF, hz.HzsdrError) as e:
+            return (np.concatenate(got) if got else buf[:0].copy()), e
+        got.append(buf[:n].copy())
+
+
+def test_nested_readers_fuse_into_one_chain_and_read_ahead(hz, S, st, fst, orc):
+    """Gain(ShiftReader(ConvertReader(src))) over 2^24 u8 samples: with the fusing constructors the three Readers are ONE
+    chain behind a pinned ring -- at most 2^24 / 2^20 launches' worth of calls (counted: hzsdr_call_count), the samples
+    the reference's nest gives bit for bit (the oracle's convert -> Shift -> Gain over the whole stream), read through a
+    consumer that asks for awkward amounts.  The partial last block of the source is dropped as ConvertReader's ReadFull
+    drops it (stream/read_transformer.go:120-135), and the stream ends in EOF."""
+    n, rate, shift, gain = (1 << 24) + 12_345, 2_400_000, 3.1e5, 0.5
+    x = rand_u8(31, n)
+    whole = n // S.READER_BLOCK * S.READER_BLOCK
+    want = zeros("c64", whole)
+    orc.convert(want, x[:whole])
+    orc.Shifter(rate)(shift, want)
+    orc.scale(want, gain)
+    r = fst.gain(fst.shift_reader(fst.convert_reader(S.BufferReader(x, rate, max_read=100_003), hz.FMT_C64), shift), gain)
+    assert isinstance(r, S.ChainReader) and r.sample_format() == hz.FMT_C64 and r.sample_rate() == rate
+    check_reader_contract(hz, S, r)
+    before = fst.ctx.call_count()
+    got, err = _drain(S, r, 77_777, hz)
+    calls = fst.ctx.call_count() - before
+    assert isinstance(err, S.EOF)
+    assert len(got) == whole and bits_equal(got, want)
+    slots = -(-whole // (32 * S.READER_BLOCK))
+    # per slot: acquire, submit, pop (+ the chain's and the ring's construction): far below one call per 32 Ki block
+    assert calls <= 3 * slots + 16, (calls, slots)
+    assert calls < whole // S.READER_BLOCK // 4
+    r.close()
+
+
+@pytest.mark.parametrize("kind", ["convert_decimate", "c64_shift_gain_ragged", "downsample_i16", "convolution_decimate",
+                                  "convolution1024_decimate", "multiply_then_more", "decimate_then_gain"])
+def test_fused_readers_equal_the_nested_ones(hz, S, st, fst, kind):
+    """Every fusable nest against the SAME nest built with the unfused constructors (the reference's own structure:
+    one ReadTransformer / wrapper and one GPU call per stage and block): the same samples bit for bit, the same end of
+    stream -- sources that end inside a block, sources that deliver in dribbles, consumers that read odd amounts."""
+    rate = 2_400_000
+    rng = np.random.default_rng(5)
+
+    def nest(s, src):
+        if kind == "convert_decimate":          # DecimateReader(Multiply(ConvertReader(i16)))
+            return s.decimate_reader(s.multiply(s.convert_reader(src, hz.FMT_C64), 0.6 + 0.8j), 5)
+        if kind == "c64_shift_gain_ragged":     # pass-through stages over c64: no block structure at all
+            return s.gain(s.shift_reader(src, -123_456.0), 1.5)
+        if kind == "downsample_i16":            # DownsampleReader converts by itself
+            return s.downsample_reader(src, 8)
+        if kind in ("convolution_decimate", "convolution1024_decimate"):  # DecimateReader(ConvolutionReader(ShiftReader(c64)))
+            L = 1000 if kind == "convolution_decimate" else 1024  # (1000 bins: the DecimateReader is a second chain)
+            t = np.arange(L) - (L - 1) / 2
+            H = np.fft.fft((np.sinc(t / 8) / 8 * np.hamming(L)).astype(np.complex128) / L).astype(np.complex64)
+            return s.decimate_reader(s.convolution_reader(s.shift_reader(src, 50_000.0), H), 4)
+        if kind == "multiply_then_more":        # Gain(Multiply(ShiftReader(ConvertReader(u8))))
+            return s.gain(s.multiply(s.shift_reader(s.convert_reader(src, hz.FMT_C64), 1e5), 1j), 0.25)
+        # a stage behind a terminal opens a second chain: Gain(DecimateReader(ConvertReader(u8)))
+        return s.gain(s.decimate_reader(s.convert_reader(src, hz.FMT_C64), 3), 2.0)
+
+    n = {"convolution_decimate": 3 * 4_096_000 // 2 + 777, "c64_shift_gain_ragged": 3_000_017}.get(kind, (1 << 21) + 4_321)
+    if kind in ("c64_shift_gain_ragged", "convolution_decimate", "convolution1024_decimate"):
+        x = rand_c64(8, n)
+    elif kind in ("convert_decimate", "downsample_i16"):
+        x = rand_i16(8, n)
+    else:
+        x = rand_u8(8, n)
+    outs = []
+    for s in (st, fst):
+        r = nest(s, S.BufferReader(x, rate, max_read=int(rng.integers(1_000, 90_000))))
+        got, err = _drain(S, r, 50_001, hz)
+        assert isinstance(err, S.EOF), (kind, err)
+        outs.append((got, r.sample_rate(), r.sample_format()))
+        if hasattr(r, "close"):
+            r.close()
+    assert outs[0][1:] == outs[1][1:]
+    assert len(outs[0][0]) == len(outs[1][0]) and len(outs[0][0]) > 0, (kind, len(outs[0][0]), len(outs[1][0]))
+    if kind.startswith("convolution"):  # (the fused chain's block kernel and the closure's differ in rounding: both FFTs)
+        a, b = outs[0][0].astype(np.complex128), outs[1][0].astype(np.complex128)
+        assert np.linalg.norm(a - b) <= 2e-6 * np.linalg.norm(a)
+    else:
+        assert bits_equal(outs[0][0], outs[1][0]), kind
+
+
+def test_fused_multiply_reader_takes_a_new_multiplier(hz, S, fst, orc):
+    """SetMultiplier on a fused Reader (stream/multiply.go:34-36; Beamform.SetPhaseAngles calls it): what has been read
+    ahead keeps the old multiplier, everything behind it the new one, the Shift's clock carries on across the rebuilt
+    chain -- so the output is the oracle's with a switch of the multiplier at ONE sample, and that sample is a whole
+    number of slots into the stream."""
+    n, rate = 6 * (1 << 20), 2_400_000
+    x = rand_c64(77, n)
+    r = fst.multiply(fst.shift_reader(S.BufferReader(x, rate), 7e4), 2j)
+    buf = zeros("c64", 1 << 19)
+    first = [buf[:r.read(buf)].copy()]
+    r.set_multiplier(0.5)
+    rest, err = _drain(S, r, 300_000, hz)
+    assert isinstance(err, S.EOF)
+    got = np.concatenate(first + [rest])
+    assert len(got) == n
+    sh = zeros("c64", n)
+    sh[:] = x
+    orc.Shifter(rate)(7e4, sh)
+    a, b = sh.copy(), sh.copy()
+    orc.rotate(a, np.complex64(2j))
+    orc.rotate(b, np.complex64(0.5))
+    same_a = np.flatnonzero(got.view(np.uint64) != a.view(np.uint64))
+    k = int(same_a[0]) if len(same_a) else n
+    assert k % (1 << 20) == 0 and (1 << 20) <= k <= 3 * (1 << 20), k  # (one slot being read, up to two more in flight)
+    assert bits_equal(got[:k], a[:k]) and bits_equal(got[k:], b[k:])
+    r.close()
