@@ -725,6 +725,12 @@ class MultiGpu:
             msg = lib.hzsdr_mgpu_last_error(self._h)
             raise _ERRORS.get(rc, HzsdrError)(f"hzsdr: {lib.hzsdr_strerror(rc).decode()}: {msg.decode() if msg else ''}")
 
+    def peer_pairs(self):
+        """(direct, staged): ordered pairs of distinct GPUs with / without peer access (hzsdr_mgpu_peer_pairs)."""
+        d, st = C.c_int(0), C.c_int(0)
+        _check(lib.hzsdr_mgpu_peer_pairs(self._h, C.byref(d), C.byref(st)))
+        return d.value, st.value
+
     def synchronize(self):
         _check(lib.hzsdr_mgpu_synchronize(self._h))
 

@@ -160,6 +160,7 @@ SIGNATURES = {
     "hzsdr_mgpu_beamform": (i32, [vp, vp, i32, i32, C.POINTER(C.c_void_p), C.POINTER(C.c_float), i32, sz, i32]),
     "hzsdr_mgpu_synchronize": (i32, [vp]),
     "hzsdr_mgpu_last_error": (C.c_char_p, [vp]),
+    "hzsdr_mgpu_peer_pairs": (i32, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "hzsdr_chain_reset": (i32, [vp]),
     "hzsdr_chain_set_time": (i32, [vp, f64]),
     "hzsdr_chain_time": (i32, [vp, C.POINTER(f64)]),

@@ -65,6 +65,7 @@ struct hzsdr_mgpu {
     Rccl rccl;
     std::vector<ncclComm_t> comms;
     std::string last_error;
+    int pairs_direct = 0, pairs_staged = 0;  // ordered pairs of distinct GPUs: peer access enabled / copies stage through the host
 };
 
 namespace hz {
@@ -155,13 +156,23 @@ int hzsdr_mgpu_open(const int *devices, int n_devices, hzsdr_mgpu **out) {
         for (int b = 0; b < n_devices; b++)
             if (devices[a] != devices[b]) {
                 int can = 0;
-                if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) == hipSuccess && can) {
+                const hipError_t q = hipDeviceCanAccessPeer(&can, devices[a], devices[b]);
+                bool direct = false;
+                if (q == hipSuccess && can) {
                     (void)hipSetDevice(devices[a]);
                     const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
-                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                    direct = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+                    if (!direct)
                         m->last_error = "peer access " + std::to_string(devices[a]) + " -> " + std::to_string(devices[b]) +
                                         " could not be enabled (" + hipGetErrorString(e) + "): copies between them stage through the host";
+                } else {
+                    // (said, not swallowed: the exchange still works -- hipMemcpyPeerAsync stages through the host --
+                    // but at PCIe speed instead of xGMI's; hzsdr_mgpu_peer_pairs / hzsdr_mgpu_last_error report it)
+                    m->last_error = "GPU " + std::to_string(devices[a]) + " cannot access GPU " + std::to_string(devices[b]) +
+                                    " directly" + (q != hipSuccess ? std::string(" (") + hipGetErrorString(q) + ")" : std::string()) +
+                                    ": copies between them stage through the host";
                 }
+                (direct ? m->pairs_direct : m->pairs_staged)++;
                 (void)hipGetLastError();
             }
     *out = m;
@@ -177,6 +188,13 @@ int hzsdr_mgpu_ctx(hzsdr_mgpu *m, int shard, hzsdr_ctx **ctx) {
 }
 
 const char *hzsdr_mgpu_last_error(const hzsdr_mgpu *m) { return m ? m->last_error.c_str() : ""; }
+
+int hzsdr_mgpu_peer_pairs(const hzsdr_mgpu *m, int *direct, int *staged) {
+    if (!m) return HZSDR_ERR_INVALID_ARGUMENT;
+    if (direct) *direct = m->pairs_direct;
+    if (staged) *staged = m->pairs_staged;
+    return HZSDR_OK;
+}
 
 int hzsdr_mgpu_synchronize(hzsdr_mgpu *m) {
     if (!m) return HZSDR_ERR_INVALID_ARGUMENT;

@@ -288,7 +288,14 @@ def _bench_group(hz, ctx, torch, dist, rank, g, group, k, n, steps, warmup, synt
         except Exception as e:  # noqa: BLE001
             err = f"{type(e).__name__}: {e}"[:300]
         if not all_ok(dist, torch, err is None, group, flag_dev):
-            res[name] = {"error": err or "failed on another rank"}
+            # every rank's own reason, by rank (a method that fails on rank 3 alone must say so on rank 0's line)
+            reasons = [None] * g
+            try:
+                dist.all_gather_object(reasons, err, group=group)
+            except Exception as e:  # noqa: BLE001  (the collective that would carry the reasons is itself what is broken)
+                reasons = [err if r == rank else f"unknown (all_gather_object failed here: {type(e).__name__})" for r in range(g)]
+            res[name] = {"error": err or "failed on another rank",
+                         "errors_by_rank": {str(r): reasons[r] for r in range(g) if reasons[r]}}
             continue
         ms = timed(fn)
         res[name] = row(ms)

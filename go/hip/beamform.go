@@ -122,6 +122,14 @@ func (g *MultiGPU) Beamform(out unsafe.Pointer, dst int, format sdr.SampleFormat
 	return nil
 }
 
+// PeerPairs reports how the shards reach each other: ordered pairs of distinct GPUs with peer access (xGMI copies) and
+// without (copies staged through the host); hzsdr_mgpu_peer_pairs.
+func (g *MultiGPU) PeerPairs() (direct, staged int) {
+	var d, s C.int
+	C.hzsdr_mgpu_peer_pairs(g.m, &d, &s)
+	return int(d), int(s)
+}
+
 func (g *MultiGPU) Synchronize() error { return toErr(nil, C.hzsdr_mgpu_synchronize(g.m)) }
 func (g *MultiGPU) Close() error       { return toErr(nil, C.hzsdr_mgpu_close(g.m)) }
 

@@ -506,6 +506,11 @@ int hzsdr_mgpu_beamform(hzsdr_mgpu *m, void *out_c64, int dst_shard, int format,
                         size_t n, int mode);
 int hzsdr_mgpu_synchronize(hzsdr_mgpu *m);
 const char *hzsdr_mgpu_last_error(const hzsdr_mgpu *m);
+/* How the shards reach each other, counted over the ordered pairs of DISTINCT GPUs when the object was opened:
+ * *direct = pairs with peer access enabled (hipMemcpyPeerAsync goes over xGMI), *staged = pairs without (the copies
+ * stage through the host at PCIe speed; hzsdr_mgpu_last_error names the last such pair).  Both 0 when every shard
+ * sits on one GPU.  No reference counterpart (stream/add.go:115-119 sums in one address space). */
+int hzsdr_mgpu_peer_pairs(const hzsdr_mgpu *m, int *direct, int *staged);
 
 /* ---- pinned ring in front of a chain -------------------- */
 

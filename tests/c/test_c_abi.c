@@ -209,6 +209,11 @@ static void beamform(void) { /* go/hip/beamform.go */
         OK(hzsdr_malloc_device(s0, 32, &dout));
         OK(hzsdr_memcpy_h2d(s0, d0, c0, 32));
         OK(hzsdr_memcpy_h2d(s1, d1, c1, 32));
+        {
+            int direct = -1, staged = -1; /* every shard on one GPU here: no pair of distinct GPUs at all */
+            OK(hzsdr_mgpu_peer_pairs(m, &direct, &staged));
+            CHECK(direct == 0 && staged == 0);
+        }
         OK(hzsdr_mgpu_synchronize(m));
         const void *dch[2] = {d0, d1};
         rc = hzsdr_mgpu_beamform(m, dout, 0, HZSDR_FMT_C64, dch, ww, 2, 4, HZSDR_MGPU_ORDERED);

@@ -107,3 +107,33 @@ def test_distinct_gpus_ordered_and_rccl(hz, orc):
             assert bits_equal(got, want)
         else:
             assert np.allclose(got, want, rtol=0, atol=4e-6)
+
+
+def test_two_rank_bench_on_one_gpu_runs_every_multi_rank_code_path():
+    """`bench.py --gpus 2` with both ranks on cuda:0 over gloo (HZ_BENCH_SAME_DEVICE=1 HZ_BENCH_BACKEND=gloo): a fresh
+    child process that starts torch.distributed.run as ITS child -- never a re-exec of a process that has touched the
+    GPU.  Not a measurement: what it proves is that nothing of the N > 1 path is left to discover on the day an 8-GPU
+    node runs it -- the launcher, the sub-group schedule, the three exchange methods with their exchange times, the
+    `rccl` object with the all-reduce of rank + 1, the one JSON line and the exit code."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, HZ_BENCH_SAME_DEVICE="1", HZ_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4", "--ramp-ms", "0",
+                        "--log2n", "20", "--no-extra", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] and d["scaling"] == "weak" and d["parity"]["ok"]
+    assert d["rccl"]["world_size"] == 2 and d["rccl"]["allreduce_sum_of_rank_plus_1"] == 3 and d["rccl"]["backend"] == "gloo"
+    bf = d["beamform"]
+    assert bf["schedule"] == {"1": [0], "2": [0, 1]}
+    assert bf["1"]["total"]["ms_per_buffer"] > 0
+    two = bf["2"]
+    assert two["ranks"] == 2 and two["channels_per_gpu"] == 2 and two["local_partial"]["ms_per_buffer"] > 0
+    for method in ("rccl_reduce", "ordered_pipeline", "ordered_alltoall"):
+        assert "error" not in two[method], (method, two[method])
+        assert two[method]["exchange_ms"] >= 0 and two[method]["ms_per_buffer"] > 0
