@@ -381,7 +381,7 @@ def main():
     chain.close()
     # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc
     # passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_summary.py), not from this process.
-    tname = next((t for t in ("r04_traffic.json", "r03_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), "r04_traffic.json")
+    tname = next((t for t in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), "r05_traffic.json")
     tpath = os.path.join(ROOT, "profiles", tname)
     if n == (1 << 24) and os.path.exists(tpath):
         try:
@@ -394,7 +394,10 @@ def main():
                         or "fir_synth_kernel16<4096, 8, true>" in k]
                 want = 2
             if len(keys) == want:
-                result["roofline"]["traffic"] = sum(tk[k]["hbm_bytes"] for k in keys)
+                # (r05 on: the PMC passes profile a launch over FOUR buffers -- tools/prof_kernels.py chain_batch4 --,
+                # earlier rounds' one over one; scaled to this run's buffers per launch)
+                per_launch_of = 4 if (tname >= "r05" and matrix) else 1
+                result["roofline"]["traffic"] = round(sum(tk[k]["hbm_bytes"] for k in keys) * (B if matrix else 1) / per_launch_of)
                 result["roofline"]["traffic_source"] = ("profiles/" + tname + " (rocprofv3 --pmc FETCH_SIZE x2 + "
                                                         "WRITE_SIZE, the kernel(s) of a chain_run)")
         except (StopIteration, KeyError, ValueError):

@@ -734,7 +734,13 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     // wave reaches its next loop -- queue, prefetch, first operands -- only then: a bubble of ~1 us in the matrix pipe
     // at every change of waves.  Issued among the wave's OWN MFMAs (the partner is in its epilogue by then) the stores
     // cost a few cycles each.  The last pass of a wave stores behind its loop as before.
-    constexpr bool kDefer = STRAIGHT && (EXP & 524288) != 0;
+    // 1 << 23: the same stores, but in ONE place -- at the next matrix loop's TOP, behind the queue, the prefetch's issue
+    // and the first operand reads, in front of the first MFMA: while the partner's loop runs the wave gets everything
+    // else of its next pass ready and waits at the stores; when the partner's stream of MFMAs ends they issue and the
+    // loop starts at once (without this the wave reaches its loop's top only behind the stores: ~0.5 us of idle matrix
+    // pipe per pass).  No branch inside the straight-line loop (524288's two cost more than they gave).
+    constexpr bool kDeferTop = STRAIGHT && (EXP & (1 << 23)) != 0;
+    constexpr bool kDefer = STRAIGHT && ((EXP & 524288) != 0 || kDeferTop);
     [[maybe_unused]] float2 yd[NB][4];
     [[maybe_unused]] uint64_t out_d = 0;
     [[maybe_unused]] uint32_t mb_d = 0, lo_d = 0, hi_d = 0;
@@ -905,6 +911,11 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                 load_b(b[0], 0, 0);
                 load_a(a[1], 1);
                 load_b(b[1], 0, 1);
+                if constexpr (kDeferTop) {
+                    __builtin_amdgcn_sched_barrier(0);  // (behind the operand reads' issue, in front of the first MFMA)
+                    flush_deferred();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 // one step; SC: the step as a compile-time value (straight-line form), or -1
                 auto step = [&](auto sc, int g, int j, int jx = 0) {
                     constexpr int SC = decltype(sc)::value;
@@ -923,7 +934,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                                 acc[f][q] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[sx % RG][f], b[sx % RG][q], acc[f][q], 0, 0, 0);
                         }
                     // (EXP & 524288: the PREVIOUS pass's stores, one column block each in two early steps)
-                    if constexpr (kDefer && SC >= 0) {
+                    if constexpr (kDefer && !kDeferTop && SC >= 0) {
                         if constexpr (SC >= 3 && (SC - 3) % 4 == 0 && (SC - 3) / 4 < NB) {
                             constexpr int bq = (SC - 3) / 4;
                             if (have_d) store_block(out_d, yd[bq], mb_d + (uint32_t)(32 * kT) * bq, lo_d, hi_d);

@@ -139,7 +139,7 @@ template <int EXP, int MIXT = 1, int NGT = 17> static void run(void *const *in, 
             for (int w = 0; w < 8; w++) {
                 const unsigned long long *s = &st[((size_t)wgx * 8 + w) * 32];
                 printf("    wg %d wave %d: start %.2f tasks %.2f x-issued %.2f tab-issued %.2f tab-landed %.2f barrier %.2f landed %.2f |", wgx, w, (double)(s[0] - t0) / 100, (double)(s[1] - t0) / 100, (double)(s[5] - t0) / 100, (double)(s[6] - t0) / 100, (double)(s[2] - t0) / 100, (double)(s[3] - t0) / 100, (double)(s[4] - t0) / 100);
-                for (int pp = 1; pp <= 2; pp++) {
+                for (int pp = 1; pp <= 3; pp++) {
                     const unsigned long long *q = s + 8 * pp;
                     if (q[1]) printf(" top %.2f grabbed %.2f", (double)(q[0] - t0) / 100, (double)(q[7] - t0) / 100);
                     if (q[1]) printf(" loop %.2f-%.2f land %.2f planes %.2f mixer %.2f stores %.2f |", (double)(q[1] - t0) / 100, (double)(q[2] - t0) / 100,
@@ -249,12 +249,13 @@ int main(int argc, char **argv) {
             run<ALL, 0>(in, out, taps, tab, n, ntaps, true);
             run<ALL | (1 << 22), 0>(in, out, taps, tab, n, ntaps, true);                // the mixer's products in scalar float32
             run<(ALL | (1 << 22)) & ~524288, 0>(in, out, taps, tab, n, ntaps, true);   // ... and the stores in the epilogue
+            run<((ALL | (1 << 22)) & ~524288) | (1 << 23), 0>(in, out, taps, tab, n, ntaps, true);  // ... the stores at the next loop's top
             run<ALL | 4, 0>(in, out, taps, tab, n, ntaps, true);                        // no mixer at all
             run<0, 0>(in, out, taps, tab, n, ntaps, true);                              // round 4's kernel
         }
         return 0;
     }
-    run<8192 | 16384 | 65536 | 131072 | 262144 | 524288, 0>(in, out, taps, tab, n, ntaps, true);  // (what the library ships: kLibExp)
+    run<8192 | 16384 | 65536 | 131072 | 262144 | (1 << 22), 0>(in, out, taps, tab, n, ntaps, true);  // (what the library ships: kLibExp)
     run<0, 0>(in, out, taps, tab, n, ntaps, true);
     run<128, 0>(in, out, taps, tab, n, ntaps, true);
     run<0, 0>(in, out, taps, tab, n, ntaps, true);
@@ -263,7 +264,7 @@ int main(int argc, char **argv) {
     run<2, 0>(in, out, taps, tab, n, ntaps, true);
     run<8, 0>(in, out, taps, tab, n, ntaps, true);
     run<32, 0>(in, out, taps, tab, n, ntaps, true);
-    run<64 | 8192 | 16384 | 65536 | 131072 | 262144 | 524288, 0>(in, out, taps, tab, n, ntaps, true);
+    run<64 | 8192 | 16384 | 65536 | 131072 | 262144 | (1 << 22), 0>(in, out, taps, tab, n, ntaps, true);  // (kLibExp with stamps)
     if (getenv("BISECT")) {  // which part of the epilogue waits for the partner's loop: without the mixer, without the stores
         run<64 | 4 | 8192 | 16384 | 65536 | 131072 | 262144 | 524288, 0>(in, out, taps, tab, n, ntaps, true);
         run<64 | 8 | 8192 | 16384 | 65536 | 131072 | 262144 | 524288, 0>(in, out, taps, tab, n, ntaps, true);

@@ -34,6 +34,11 @@ def main():
         if w == "chain":
             ch = ctx.chain(hz.FMT_U8, fs).shift(-fs / 8).fir_decimate(taps, D)
             fn = lambda: ch.run(xu8, out[:n // D])
+        elif w == "chain_batch4":  # the benchmarked form: four consecutive buffers per call, ONE launch (hzsdr_chain_run_batch)
+            ch = ctx.chain(hz.FMT_U8, fs).shift(-fs / 8).fir_decimate(taps, D)
+            xb = [xu8] + [torch.from_numpy(B.synth_u8(10 + i, n)).cuda() for i in range(3)]
+            ob = [torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(4)]
+            fn = lambda: ch.run_batch(xb, ob)
         elif w == "chain_fft":  # the same chain on the overlap-save transform kernels
             ch = ctx.chain(hz.FMT_U8, fs).shift(-fs / 8).fir_options(hz.FIR_IMPL_TRANSFORMS).fir_decimate(taps, D)
             fn = lambda: ch.run(xu8, out[:n // D])
