@@ -9,6 +9,7 @@ newest() { ls -t $1 | head -1; }
 cp $(newest "$src/bench_trace/*/*kernel_stats.csv") profiles/${tag}_bench_kernel_stats.csv
 [ -d $src/bench_trace_pipelined ] && cp $(newest "$src/bench_trace_pipelined/*/*kernel_stats.csv") profiles/${tag}_bench_pipelined_kernel_stats.csv
 [ -d $src/bench_trace_batch ] && cp $(newest "$src/bench_trace_batch/*/*kernel_stats.csv") profiles/${tag}_bench_batch_kernel_stats.csv
+python3 tools/split_launches.py $src/bench_trace $src/bench_trace_batch $src/bench_trace_pipelined > profiles/${tag}_bench_launch_split.txt 2>/dev/null || true
 [ -f $src/bench_driver_style.json ] && cp $src/bench_driver_style.json profiles/${tag}_bench_driver_style.json
 cp $(newest "$src/kern_trace/*/*kernel_stats.csv") profiles/${tag}_kernels_kernel_stats.csv
 cp $(newest "$src/fft_trace/*/*kernel_stats.csv") profiles/${tag}_fft_kernel_stats.csv
