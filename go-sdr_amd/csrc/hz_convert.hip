@@ -316,7 +316,7 @@ template <> struct SrcSample<HZSDR_FMT_C64> {
 // order from +0, divide by float32(factor)  (stream/downsample.go:99-124).
 // W raw samples are fetched per vector load (W * sizeof(raw) = 16 B) when the
 // window geometry allows (factor % W == 0 and 16-B aligned source).
-template <int FMT, int W, bool NT = false>
+template <int FMT, int W, bool NT = false, int G = 1>
 __global__ __launch_bounds__(kThreads) void downsample_kernel(
     const typename SrcSample<FMT>::raw_t *__restrict__ from, float2 *to, size_t count,
     unsigned factor) {
@@ -327,15 +327,22 @@ __global__ __launch_bounds__(kThreads) void downsample_kernel(
         const R *w = from + i * factor;
         float sr = 0.0f, si = 0.0f;
         if constexpr (W > 1) {
+            // G vectors of a window are in flight together: a lane's window is one run of bytes, and a non-temporal
+            // load leaves nothing of its cache line behind for the next one -- issued one by one the second vector of
+            // a 32-byte window fetched its line AGAIN (FETCH_SIZE 1.39x the input, 25 us where the cached form took 19)
             const Vec<R, W> *wv = reinterpret_cast<const Vec<R, W> *>(w);
-            for (unsigned j = 0; j < factor / W; j++) {
-                Vec<R, W> v = ld_stream<NT>(wv + j);
+            for (unsigned j = 0; j < factor / W; j += G) {
+                Vec<R, W> v[G];
 #pragma unroll
-                for (int k = 0; k < W; k++) {
-                    float2 c = SrcSample<FMT>::cvt(v.v[k]);
-                    sr = __fadd_rn(sr, c.x);
-                    si = __fadd_rn(si, c.y);
-                }
+                for (int g = 0; g < G; g++) v[g] = ld_stream<NT>(wv + j + g);
+#pragma unroll
+                for (int g = 0; g < G; g++)
+#pragma unroll
+                    for (int k = 0; k < W; k++) {
+                        float2 c = SrcSample<FMT>::cvt(v[g].v[k]);
+                        sr = __fadd_rn(sr, c.x);
+                        si = __fadd_rn(si, c.y);
+                    }
             }
         } else {
             for (unsigned j = 0; j < factor; j++) {
@@ -357,9 +364,19 @@ static void launch_downsample(hzsdr_ctx *ctx, const void *from, void *to, size_t
     dim3 g(blocks_for(ctx, count)), b(kThreads);
     // (from 64 MiB on here: a decimating kernel's call is mostly INPUT, and a stream's next buffer of that size has
     // pushed this one out of the 256 MB cache long before its turn comes again -- 2^24 i16 samples by 8 are 80 MiB)
-    if (factor % W == 0 && (uintptr_t)from % 16 == 0 && count * ((size_t)factor * sizeof(R) + 8) >= ((size_t)64 << 20))
-        hipLaunchKernelGGL((downsample_kernel<FMT, W, true>), g, b, 0, ctx->stream, (const R *)from, (float2 *)to, count, factor);
-    else if (factor % W == 0 && (uintptr_t)from % 16 == 0)
+    const bool vec = factor % W == 0 && (uintptr_t)from % 16 == 0;
+    const unsigned nv = factor / W;  // 16-byte vectors per window
+    const bool past = count * ((size_t)factor * sizeof(R) + 8) >= ((size_t)64 << 20);
+    // non-temporal only where a window's vectors travel together (see the kernel): windows of 1, 2 or 4k vectors
+    if (vec && past && nv % 4 == 0)
+        hipLaunchKernelGGL((downsample_kernel<FMT, W, true, 4>), g, b, 0, ctx->stream, (const R *)from, (float2 *)to, count, factor);
+    else if (vec && past && nv == 2)
+        hipLaunchKernelGGL((downsample_kernel<FMT, W, true, 2>), g, b, 0, ctx->stream, (const R *)from, (float2 *)to, count, factor);
+    else if (vec && past && nv == 1)
+        hipLaunchKernelGGL((downsample_kernel<FMT, W, true, 1>), g, b, 0, ctx->stream, (const R *)from, (float2 *)to, count, factor);
+    else if (vec && nv % 2 == 0)
+        hipLaunchKernelGGL((downsample_kernel<FMT, W, false, 2>), g, b, 0, ctx->stream, (const R *)from, (float2 *)to, count, factor);
+    else if (vec)
         hipLaunchKernelGGL((downsample_kernel<FMT, W>), g, b, 0, ctx->stream, (const R *)from, (float2 *)to, count, factor);
     else
         hipLaunchKernelGGL((downsample_kernel<FMT, 1>), g, b, 0, ctx->stream, (const R *)from, (float2 *)to, count, factor);

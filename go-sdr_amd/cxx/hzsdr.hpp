@@ -68,6 +68,12 @@ public:
     ~Context() { if (c_) hzsdr_close(c_); }
     Context(const Context &) = delete;
     hzsdr_ctx *raw() const { return c_; }
+    // hzsdr_call_count: library calls made on this context so far
+    unsigned long long CallCount() const {
+        unsigned long long n = 0;
+        check(c_, hzsdr_call_count(c_, &n));
+        return n;
+    }
 
     // sdr.ConvertBuffer (conv.go:55)
     size_t ConvertBuffer(Samples dst, Samples src) const {
@@ -612,6 +618,7 @@ public:
         return Samples{format, p, slot_length_};
     }
     void Submit(int slot, size_t n) { check(x_.raw(), hzsdr_ring_submit(r_, slot, n)); }
+    void Release(int slot) { check(x_.raw(), hzsdr_ring_release(r_, slot)); }  // the acquired slot, unused
     // read cursor: the oldest submitted slot's output (complex64), valid until that slot is resubmitted
     Samples Pop() {
         const void *p = nullptr;
@@ -626,6 +633,179 @@ private:
     hzsdr_ring *r_ = nullptr;
     void *base_ = nullptr;
     size_t total_ = 0, slot_length_ = 0;
+};
+
+
+// ---- nested Readers that fuse into one chain and read ahead (go/hip/fused.go is this, in Go) ---------------------------
+// The constructors of `Fused` do not wrap a Reader that one of them made: they extend its chain -- ConvertReader ->
+// ShiftReader -> Gain -> Multiply -> DecimateReader / DownsampleReader / ConvolutionReader collapse into one
+// hzsdr_chain, one launch per slot -- and the Reader reads AHEAD: `readahead` Reader blocks of 32 Ki samples per slot of a
+// pinned ring.  What the nest means is kept: the same samples bit for bit, block-structured stages hand out whole
+// blocks only (a source that ends inside a block loses that partial block, as ReadFull's ErrUnexpectedEOF does in
+// read_transformer.go:120-135), pass-through stages hand out whatever the source delivered, the source's error is
+// sticky and surfaces behind everything read before it.
+class ChainReader : public Reader {
+public:
+    struct Stage { int kind; double shift; float gain, re, im; };  // 0 Shift, 1 Gain, 2 Multiply
+    ChainReader(const Context &x, ReaderPtr src, int readahead) : x_(x), src_(std::move(src)), readahead_(readahead) {
+        src_format_ = src_->SampleFormat();
+        rate_ = src_->SampleRate();
+    }
+    bool open() const { return !chain_ && term_ == 0; }
+    bool c64_here() const { return src_format_ == HZSDR_FMT_C64 || converted_; }
+    bool extend_convert(int to) {
+        if (!open() || to != HZSDR_FMT_C64 || !stages_.empty() || src_format_ == HZSDR_FMT_C64 || converted_) return false;
+        converted_ = true;
+        block_ = lcm(block_, kBlock);
+        return true;
+    }
+    bool extend_stage(const Stage &st) {
+        if (!open() || !c64_here()) return false;
+        stages_.push_back(st);
+        return true;
+    }
+    // kind 1 Decimate, 2 Downsample (its own conversion of a raw source included), 3 Convolution
+    bool extend_terminal(int kind, unsigned factor, Samples filter, size_t block) {
+        if (chain_) return false;
+        if (kind == 1 && term_ == 3 && decimate_ == 1 && kBlock % filter_.size() == 0) {  // DecimateReader behind the ConvolutionReader
+            decimate_ = factor;
+            block_ = lcm(block_, kBlock);
+            rate_ /= factor;
+            return true;
+        }
+        if (kind == 2 && open() && !c64_here() && stages_.empty()) converted_ = true;
+        if (!open() || !c64_here()) return false;
+        term_ = kind, factor_ = factor;
+        if (kind == 3) filter_.assign((const std::complex<float> *)filter.data, (const std::complex<float> *)filter.data + filter.length);
+        block_ = lcm(block_, block);
+        if (kind == 1 || kind == 2) rate_ /= factor;
+        return true;
+    }
+    int SampleFormat() const override { return c64_here() ? HZSDR_FMT_C64 : src_format_; }
+    unsigned SampleRate() const override { return rate_; }
+    size_t Read(Samples s) override {
+        if (s.format != SampleFormat() || s.format != HZSDR_FMT_C64) throw Error(HZSDR_ERR_FORMAT_MISMATCH, hzsdr_strerror(HZSDR_ERR_FORMAT_MISMATCH));
+        if (!chain_) build();
+        if (off_ >= pending_.length) {
+            while (inflight_ < 2 && fill_one()) {}
+            if (inflight_ == 0) {
+                if (err_) std::rethrow_exception(err_);
+                throw Eof();
+            }
+            pending_ = ring_->Pop();
+            inflight_--;
+            off_ = 0;
+            if (pending_.length == 0) return 0;
+        }
+        const size_t n = std::min(pending_.length - off_, s.length);
+        memcpy(s.data, (const char *)pending_.data + 8 * off_, 8 * n);
+        off_ += n;
+        return n;
+    }
+
+private:
+    static constexpr size_t kBlock = 32 * 1024;
+    static size_t gcd(size_t a, size_t b) { while (b) { const size_t t = a % b; a = b; b = t; } return a; }
+    static size_t lcm(size_t a, size_t b) { return a / gcd(a, b) * b; }
+    void build() {
+        chain_ = std::make_unique<Chain>(x_, src_format_, src_->SampleRate());
+        for (const Stage &st : stages_) {
+            if (st.kind == 0) chain_->Shift(st.shift);
+            else if (st.kind == 1) chain_->Gain(st.gain);
+            else chain_->Multiply(st.re, st.im);
+        }
+        if (term_ == 1) chain_->Decimate(factor_);
+        else if (term_ == 2) chain_->Downsample(factor_);
+        else if (term_ == 3) chain_->Convolution(Samples{HZSDR_FMT_C64, filter_.data(), filter_.size()}, decimate_);
+        const size_t unit = block_ > 1 ? block_ : kBlock;
+        slot_len_ = std::max<size_t>(1, (size_t)readahead_ * kBlock / unit) * unit;
+        ring_ = std::make_unique<Ring>(*chain_, slot_len_, 3);
+    }
+    bool fill_one() {
+        if (err_) return false;
+        int slot = -1;
+        Samples iq = ring_->Acquire(src_format_, &slot);
+        size_t n = 0;
+        try {
+            while (n < slot_len_) n += src_->Read(iq.slice(n, slot_len_));
+        } catch (...) {
+            err_ = std::current_exception();
+        }
+        n = n / block_ * block_;
+        if (n == 0) {
+            ring_->Release(slot);
+            return false;
+        }
+        ring_->Submit(slot, n);
+        inflight_++;
+        return true;
+    }
+    const Context &x_;
+    ReaderPtr src_;
+    int readahead_, src_format_ = 0;
+    unsigned rate_ = 0;
+    bool converted_ = false;
+    std::vector<Stage> stages_;
+    int term_ = 0;
+    unsigned factor_ = 1, decimate_ = 1;
+    std::vector<std::complex<float>> filter_;
+    size_t block_ = 1, slot_len_ = 0;
+    std::unique_ptr<Chain> chain_;
+    std::unique_ptr<Ring> ring_;
+    Samples pending_{};
+    size_t off_ = 0;
+    int inflight_ = 0;
+    std::exception_ptr err_;
+};
+
+// The constructor set that fuses (go/hip: Context.Readers()); every name falls back to the plain constructor above when
+// the stage cannot join a chain.
+struct Fused {
+    const Context &x;
+    int readahead = 32;
+    template <class How> std::shared_ptr<ChainReader> fused(ReaderPtr r, How how) const {
+        if (auto cr = std::dynamic_pointer_cast<ChainReader>(r)) {
+            if (how(*cr)) return cr;
+        }
+        auto cr = std::make_shared<ChainReader>(x, r, readahead);
+        if (how(*cr)) return cr;
+        return nullptr;
+    }
+    ReaderPtr ConvertReader(ReaderPtr in, int to) const {
+        if (auto f = fused(in, [&](ChainReader &c) { return c.extend_convert(to); })) return f;
+        return stream::ConvertReader(x, std::move(in), to);
+    }
+    ReaderPtr ShiftReader(ReaderPtr r, double hz) const {
+        if (r->SampleFormat() != HZSDR_FMT_C64) throw Error(HZSDR_ERR_FORMAT_UNKNOWN, hzsdr_strerror(HZSDR_ERR_FORMAT_UNKNOWN));
+        if (auto f = fused(r, [&](ChainReader &c) { return c.extend_stage({0, hz, 0.f, 0.f, 0.f}); })) return f;
+        return stream::ShiftReader(x, std::move(r), hz);
+    }
+    ReaderPtr Gain(ReaderPtr r, float v) const {
+        if (r->SampleFormat() == HZSDR_FMT_C64)
+            if (auto f = fused(r, [&](ChainReader &c) { return c.extend_stage({1, 0.0, v, 0.f, 0.f}); })) return f;
+        return stream::Gain(x, std::move(r), v);
+    }
+    ReaderPtr Multiply(ReaderPtr r, float re, float im) const {
+        if (r->SampleFormat() == HZSDR_FMT_C64 && !(re == 1.0f && im == 0.0f))
+            if (auto f = fused(r, [&](ChainReader &c) { return c.extend_stage({2, 0.0, 0.f, re, im}); })) return f;
+        return stream::Multiply(x, std::move(r), re, im);
+    }
+    ReaderPtr DecimateReader(ReaderPtr in, unsigned factor) const {
+        if (in->SampleFormat() == HZSDR_FMT_C64 && factor > 0)
+            if (auto f = fused(in, [&](ChainReader &c) { return c.extend_terminal(1, factor, Samples{}, 32 * 1024); })) return f;
+        return stream::DecimateReader(x, std::move(in), factor);
+    }
+    ReaderPtr DownsampleReader(ReaderPtr in, unsigned factor) const {
+        const int f0 = in->SampleFormat();
+        if ((f0 == HZSDR_FMT_C64 || f0 == HZSDR_FMT_U8 || f0 == HZSDR_FMT_I16) && factor > 0)
+            if (auto f = fused(in, [&](ChainReader &c) { return c.extend_terminal(2, factor, Samples{}, 32 * 1024); })) return f;
+        return stream::DownsampleReader(x, std::move(in), factor);
+    }
+    ReaderPtr ConvolutionReader(ReaderPtr r, Samples filter) const {
+        if (r->SampleFormat() != HZSDR_FMT_C64) throw Error(HZSDR_ERR_FORMAT_UNKNOWN, hzsdr_strerror(HZSDR_ERR_FORMAT_UNKNOWN));
+        if (auto f = fused(r, [&](ChainReader &c) { return c.extend_terminal(3, 1, filter, filter.length); })) return f;
+        return stream::ConvolutionReader(x, std::move(r), filter);
+    }
 };
 
 }  // namespace stream

@@ -432,6 +432,49 @@ int main() {
         for (size_t i = 0; i < o2.size(); i++) worst = std::fmax(worst, std::abs(o2[i] - want[i]));
         EXPECT(worst < 2e-6f);
     }
+    {  // nested Readers that fuse and read ahead (stream::Fused; go/hip/fused.go): Gain(ShiftReader(ConvertReader(u8 source)))
+       // and DecimateReader(Multiply(ConvertReader(..))) against the same nests in the reference's own structure -- the
+       // same samples bit for bit, the source's partial last block dropped, far fewer calls of the library
+        const size_t n = (1 << 22) + 4321;
+        std::vector<uint8_t> u8(2 * n);
+        for (size_t i = 0; i < u8.size(); i++) u8[i] = (uint8_t)((i * 2654435761u) >> 23);
+        auto drain = [](Reader &r, std::vector<c64> &out) {
+            std::vector<c64> buf(50001);
+            try {
+                for (;;) {
+                    const size_t k = r.Read(Samples{HZSDR_FMT_C64, buf.data(), buf.size()});
+                    out.insert(out.end(), buf.begin(), buf.begin() + (long)k);
+                }
+            } catch (const Eof &) {
+            }
+        };
+        const stream::Fused f{ctx, 32};
+        for (int nest = 0; nest < 2; nest++) {
+            auto src_a = std::make_shared<BufferReader>(view(HZSDR_FMT_U8, u8, 2), 2400000u, 77777);
+            auto src_b = std::make_shared<BufferReader>(view(HZSDR_FMT_U8, u8, 2), 2400000u, 12345);
+            ReaderPtr plain, fused;
+            if (nest == 0) {
+                plain = stream::Gain(ctx, stream::ShiftReader(ctx, stream::ConvertReader(ctx, src_a, HZSDR_FMT_C64), 310000.0), 0.5f);
+                fused = f.Gain(f.ShiftReader(f.ConvertReader(src_b, HZSDR_FMT_C64), 310000.0), 0.5f);
+            } else {
+                plain = stream::DecimateReader(ctx, stream::Multiply(ctx, stream::ConvertReader(ctx, src_a, HZSDR_FMT_C64), 0.6f, 0.8f), 5);
+                fused = f.DecimateReader(f.Multiply(f.ConvertReader(src_b, HZSDR_FMT_C64), 0.6f, 0.8f), 5);
+            }
+            EXPECT(std::dynamic_pointer_cast<stream::ChainReader>(fused) != nullptr);
+            EXPECT(fused->SampleRate() == plain->SampleRate() && fused->SampleFormat() == HZSDR_FMT_C64);
+            std::vector<c64> a, b;
+            const unsigned long long c0 = ctx.CallCount();
+            drain(*plain, a);
+            const unsigned long long c1 = ctx.CallCount();
+            drain(*fused, b);
+            const unsigned long long c2 = ctx.CallCount();
+            const size_t whole = n / 32768 * 32768;
+            EXPECT(nest == 0 ? a.size() == whole : (a.size() > 0 && a.size() % (whole / 32768) == 0));  // (whole 32 Ki blocks only)
+            EXPECT(a.size() == b.size());
+            EXPECT(a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(c64)) == 0);
+            EXPECT(c2 - c1 < 40 && c1 - c0 >= whole / 32768);
+        }
+    }
     std::printf(failures ? "%d FAILED\n" : "all host-mirror tests passed\n", failures);
     return failures ? 1 : 0;
 }
