@@ -775,6 +775,72 @@ __global__ __launch_bounds__(fv::block(N), conv_occupancy(N, STAGED)) void conv_
     }
 }
 
+// c64 blocks of N <= 1024 points (a transform inside ONE wave) with nothing elementwise in front: W waves of a workgroup
+// walk the blocks side by side and share ONE copy of the twiddle tables and of the filter's bins IN LDS.
+// Why: a wave's vector-memory loads return in order.  conv_blocks_kernel16 keeps the next block's sixteen loads in flight
+// under the current block's transforms, but its table and filter reads (L2 hits) queue up BEHIND those loads, so the
+// first twiddle a block needs waits for the prefetch to land from HBM -- a hundred instructions into the block the
+// prefetch hid nothing (ISA: `s_waitcnt vmcnt(5)` behind six table loads behind the sixteen prefetches).  LDS reads
+// count on lgkmcnt: here the vector-memory queue of a wave holds its prefetch and its stores, nothing else.
+template <int N> struct ConvShared {
+    static constexpr int TPT = fv::tpt(N), XPW = 64 / TPT;  // transforms per wave
+    static constexpr int FL = fv::fwd_tab_len(N), BL = fv::bwd_tab_len(N);
+    static constexpr size_t table_bytes = (size_t)(FL + BL) * sizeof(cf4) + (size_t)N * sizeof(cf);
+    static constexpr size_t wave_bytes = (size_t)XPW * fv::lds_elems(N) * sizeof(cf);
+    static constexpr size_t lds_bytes(int waves) { return table_bytes + wave_bytes * waves; }
+    static_assert(TPT <= 64 && TPT >= 16, "one wave per transform");
+};
+
+template <int N, int W>
+__global__ __launch_bounds__(64 * W) void conv_blocks_shared_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
+                                                                    const float2 *__restrict__ filt, FvTabs tabs, size_t nblocks) {
+    using G = ConvShared<N>;
+    constexpr int TPT = G::TPT, XPW = G::XPW, R0 = fv::first_radix(N);
+    cf4 *lf = reinterpret_cast<cf4 *>(fv_lds());
+    cf4 *lb = lf + G::FL;
+    cf *lh = reinterpret_cast<cf *>(lb + G::BL);
+    const int wave = threadIdx.x / 64, wl = threadIdx.x % 64;
+    const int sub = XPW == 1 ? 0 : wl / TPT, lane = XPW == 1 ? wl : wl % TPT;
+    cf *lds = lh + N + (size_t)(wave * XPW + sub) * fv::lds_elems(N);
+    for (int i = threadIdx.x; i < G::FL; i += 64 * W) lf[i] = tabs.fwd[i];
+    for (int i = threadIdx.x; i < G::BL; i += 64 * W) lb[i] = tabs.bwd[i];
+    for (int i = threadIdx.x; i < N; i += 64 * W) lh[i] = fv::from2(filt[i]);
+    __syncthreads();  // the only barrier: from here on the waves never meet
+    // consecutive blocks side by side: the workgroup reads W * XPW blocks = W * 8 KiB in one run per trip
+    const size_t stride = (size_t)gridDim.x * W * XPW;
+    size_t b = ((size_t)blockIdx.x * W + wave) * XPW + sub;
+    cf v[16];
+    float2 nx[16];
+    {
+        const float2 *pb = in + b * N + lane;
+#pragma unroll
+        for (int q = 0; q < 16; q++) nx[q] = b < nblocks ? pb[fv::edge_off<N, R0>(q)] : float2{};
+    }
+#pragma unroll 1
+    for (size_t b0 = ((size_t)blockIdx.x * W + wave) * XPW; b0 < nblocks; b0 += stride, b += stride) {  // (uniform in a wave)
+        const bool live = XPW == 1 || b < nblocks;
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = fv::from2(nx[q]);
+        const size_t bn = b + stride;
+        if (XPW == 1 ? b0 + stride < nblocks : bn < nblocks) {
+            const float2 *pb = in + bn * N + lane;
+#pragma unroll
+            for (int q = 0; q < 16; q++) nx[q] = pb[fv::edge_off<N, R0>(q)];
+        }
+        fv::forward<N, false, true>(v, lds, lf, lane);
+        // freq1[i] *= freq[i] (fft/convolution.go:187-189) as a float32 product, like conv_blocks_kernel16
+        const cf *fl = lh + lane;
+#pragma unroll
+        for (int q = 0; q < 16; q++) v[q] = fv::cmul(v[q], fl[fv::edge_off<N, 16>(q)]);
+        fv::backward<N, true>(v, lds, lb, lane);
+        if (live) {
+            float2 *ob = out + b * N + lane;
+#pragma unroll
+            for (int q = 0; q < 16; q++) ob[fv::edge_off<N, R0>(q)] = fv::to2(v[q]);
+        }
+    }
+}
+
 // FOLD = D (power of two <= 16 with N/D >= 256): lane-local spectral fold to M = N/D
 // bins; the M-point inverse runs in fir_synth_kernel16.  (One kernel did both at first:
 // the inverse kept one group of M/16 lanes busy and parked the rest of the workgroup,

@@ -120,6 +120,31 @@ __global__ __launch_bounds__(kThreads) void convert_vec_kernel(
     }
 }
 
+// The form for calls that stream past the cache: a workgroup's tile is U runs of 256 vectors, a lane's U loads in flight
+// before its first store, non-temporal both ways, one tile per workgroup -- u8 -> c64 reads 4 bytes per lane and load:
+// with ONE such load per wave in flight the chip's resident waves hold 2 MB of reads, the rate of a 2 us latency at
+// 1 TB/s, which is what the kernel ran at (tools/stream_rate.hip over a rotation of buffers: 31.6 us; U = 2: 28.0 us =
+// 6.0 TB/s, U = 4 28.5, U = 8 30.8).
+template <int C, int SW, int U>
+__global__ __launch_bounds__(kThreads) void convert_tile_kernel(const typename ConvTraits<C>::src_t *__restrict__ src,
+                                                                typename ConvTraits<C>::dst_t *__restrict__ dst, int arg) {
+    using G = ConvGeom<C>;
+    using SV = Vec<typename G::S, G::K>;
+    using DV = Vec<typename G::D, G::K>;
+    const SV *s = reinterpret_cast<const SV *>(src) + (size_t)blockIdx.x * (kThreads * U) + threadIdx.x;
+    DV *d = reinterpret_cast<DV *>(dst) + (size_t)blockIdx.x * (kThreads * U) + threadIdx.x;
+    SV a[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) a[u] = ld_stream<true>(s + u * kThreads);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        DV r;
+#pragma unroll
+        for (int k = 0; k < G::K; k++) r.v[k] = conv1s<C, SW>(a[u].v[k], arg);
+        st_stream<true>(d + u * kThreads, r);
+    }
+}
+
 template <int C, int SW>
 __global__ __launch_bounds__(kThreads) void convert_scalar_kernel(
     const typename ConvTraits<C>::src_t *__restrict__ src,
@@ -145,8 +170,14 @@ static void launch_convert(hzsdr_ctx *ctx, const void *src, void *dst, size_t nc
         // (one vector per lane up to the grid's cap of 128 workgroups per CU, the kernel's four-deep loop only beyond:
         // u8 -> c64 over 2^24 samples 26.7 us instead of 27.5 from the cache, 35.5 instead of 36.7 from HBM)
         // (a call of 96 MiB or more streams past the memory-side cache: hz_device.h)
-        if (streams_past_cache(ncomp * (sizeof(S) + sizeof(D))))
-            hipLaunchKernelGGL((convert_vec_kernel<C, SW, true>), dim3(blocks_for(ctx, nvec)), dim3(kThreads), 0, ctx->stream, s, d, nvec, arg);
+        if (streams_past_cache(ncomp * (sizeof(S) + sizeof(D)))) {
+            constexpr int U = 2;
+            const size_t tiles = nvec / ((size_t)kThreads * U), rest = nvec - tiles * kThreads * U;
+            hipLaunchKernelGGL((convert_tile_kernel<C, SW, U>), dim3((unsigned)tiles), dim3(kThreads), 0, ctx->stream, s, d, arg);
+            if (rest)
+                hipLaunchKernelGGL((convert_vec_kernel<C, SW, true>), dim3(blocks_for(ctx, rest)), dim3(kThreads), 0, ctx->stream,
+                                   s + tiles * kThreads * U * G::K, d + tiles * kThreads * U * G::K, rest, arg);
+        }
         else
             hipLaunchKernelGGL((convert_vec_kernel<C, SW>), dim3(blocks_for(ctx, nvec)), dim3(kThreads),
                                0, ctx->stream, s, d, nvec, arg);

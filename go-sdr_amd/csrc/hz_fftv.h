@@ -339,6 +339,20 @@ __device__ __forceinline__ void twiddle_rows(cf *v, TabPtr tab, int lane) {
     }
 }
 
+// Between a pass's LDS stores and the next pass's loads: a workgroup barrier -- or, WAVE, nothing but the compiler's
+// order: for a caller whose transforms each live inside ONE wave (64 lanes or fewer, the lanes of a transform adjacent
+// in the wave, its LDS region its own).  A wave's LDS instructions execute in the order it issues them, so such a
+// workgroup may hold many waves that never meet (conv_blocks_shared_kernel: sixteen, with one copy of the tables).
+// (Not a property of N: fft2_cols_kernel spreads a 16-lane transform over four waves.)
+template <bool WAVE> __device__ __forceinline__ void sync() {
+    if constexpr (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        __syncthreads();
+    }
+}
+
 // ---- whole transforms on registers -------------------------------------------------------------
 // v[16]: on entry the inputs in the edge layout of the first pass's radix, on exit the
 // outputs in the edge layout of the last pass's radix.  `lds` = this transform's padded
@@ -346,37 +360,37 @@ __device__ __forceinline__ void twiddle_rows(cf *v, TabPtr tab, int lane) {
 // in hz_fft.hip).  Every lane of the workgroup calls.
 // FROM_LDS: the caller loaded v from `lds` itself, so a barrier precedes the first store.
 
-template <int N, int NS> __device__ __forceinline__ void forward_from(cf *v, cf *lds, const cf4 *tab, int lane) {
-    __syncthreads();
+template <int N, int NS, bool WAVE = false> __device__ __forceinline__ void forward_from(cf *v, cf *lds, const cf4 *tab, int lane) {
+    sync<WAVE>();
     load_lds<N, 16>(v, lds, lane);
     pass16<N, NS, false>(v, tab + fwd_tab_off(N, NS), lane);
     if constexpr (NS * 16 < N) {
-        __syncthreads();
+        sync<WAVE>();
         store_lds<N, 16, NS>(v, lds, lane);
-        forward_from<N, NS * 16>(v, lds, tab, lane);
+        forward_from<N, NS * 16, WAVE>(v, lds, tab, lane);
     }
 }
 
-template <int N, bool FROM_LDS = false>
+template <int N, bool FROM_LDS = false, bool WAVE = false>
 __device__ __forceinline__ void forward(cf *v, cf *lds, const cf4 *tab, int lane) {
     constexpr int R0 = first_radix(N);
     butterflies<R0, false>(v);  // Ns = 1: no twiddles
-    if constexpr (FROM_LDS) __syncthreads();
+    if constexpr (FROM_LDS) sync<WAVE>();
     store_lds<N, R0, 1>(v, lds, lane);
-    forward_from<N, R0>(v, lds, tab, lane);
+    forward_from<N, R0, WAVE>(v, lds, tab, lane);
 }
 
-template <int N, int NS> __device__ __forceinline__ void backward_from(cf *v, cf *lds, const cf4 *tab, int lane, bool active) {
+template <int N, int NS, bool WAVE = false> __device__ __forceinline__ void backward_from(cf *v, cf *lds, const cf4 *tab, int lane, bool active) {
     constexpr int R0 = first_radix(N);
-    __syncthreads();
+    sync<WAVE>();
     if constexpr (NS * R0 < N) {
         if (active) {
             load_lds<N, 16>(v, lds, lane);
             pass16<N, NS, true>(v, tab + bwd_tab_off(N, NS), lane);
         }
-        __syncthreads();
+        sync<WAVE>();
         if (active) store_lds<N, 16, NS>(v, lds, lane);
-        backward_from<N, NS * 16>(v, lds, tab, lane, active);
+        backward_from<N, NS * 16, WAVE>(v, lds, tab, lane, active);
     } else {
         if (active) {
             load_lds<N, R0>(v, lds, lane);
@@ -451,12 +465,12 @@ template <int N> __device__ __forceinline__ void backward_regs(cf *v, cf *lds, c
 
 // `active` (wave-uniform where it matters): lanes with active == false only keep the
 // workgroup barriers company (a transform smaller than the workgroup on its first lanes).
-template <int N>
+template <int N, bool WAVE = false>
 __device__ __forceinline__ void backward(cf *v, cf *lds, const cf4 *tab, int lane, bool active = true) {
     if (active) butterflies<16, true>(v);  // first radix-16 pass, Ns = 1
-    __syncthreads();                       // other lanes may still be reading lds (forward's last pass)
+    sync<WAVE>();                       // other lanes may still be reading lds (forward's last pass)
     if (active) store_lds<N, 16, 1>(v, lds, lane);
-    backward_from<N, 16>(v, lds, tab, lane, active);
+    backward_from<N, 16, WAVE>(v, lds, tab, lane, active);
 }
 
 }  // namespace fv

@@ -178,3 +178,51 @@ def test_filter_produced_on_the_stream_just_before(hz, dev, orc):
         assert np.linalg.norm(g2 - 2 * want[:flen]) <= 2e-6 * np.linalg.norm(2 * want[:flen].astype(np.complex128))
         for o in (ch, cv, plan, plan_busy):
             o.close()
+
+
+def test_streaming_kernels_in_their_large_call_forms(hz, dev, orc):
+    """Calls of 2^24 samples take other kernel forms than small ones -- non-temporal loads and stores, a converter
+    whose lanes hold two loads in flight per tile, a Downsample whose window vectors travel together, the copy kernel
+    behind a same-format convert (csrc/hz_device.h: streams_past_cache) -- so they are compared with the oracle at
+    that size too, bit for bit, with lengths that leave a ragged tail behind the tiles."""
+    from util import bits_equal, rand_i16
+    ctx, torch = dev
+    n = (1 << 24) + 4099
+    # u8 -> c64 (iq_u8.go:103-121) and c64 -> i16 (iq_c64.go:92-103)
+    x = rand_u8(31, n)
+    want = zeros("c64", n)
+    orc.convert(want, x)
+    d = torch.zeros(n, dtype=torch.complex64, device="cuda")
+    assert ctx.convert(d, torch.from_numpy(x).cuda()) == n
+    ctx.synchronize()
+    assert bits_equal(d.cpu().numpy(), want)
+    back = torch.zeros((n, 2), dtype=torch.int16, device="cuda")
+    wi = zeros("i16", n)
+    orc.convert(wi, want)
+    assert ctx.convert(back, d) == n
+    # same-format convert = CopySamples (copy.go:31-52)
+    cp = torch.zeros(n, dtype=torch.complex64, device="cuda")
+    assert ctx.convert(cp, d) == n
+    ctx.synchronize()
+    assert bits_equal(back.cpu().numpy(), wi)
+    assert bits_equal(cp.cpu().numpy(), want)
+    # Scale and Rotate in place (internal/simd/mult.go:29-45)
+    ws = want.copy()
+    orc.scale(ws, np.float32(0.999))
+    ctx.scale(d, 0.999)
+    ctx.synchronize()
+    assert bits_equal(d.cpu().numpy(), ws)
+    orc.rotate(ws, np.complex64(0.6 + 0.8j))
+    ctx.rotate(d, 0.6 + 0.8j)
+    ctx.synchronize()
+    assert bits_equal(d.cpu().numpy(), ws)
+    # boxcar Downsample (stream/downsample.go:99-124): windows of 2 vectors (i16 / 8), 4 (/ 16), 1 (/ 4), 3 (/ 12)
+    xi = rand_i16(32, n)
+    di = torch.from_numpy(xi).cuda()
+    for factor in (8, 16, 4, 12):
+        wd = zeros("c64", n // factor + 1)
+        cnt = orc.downsample(wd, xi, factor)
+        dd = torch.zeros(n // factor + 1, dtype=torch.complex64, device="cuda")
+        assert ctx.downsample(dd, di, factor) == cnt
+        ctx.synchronize()
+        assert bits_equal(dd.cpu().numpy(), wd), factor

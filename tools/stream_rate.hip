@@ -25,6 +25,50 @@ template <int NT, class T> __device__ __forceinline__ void st(T *p, T v) {
 
 __device__ __forceinline__ float u8f(unsigned b) { return __fdiv_rn(__fsub_rn((float)b, 127.5f), 127.5f); }
 
+// (b - 127.5) / 127.5 = (2 b - 255) / 255 without the division sequence: quotient estimate by the rounded reciprocal, one
+// residual step -- t * c, fma(-q, 255, t), fma(r, c, q) -- correctly rounded for all 256 bytes (checked on the host in main)
+__device__ __host__ __forceinline__ float u8f_fast(unsigned b) {
+    const float t = (float)(2 * (int)b - 255), c = 1.0f / 255.0f;
+    const float q = t * c;
+    const float r = __builtin_fmaf(-q, 255.0f, t);
+    return __builtin_fmaf(r, c, q);
+}
+template <int NT> __global__ __launch_bounds__(256) void k_u8_fast(const unsigned *in, v4f *out, size_t nvec) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        const unsigned w0 = ld<NT>(in + i);
+        st<NT>(out + i, v4f{u8f_fast(w0 & 255), u8f_fast((w0 >> 8) & 255), u8f_fast((w0 >> 16) & 255), u8f_fast(w0 >> 24)});
+    }
+}
+
+// the same arithmetic, U loads of a lane in flight before the first store (a workgroup's tile = U runs of 256 words)
+template <int U, int NT> __global__ __launch_bounds__(256) void k_u8_tile(const unsigned *in, v4f *out, size_t nvec) {
+    const size_t tile = (size_t)256 * U;
+    for (size_t t0 = (size_t)blockIdx.x * tile; t0 + tile <= nvec; t0 += (size_t)gridDim.x * tile) {
+        unsigned a[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) a[u] = ld<NT>(in + t0 + u * 256 + threadIdx.x);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const unsigned w0 = a[u];
+            st<NT>(out + t0 + u * 256 + threadIdx.x, v4f{u8f_fast(w0 & 255), u8f_fast((w0 >> 8) & 255), u8f_fast((w0 >> 16) & 255), u8f_fast(w0 >> 24)});
+        }
+    }
+}
+// 16 bytes in per lane (8 samples), four 16-byte stores: the wave's store instruction j writes quarter j of each lane's
+// 64 bytes -- quarter lines per instruction, whole lines per wave
+template <int NT> __global__ __launch_bounds__(256) void k_u8_wide(const v4i *in, v4f *out, size_t nq) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += stride) {
+        const v4i a = ld<NT>(in + i);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned w0 = (unsigned)a[j];
+            st<NT>(out + 4 * i + j, v4f{u8f_fast(w0 & 255), u8f_fast((w0 >> 8) & 255), u8f_fast((w0 >> 16) & 255), u8f_fast(w0 >> 24)});
+        }
+    }
+}
+
 // u8 -> c64: a lane converts U groups of 8 bytes (4 samples: one 8-byte load, two 16-byte stores), the groups of a
 // trip 256 lanes apart (coalesced)
 template <int U, int NT> __global__ __launch_bounds__(256) void k_u8(const v2u *in, v4f *out, size_t ngrp) {
@@ -160,6 +204,19 @@ template <class F> static void timeit(const char *what, double bytes, F launch) 
     printf("  %-64s %6.1f us  %5.2f TB/s\n", what, us, bytes / us * 1e-6);
 }
 
+// yardsticks for the one-sided kernels: a pure FILL (16-byte stores only) and a pure READ (16-byte loads, one word
+// stored per workgroup so the loads stay) of a c64 buffer
+template <int NT> __global__ __launch_bounds__(256) void k_fill(v4f *out, size_t nvec, float v) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) st<NT>(out + i, v4f{v, v, v, v});
+}
+template <int NT> __global__ __launch_bounds__(256) void k_read(const v4f *in, size_t nvec, float *sink) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    v4f acc = {0, 0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) acc += ld<NT>(in + i);
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) sink[blockIdx.x] = acc.x;
+}
+
 static unsigned grid_for(size_t items, size_t per_block, unsigned cap) {
     size_t b = (items + per_block - 1) / per_block;
     if (cap && b > cap) b = cap;
@@ -189,6 +246,27 @@ int main() {
     U8LIB(3, 32768);
     U8LIB(2, 32768);
     U8LIB(3, 0);
+    {
+        int bad = 0;
+        for (unsigned b = 0; b < 256; b++) bad += u8f_fast(b) != ((float)b - 127.5f) / 127.5f;
+        printf("  (division-free form: %d of 256 bytes differ from (b - 127.5) / 127.5)\n", bad);
+    }
+#define U8FAST(NT, CAP) timeit("library form, division-free arithmetic, NT " #NT ", grid cap " #CAP, 10.0 * n, [&](int b) { \
+        hipLaunchKernelGGL((k_u8_fast<NT>), dim3(grid_for(nvec1, 256, CAP)), dim3(256), 0, 0, (const unsigned *)u8[b], (v4f *)c64[b], nvec1); })
+    U8FAST(0, 32768);
+    U8FAST(3, 32768);
+    U8FAST(3, 0);
+#define U8TILE(U, NT, CAP) timeit("division-free, " #U " loads in flight per lane, NT " #NT ", grid cap " #CAP, 10.0 * n, [&](int b) { \
+        hipLaunchKernelGGL((k_u8_tile<U, NT>), dim3(grid_for(nvec1, 256 * U, CAP)), dim3(256), 0, 0, (const unsigned *)u8[b], (v4f *)c64[b], nvec1); })
+    U8TILE(2, 3, 0);
+    U8TILE(4, 3, 0);
+    U8TILE(8, 3, 0);
+    U8TILE(4, 3, 4096);
+    U8TILE(4, 2, 0);
+    timeit("division-free, 16 B in / 64 B out per lane, NT 3", 10.0 * n, [&](int b) {
+        hipLaunchKernelGGL((k_u8_wide<3>), dim3(grid_for(n / 8, 256, 0)), dim3(256), 0, 0, (const v4i *)u8[b], (v4f *)c64[b], n / 8); });
+    timeit("division-free, 16 B in / 64 B out per lane, NT 0", 10.0 * n, [&](int b) {
+        hipLaunchKernelGGL((k_u8_wide<0>), dim3(grid_for(n / 8, 256, 0)), dim3(256), 0, 0, (const v4i *)u8[b], (v4f *)c64[b], n / 8); });
 #define U8(U, NT, CAP) timeit("8 B in, 32 B out per lane, U " #U ", NT " #NT ", grid cap " #CAP, 10.0 * n, [&](int b) { \
         hipLaunchKernelGGL((k_u8<U, NT>), dim3(grid_for(ngrp, 256 * U, CAP)), dim3(256), 0, 0, (const v2u *)u8[b], (v4f *)c64[b], ngrp); })
     U8(1, 0, 0);
@@ -220,5 +298,18 @@ int main() {
     SC(2, 0, 0);
     SC(4, 3, 0);
     SC(2, 2, 0);
+    printf("one-sided yardsticks over the c64 buffers (8 B/sample):\n");
+    float *sink;
+    CK(hipMalloc(&sink, 1 << 20));
+#define FILL(NT, CAP) timeit("fill (stores only), NT " #NT ", grid cap " #CAP, 8.0 * n, [&](int b) { \
+        hipLaunchKernelGGL((k_fill<NT>), dim3(grid_for(n / 2, 256, CAP)), dim3(256), 0, 0, (v4f *)c64[b], n / 2, 0.5f); })
+    FILL(0, 32768);
+    FILL(2, 32768);
+    FILL(2, 0);
+#define READ(NT, CAP) timeit("read (loads only), NT " #NT ", grid cap " #CAP, 8.0 * n, [&](int b) { \
+        hipLaunchKernelGGL((k_read<NT>), dim3(grid_for(n / 2, 256, CAP)), dim3(256), 0, 0, (const v4f *)c64[b], n / 2, sink); })
+    READ(0, 32768);
+    READ(1, 32768);
+    READ(1, 0);
     return 0;
 }
