@@ -175,6 +175,8 @@ static bool mm_eligible(const hzsdr_chain *c) {
 static bool mm2_eligible(const hzsdr_chain *c) {
     if (c->fir_impl == HZSDR_FIR_IMPL_MATRIX_CHUNKS || (c->fir_impl == HZSDR_FIR_IMPL_AUTO && diag_env().mm_v1)) return false;
     if (!mm2::factor_ok(c->factor)) return false;
+    // (the kernel's int32 sum of the two top digit planes must hold for every input: hz_firmm_plan.h)
+    if (!mm::int32_combine_ok(c->taps_host.data(), c->ntaps, mm_scale(c), mm::digit_shift(c->taps_host.data(), c->ntaps, mm_scale(c)))) return false;
     const mm2::Geom g = mm2::make_geom((int)c->ntaps, (int)c->factor, c->off, 0);
     const int D = (int)c->factor;
     return mm2::image_bytes(D, g.ks) <= (size_t)mm2::kU * 64 * 16 && mm2::table_bytes(g.ne) <= (size_t)4 * mm2::kThreads * 16 &&

@@ -99,6 +99,18 @@ inline int digit_shift(const double *taps, size_t ntaps, double scale) {
     return S < -900 ? -900 : S > 900 ? 900 : S;
 }
 
+// The persistent-pass kernel adds the two top digit planes in int32 before the float64 step: hi = 256 sum_0 + sum_1 =
+// sum over the 2 ntaps (coefficient, byte) products of an output part of A x, A = 256 d0 + d1.  With q = A 2^16 + (d2 2^8 + d3),
+// |d2 2^8 + d3| <= 2^15 + 2^7 and |q| <= |h' component| 2^S + 1/2:  |A| <= |h' component| 2^(S-16) + 0.52, and over a tap's two
+// components |re| + |im| <= sqrt(2) |h'| whatever the run's modulation.  |x| <= 128.  True when |hi| < 2^31 for EVERY
+// input and modulation (a long flat filter -- 1024 equal taps -- does not pass: such a chain takes the chunk form).
+inline bool int32_combine_ok(const double *taps, size_t ntaps, double scale, int S) {
+    double sum = 0.0;
+    for (size_t k = 0; k < ntaps; k++) sum += hypot(taps[2 * k], taps[2 * k + 1]);
+    const double bound = 128.0 * (1.4142135623730951 * sum * scale * ldexp(1.0, S - 16) + 2.0 * (double)ntaps);
+    return bound < 2147483648.0;
+}
+
 // The digit table of taps[k] * exp(-i omega k step) * scale: 32-bit fixed point q = round(h' 2^S) in four balanced
 // base-256 digits, d = 0 most significant.  Chunk form (v2 = false): F[digit][E][part][16]; persistent-pass form:
 // T[f][E][part][pl][16] with digit = 2 f + pl (a fragment row holds two digit planes).  Entry E, byte e of part

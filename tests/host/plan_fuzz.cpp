@@ -51,7 +51,7 @@ int main(int argc, char **argv) {
     const int cases = argc > 1 ? atoi(argv[1]) : 3000;
     const double tau = 6.283185307179586476925286766559;
     const uint64_t rates[] = {250000, 1000000, 1048576, 1800000, 2048000, 2097152, 2400000, 8000000, 20000000, 200000000};
-    long planned = 0, fell_back = 0, chunks_planned = 0, tables = 0;
+    long planned = 0, fell_back = 0, chunks_planned = 0, tables = 0, combine_refused = 0;
     for (g_case = 0; g_case < cases; g_case++) {
         const uint64_t fs = rates[rnd() % (sizeof rates / sizeof rates[0])];
         double ts0;
@@ -178,6 +178,7 @@ int main(int argc, char **argv) {
                 sr += q[2 * k], si += q[2 * k + 1];
             }
             size_t seen = 0;
+            int64_t top2[2] = {0, 0};  // sum over an output part's entries of |256 d0 + d1|
             for (int E = 0; E < g.ne; E++)
                 for (int pout = 0; pout < 2; pout++)
                     for (int e = 0; e < 16; e++) {
@@ -186,6 +187,7 @@ int main(int argc, char **argv) {
                         for (int d = 0; d < 4; d++) {
                             const size_t at = v2 ? ((((size_t)(d >> 1) * g.ne + E) * 2 + pout) * 2 + (d & 1)) : (((size_t)d * g.ne + E) * 2 + pout);
                             v = v * 256 + (int8_t)tab[at * 16 + e];
+                            if (d == 1) top2[pout] += llabs(v);
                         }
                         if (kap < 0 || kap >= nt) {
                             REQUIRE(v == 0);
@@ -196,6 +198,9 @@ int main(int argc, char **argv) {
                         seen++;
                     }
             REQUIRE(seen == 4 * (size_t)nt);  // every tap, (re, im) x (I, Q), exactly once
+            // mm::int32_combine_ok: where it says yes, the int32 sum of the two top planes holds for every input byte
+            if (mm::int32_combine_ok(taps.data(), (size_t)nt, scale, S)) REQUIRE(128 * top2[0] < (1ll << 31) && 128 * top2[1] < (1ll << 31));
+            else combine_refused++;
             double dc[2];
             memcpy(dc, tab.data() + (size_t)4 * g.ne * 32, 16);
             REQUIRE(scale == 1.0 / 128.0 ? (dc[0] == 0.0 && dc[1] == 0.0) : (dc[0] == 0.5 * (double)(sr - si) && dc[1] == 0.5 * (double)(sr + si)));
@@ -311,6 +316,6 @@ int main(int argc, char **argv) {
         REQUIRE(short_planned <= 1);
         printf("plan_fuzz wrap call: %zu clock runs, %d with a table, %d on the matrix path (%d of them short), %d fix-up tasks\n", need, with_table, L.n, short_planned, F.n_task);
     }
-    printf("plan_fuzz ok: %d cases, %ld planned, %ld kept the transforms; %ld chunk plans, %ld digit tables\n", cases, planned, fell_back, chunks_planned, tables);
+    printf("plan_fuzz ok: %d cases, %ld planned, %ld kept the transforms; %ld chunk plans, %ld digit tables (%ld refused the int32 plane sum)\n", cases, planned, fell_back, chunks_planned, tables, combine_refused);
     return 0;
 }

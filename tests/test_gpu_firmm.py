@@ -223,6 +223,29 @@ def test_where_the_matrix_form_must_not_run(hz, ctx, orc):
     assert np.linalg.norm(d) <= 3e-7 * np.linalg.norm(want8.astype(np.complex128))
 
 
+def test_flat_filter_leaves_the_int32_plane_sum(hz, ctx, orc):
+    """The persistent-pass kernel adds its two top digit planes in int32.  That sum holds for every input only while
+    sqrt(2) * sum|h| stays below the bound of hz_firmm_plan.h (int32_combine_ok); a 1024-tap boxcar -- every tap at the
+    maximum -- with the input that lines all signs up (bytes 0 and 255) would pass 2^31, so such a chain takes the
+    chunk form of the matrix path, whose planes meet in float64, and the result stays inside the bound."""
+    rate, D, n = 20_000_000, 8, 1 << 19
+    flat = np.full(1024, (1 + 1j) / 1024, np.complex64)
+    ch = ctx.chain(hz.FMT_U8, rate).fir_decimate(flat, D)
+    for x in (np.zeros((n, 2), np.uint8), np.full((n, 2), 255, np.uint8), rand_u8(77, n)):
+        out = zeros("c64", n // D)
+        ch.reset()
+        ch.run(x, out)
+        assert ch.last_fir_path() == hz.FIR_PATH_MATRIX and ch.last_fir_kernel() == hz.FIR_KERNEL_MATRIX_CHUNKS
+        want, xmax = oracle(orc, x, rate, [], flat, D)
+        assert_fir_close(out, want, flat, xmax, "flat filter")
+    ch.close()
+    # an ordinary low-pass of the same length keeps the persistent passes
+    ch = ctx.chain(hz.FMT_U8, rate).fir_decimate(taps_for(1024), D)
+    ch.run(rand_u8(78, n), zeros("c64", n // D))
+    assert ch.last_fir_kernel() == hz.FIR_KERNEL_MATRIX_PASSES
+    ch.close()
+
+
 def test_misaligned_device_buffers_take_the_transforms(hz, orc):
     import torch
     ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
