@@ -748,6 +748,31 @@ def test_convolution_blocks_walk_far_more_blocks_than_the_grid_holds(env, orc, f
         assert _rel_l2(got[b * flen:(b + 1) * flen], want[i * flen:(i + 1) * flen]) < 2e-6, (flen, b)
 
 
+@pytest.mark.parametrize("flen,nblk", [(1024, 8192 + 5), (512, 20000 + 3), (256, 40000 + 37)])
+def test_convolution_blocks_shared_tables_walk_ragged_block_counts(env, orc, flen, nblk):
+    """Blocks of 1024 points and fewer run in workgroups of sixteen waves that share the tables in LDS and never
+    meet after the first barrier (conv_blocks_shared_kernel): a wave holds one, two or four transforms, walks
+    its blocks with the next ones' loads in flight, and the last trip is ragged -- some waves, and some of a wave's
+    transforms, have no block left.  Sampled blocks against the oracle (blocks are independent), the partial block
+    behind the last whole one untouched.  Tolerance: relative L2 <= 2e-6 per block."""
+    if env.kind != "device":
+        pytest.skip("one memory space is enough for a kernel-internal ordering")
+    rng = np.random.default_rng(flen)
+    n = nblk * flen + flen // 2
+    x = (rng.standard_normal(n, dtype=np.float32) + 1j * rng.standard_normal(n, dtype=np.float32)).astype(np.complex64)
+    H = _lowpass_bins(flen)
+    out = env.zeros("c64", n)
+    assert env.ctx.convolution_blocks(out, env.put(x), env.put(H)) == nblk * flen
+    got = env.get(out)
+    assert np.all(got[nblk * flen:] == 0)
+    pick = sorted(set(list(range(0, nblk, 211)) + [1, 2, 3, 63, 64, 65] + list(range(nblk - 70, nblk))))
+    xs = np.concatenate([x[b * flen:(b + 1) * flen] for b in pick])
+    want = zeros("c64", len(xs))
+    assert orc.convolution_reader(want, xs, H) == len(xs)
+    for i, b in enumerate(pick):
+        assert _rel_l2(got[b * flen:(b + 1) * flen], want[i * flen:(i + 1) * flen]) < 2e-6, (flen, b)
+
+
 @pytest.mark.parametrize("n", [8, 1024, 32768, 1000, 4099])
 def test_convolve_closures(env, orc, n):
     hz = env.hz
