@@ -775,7 +775,7 @@ __global__ __launch_bounds__(fv::block(N), conv_occupancy(N, STAGED)) void conv_
     }
 }
 
-// c64 blocks of N <= 1024 points (a transform inside ONE wave) with nothing elementwise in front: W waves of a workgroup
+// Blocks of N <= 1024 points (a transform inside ONE wave) with nothing elementwise in front but the conversion: W waves of a workgroup
 // walk the blocks side by side and share ONE copy of the twiddle tables and of the filter's bins IN LDS.
 // Why: a wave's vector-memory loads return in order.  conv_blocks_kernel16 keeps the next block's sixteen loads in flight
 // under the current block's transforms, but its table and filter reads (L2 hits) queue up BEHIND those loads, so the
@@ -791,8 +791,8 @@ template <int N> struct ConvShared {
     static_assert(TPT <= 64 && TPT >= 16, "one wave per transform");
 };
 
-template <int N, int W>
-__global__ __launch_bounds__(64 * W) void conv_blocks_shared_kernel(const float2 *__restrict__ in, float2 *__restrict__ out,
+template <int N, int W, int FMT = HZSDR_FMT_C64>
+__global__ __launch_bounds__(64 * W) void conv_blocks_shared_kernel(const typename Raw<FMT>::t *__restrict__ in, float2 *__restrict__ out,
                                                                     const float2 *__restrict__ filt, FvTabs tabs, size_t nblocks) {
     using G = ConvShared<N>;
     constexpr int TPT = G::TPT, XPW = G::XPW, R0 = fv::first_radix(N);
@@ -809,21 +809,22 @@ __global__ __launch_bounds__(64 * W) void conv_blocks_shared_kernel(const float2
     // consecutive blocks side by side: the workgroup reads W * XPW blocks = W * 8 KiB in one run per trip
     const size_t stride = (size_t)gridDim.x * W * XPW;
     size_t b = ((size_t)blockIdx.x * W + wave) * XPW + sub;
+    using RT = typename Raw<FMT>::t;  // (a byte or i16 source converts on its way into the first pass's registers)
     cf v[16];
-    float2 nx[16];
+    RT nx[16];
     {
-        const float2 *pb = in + b * N + lane;
+        const RT *pb = in + b * N + lane;
 #pragma unroll
-        for (int q = 0; q < 16; q++) nx[q] = b < nblocks ? pb[fv::edge_off<N, R0>(q)] : float2{};
+        for (int q = 0; q < 16; q++) nx[q] = b < nblocks ? pb[fv::edge_off<N, R0>(q)] : RT{};
     }
 #pragma unroll 1
     for (size_t b0 = ((size_t)blockIdx.x * W + wave) * XPW; b0 < nblocks; b0 += stride, b += stride) {  // (uniform in a wave)
         const bool live = XPW == 1 || b < nblocks;
 #pragma unroll
-        for (int q = 0; q < 16; q++) v[q] = fv::from2(nx[q]);
+        for (int q = 0; q < 16; q++) v[q] = fv::from2(Raw<FMT>::cvt(nx[q]));
         const size_t bn = b + stride;
         if (XPW == 1 ? b0 + stride < nblocks : bn < nblocks) {
-            const float2 *pb = in + bn * N + lane;
+            const RT *pb = in + bn * N + lane;
 #pragma unroll
             for (int q = 0; q < 16; q++) nx[q] = pb[fv::edge_off<N, R0>(q)];
         }

@@ -13,15 +13,15 @@ static int launch_conv_n(hzsdr_ctx *ctx, const void *in, void *out, const void *
         constexpr int XPB = fv::xpb(N);
         const dim3 grid((unsigned)((nblocks + XPB - 1) / XPB)), block(fv::block(N));
         const size_t lds = (size_t)XPB * fv::lds_elems(N) * sizeof(cf);
-        if constexpr (fv::tpt(N) <= 64 && FMT == HZSDR_FMT_C64) {
-            if (direct && dec <= 1) {
+        if constexpr (fv::tpt(N) <= 64) {
+            if (P.n == 0 && dec <= 1) {
                 // one workgroup of sixteen waves per CU, tables and filter once in its LDS
                 using G = ConvShared<N>;
                 constexpr int W = 16;
                 const size_t groups = (nblocks + (size_t)W * G::XPW - 1) / ((size_t)W * G::XPW);
                 const dim3 grid_s((unsigned)std::min<size_t>(groups, (size_t)ctx->num_cus));
-                return launch_fv(conv_blocks_shared_kernel<N, W>, grid_s, dim3(64 * W), G::lds_bytes(W), ctx->stream, (const float2 *)in,
-                                 (float2 *)out, (const float2 *)filt, tabs, nblocks);
+                return launch_fv(conv_blocks_shared_kernel<N, W, FMT>, grid_s, dim3(64 * W), G::lds_bytes(W), ctx->stream,
+                                 (const typename Raw<FMT>::t *)in, (float2 *)out, (const float2 *)filt, tabs, nblocks);
             }
         }
         if (direct) {

@@ -1035,6 +1035,33 @@ def test_chain_reference_convolution_then_decimate(env, orc):
     ch.close()
 
 
+@pytest.mark.parametrize("fmt,flen,nblk", [("u8", 1024, 4096 + 7), ("i16", 512, 8192 + 3), ("i8", 256, 16384 + 21)])
+def test_chain_convert_then_convolution_from_byte_sources(env, orc, fmt, flen, nblk):
+    """ConvertReader -> ConvolutionReader fused, nothing elementwise between them: the shared-table block kernel
+    converts on its way into the first pass's registers (csrc/hz_chain_dev.h: conv_blocks_shared_kernel<N, W, FMT>).
+    The conversion is bit-exact, so what differs from the oracle is FFT round-off: relative L2 <= 2e-6 per block,
+    on a sample of the blocks; the partial block is not consumed."""
+    if env.kind != "device":
+        pytest.skip("one memory space is enough for a kernel-internal path")
+    gen = {"u8": rand_u8, "i8": rand_i8, "i16": rand_i16}[fmt]
+    n = nblk * flen + flen // 3
+    x = gen(41, n)
+    H = _lowpass_bins(flen)
+    ch = env.ctx.chain(getattr(env.hz, "FMT_" + fmt.upper()), 2_400_000).convolution(env.put(H))
+    out = env.zeros("c64", n)
+    assert ch.run(env.put(x), out) == (nblk * flen, nblk * flen)
+    got = env.get(out)
+    ch.close()
+    pick = sorted(set(list(range(0, nblk, 331)) + [1, 2, 3, 64] + list(range(nblk - 40, nblk))))
+    xs = np.concatenate([x[b * flen:(b + 1) * flen] for b in pick])
+    xc = zeros("c64", len(xs))
+    orc.convert(xc, xs)
+    want = zeros("c64", len(xs))
+    assert orc.convolution_reader(want, xc, H) == len(xs)
+    for i, b in enumerate(pick):
+        assert _rel_l2(got[b * flen:(b + 1) * flen], want[i * flen:(i + 1) * flen]) < 2e-6, (fmt, flen, b)
+
+
 @pytest.mark.parametrize("flen,D", [(1536, 8), (96, 4), (1200, 1), (4099, 1)])
 def test_chain_convolution_of_any_length_then_decimate(env, orc, flen, D):
     """The same chain with a filter whose length is not a power of two (stream/convolution.go:57-61 blocks on
