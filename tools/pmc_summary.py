@@ -45,7 +45,8 @@ def main():
         res["kernels"][short] = {"FETCH_SIZE_bytes_raw": round(fr), "WRITE_SIZE_bytes": round(wr),
                                  "read_bytes_corrected_x2": round(2 * fr), "hbm_bytes": round(2 * fr + wr)}
         if any(t in short for t in ("convert_vec_kernel<0>", "convert_vec_kernel<(hz::Conv)0>",
-                                    "convert_vec_kernel<0, 0>", "convert_vec_kernel<0, 0, true>", "convert_vec_kernel<0, 0, false>")):
+                                    "convert_vec_kernel<0, 0>", "convert_vec_kernel<0, 0, true>", "convert_vec_kernel<0, 0, false>",
+                                    "convert_tile_kernel<0, 0, 2>")):
             cal = {"kernel": short, "known_read_bytes": 2 * n, "known_write_bytes": 8 * n,
                    "read_factor_needed": round(2 * n / fr, 3) if fr else None,
                    "write_factor_needed": round(8 * n / wr, 3) if wr else None}
