@@ -424,7 +424,9 @@ int hzsdr_chain_shift_ulp1(hzsdr_chain *c, int on);
 int hzsdr_chain_last_fir_path(const hzsdr_chain *c, int *path);
 /* The same question one level down: WHICH matrix kernel (logs, benchmarks, the tests that pin a kernel):
  *   HZSDR_FIR_KERNEL_MATRIX_PASSES  csrc/hz_firmm2.h -- one persistent workgroup per CU, the tap table in LDS,
- *                                   512-output passes from a queue: factor 8, up to ~1150 taps
+ *                                   512-output passes from a queue: factor 8, up to ~1150 taps, filters whose two top
+ *                                   digit planes add up in int32 for every input (csrc/hz_firmm_plan.h,
+ *                                   int32_combine_ok: every practical low-pass; a 1024-tap boxcar takes CHUNKS)
  *   HZSDR_FIR_KERNEL_MATRIX_CHUNKS  csrc/hz_firmm.h -- one round of 2048-output chunk workgroups: the other
  *                                   factors and tap counts of HZSDR_FIR_PATH_MATRIX (and HZ_MM_V1=1)
  * (no reference counterpart: stream.* Readers have one implementation each.) */
