@@ -89,6 +89,21 @@ def timed_rot(torch, fn_i, steps, warmup):
     return timed(torch, lambda: fn_i(next(it)), steps, warmup)
 
 
+def stream_rot(torch, fn_i, steps, warmup):
+    """Device time per call of `steps` back-to-back calls of a rotation: ONE event pair around all of them -- what
+    rocprofv3 lists per launch; an event pair per call (`timed`) adds the gap between two launches to a short kernel."""
+    for i in range(warmup):
+        fn_i(i)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(steps):
+        fn_i(warmup + i)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / steps
+
+
 def self_launch(args):
     """Parent of a multi-rank run: spawn torch.distributed.run as a child, relay stdout
     (the ONE JSON line rank 0 prints) and stderr, return the child's exit code."""
@@ -479,11 +494,18 @@ def main():
         cs = [c] + [torch.from_numpy(synth_c64(20 + i, n)).cuda() for i in range(kRot - 1)]
         outs = [out] + [torch.zeros(n, dtype=torch.complex64, device="cuda") for _ in range(kRot - 1)]
 
+        def back_to_back(fn_i, bytes_per_sample):
+            # the same rotation, 3 k calls one behind the other between ONE event pair (no event between the launches)
+            ms = stream_rot(torch, fn_i, 3 * k, w)
+            return {"stream_ms": round(ms, 4), "stream_GBps": round(bytes_per_sample * n / (ms * 1e-3) / 1e9, 1),
+                    "stream_hbm_frac": round(bytes_per_sample * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
         def both(name, fn_i, bytes_per_sample):
             _, ms = timed(torch, lambda: fn_i(0), k, w)
             extra[name] = rate(n, float(np.median(ms)), bytes_per_sample)
             _, ms = timed_rot(torch, fn_i, k, w)
             extra[name]["hbm"] = dict(rate(n, float(np.median(ms)), bytes_per_sample), buffer_pairs=kRot)
+            extra[name]["hbm"].update(back_to_back(fn_i, bytes_per_sample))
 
         # the same-run device copy (8 B read + 8 B written per sample): the practical HBM
         # ceiling the HBM-bound rows below are also quoted against
@@ -545,6 +567,7 @@ def main():
         extra["downsample8_i16"] = rate(n, float(np.median(ms)), 5)
         _, ms = timed_rot(torch, lambda i: ctx.downsample(o8s[i % 6], xis[i % 6], 8), k, w)
         extra["downsample8_i16"]["hbm"] = dict(rate(n, float(np.median(ms)), 5), buffer_pairs=6)
+        extra["downsample8_i16"]["hbm"].update(back_to_back(lambda i: ctx.downsample(o8s[i % 6], xis[i % 6], 8), 5))
         del xis[1:], o8s[1:]
         # cfg 4, north-star form: a designed FIR-decimate by 8 from i16 (polyphase: 256 and 1024 taps; 4 + 8/8 B per
         # input sample), on the overlap-save transform kernels (i16 has no matrix form)
@@ -565,6 +588,8 @@ def main():
                 row["frac_of_device_copy"] = round(row["GBps"] / copy_gbps, 4)
                 if "hbm" in row:
                     row["hbm"]["frac_of_device_copy"] = round(row["hbm"]["GBps"] / copy_hbm_gbps, 4)
+                    if "stream_GBps" in row["hbm"]:
+                        row["hbm"]["stream_frac_of_device_copy"] = round(row["hbm"]["stream_GBps"] / extra["device_copy_c64"]["hbm"]["stream_GBps"], 4)
         extra["small_buffers"] = small_buffers_gpu(hz, ctx, torch, local_rank)
         result["extra"] = extra
 
