@@ -436,6 +436,11 @@ int pipeline_begin(hzsdr_chain *c, const CallBatch &cb, int fmt_size, hipStream_
         HZ_HIP(ctx, hipStreamWaitEvent(*a, c->ready, 0));
         if (b) HZ_HIP(ctx, hipStreamWaitEvent(*b, c->ready, 0));
     }
+    // The two streams never wait for each other otherwise, so nothing would bound how far one may fall behind: call
+    // k - 3's kernel ran on the OTHER stream, and a caller that rotates three buffer sets writes the set it wrote.
+    // This call's stream waits for that kernel (long finished in any normal run: the wait costs the GPU nothing);
+    // with the check above -- calls k - 1 and k - 2 -- every earlier call is then ordered in front of this one.
+    if (k >= 3) HZ_HIP(ctx, hipStreamWaitEvent(*a, c->ev_done[(k - 3) & 3], 0));
     c->pbufs[1] = c->pbufs[0];
     c->pbufs[0] = now;
     return HZSDR_OK;

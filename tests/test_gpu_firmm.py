@@ -385,6 +385,41 @@ def test_pipelined_chain_is_bit_identical_to_the_plain_one(hz):
         c.close()
 
 
+@pytest.mark.parametrize("sets", [2, 3, 5])
+def test_pipelined_chain_over_a_small_rotation_of_buffers(hz, sets):
+    """A caller that rotates two, three or five (input, output) sets under hzsdr_chain_run_after with nothing to wait
+    for: a call writes the output a call two, three or five places back wrote.  Two back is the chain's own stream,
+    three back its OTHER stream (the call's stream waits for that kernel: csrc/hz_chain_fir.hip, pipeline_begin), one
+    back and the history kernels are found by buffer span.  Each output is copied away on the context's stream right
+    behind its call (ordered there, like any consumer) and compared with the plain chain's, bit for bit."""
+    import torch
+    n, fs, D = 1 << 20, 20_000_000, 8
+    taps = taps_for(1024, 1 / 16, 0.0)
+    res = []
+    for piped in (False, True):
+        s = torch.cuda.Stream()
+        ctx = hz.Context(0, hz.MEM_DEVICE, stream=s.cuda_stream)
+        ch = ctx.chain(hz.FMT_U8, fs).shift(-fs / 8).fir_decimate(taps, D)
+        if piped:
+            ch.pipeline(True)
+        ch.set_time(TAU - 0.3)
+        xs = [torch.from_numpy(rand_u8(500 + i, n)).cuda() for i in range(sets)]
+        ys = [torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(sets)]
+        keep = [torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(24)]
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s):
+            for i in range(24):
+                run = ch.run_after if piped else ch.run
+                assert run(xs[i % sets], ys[i % sets]) == (n, n // D)
+                keep[i].copy_(ys[i % sets])  # (on the context's stream: behind the call, in front of the next writer)
+        ctx.synchronize()
+        res.append([torch.view_as_real(k).view(torch.int32).cpu().numpy() for k in keep])
+        ch.close()
+        ctx.close()
+    for i, (a, b) in enumerate(zip(*res)):
+        assert np.array_equal(a, b), "call %d differs" % i
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_pipelined_chain_random_calls_bit_identical(hz, seed):
     """Random call lengths (whole tiles and ragged, some below the matrix path's minimum), i8 and u8 sources, random
