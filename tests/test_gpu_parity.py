@@ -644,6 +644,26 @@ def test_fft_any_length_against_float64(env, n):
     p.close()
 
 
+def test_fft_any_length_at_its_upper_limit(env):
+    """The largest length that is not a power of two: 2^23 - 3 runs as a chirp transform over the 2^24-point plan
+    (include/hzsdr.h: any length up to 2^23, powers of two up to 2^24); 2^23 + 1 is refused when the plan is made, as a
+    planner's refusal is in the reference (fft/fft.go:45-48 returns an error).  Tolerance as above."""
+    if env.kind != "device":
+        pytest.skip("1 GiB of scratch once is enough")
+    hz = env.hz
+    n = (1 << 23) - 3
+    x = rand_c64(77, n)
+    X = np.fft.fft(x.astype(np.complex128))
+    iq, fr = env.put(x), env.zeros("c64", n)
+    p = env.ctx.fft_plan(iq, fr, hz.FFT_FORWARD)
+    p.transform()
+    assert _rel_l2(env.get(fr), X) < 3e-7 * 23 + 1e-7
+    p.close()
+    big = env.zeros("c64", (1 << 23) + 1)
+    with pytest.raises(hz.ErrInvalidArgument):
+        env.ctx.fft_plan(big, env.zeros("c64", (1 << 23) + 1), hz.FFT_FORWARD)
+
+
 def test_fft_conformance_at_a_length_that_is_not_a_power_of_two(env, orc):
     """testutils/fft.go:54-138 at N = 1000: a CW tone lands in its bin (forward), a single bin comes back as that bin
     (backward then forward), mismatched lengths are refused."""
