@@ -466,10 +466,12 @@ static int mm2_launch_pipelined(hzsdr_chain *c, const void *in, void *out, size_
     HZ_TRY(pipeline_begin(c, cb, format_size(c->src_fmt), &a, &b));
     // (the history is the call's last `off` samples: of the last buffer, indexed like the whole call)
     const void *last = (const void *)(uintptr_t)B.vin[B.nbuf - 1];
-    int rc = mm2::launch_history(b, c->src_fmt, last, (float2 *)c->hist[c->hist_next()], (uint8_t *)c->rhist[c->hist_next()], n, c->mmg.off, P);
-    if (rc == HZSDR_OK)
-        rc = mm2::launch_fir(a, ctx->num_cus, c->src_fmt, c->factor, in, (float2 *)out, (const float2 *)c->hist[c->hist_cur], nullptr,
+    // (the call's kernel first: a sequence's first call starts on an idle GPU, and the history kernel is needed by the
+    // NEXT call only)
+    int rc = mm2::launch_fir(a, ctx->num_cus, c->src_fmt, c->factor, in, (float2 *)out, (const float2 *)c->hist[c->hist_cur], nullptr,
                              (const uint8_t *)c->rhist[c->hist_cur], nullptr, (const float2 *)c->taps_dev, n, g2, L, P, F, B, c->fir_loop_form);
+    if (rc == HZSDR_OK)
+        rc = mm2::launch_history(b, c->src_fmt, last, (float2 *)c->hist[c->hist_next()], (uint8_t *)c->rhist[c->hist_next()], n, c->mmg.off, P);
     // (whatever happened, what was launched is joined; after a failure the chain starts over: the history ring's
     // place in the streams' order is no longer what the next call would assume)
     const int rj = pipeline_join(c, a, b);
