@@ -19,8 +19,10 @@ def main():
         if not files:
             print(f"{d}: no kernel trace")
             continue
+        import os
+        newest = max(files, key=os.path.getmtime)  # (a directory collects one file set per profiled run)
         du = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-              for r in csv.DictReader(open(files[0])) if "fir_mm2_kernel" in r["Kernel_Name"]]
+              for r in csv.DictReader(open(newest)) if "fir_mm2_kernel" in r["Kernel_Name"]]
         one = [x for x in du if x <= 70]
         many = [x for x in du if x > 70]
         print(f"{d.rstrip('/').split('/')[-1]}: {len(du)} launches of hz::mm2::fir_mm2_kernel")
