@@ -138,6 +138,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the per-config side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle TIMING (the parity check still runs)")
     ap.add_argument("--no-oracle", action="store_true", help="skip everything that needs oracle/ (profiling runs)")
+    ap.add_argument("--no-full-parity", action="store_true", help="skip the full-size check of the timed form (2 x batch x 2^log2n samples through the oracle)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="the headline chain WITHOUT hzsdr_chain_pipeline: one launch behind the other, as rounds 1-3 measured")
     ap.add_argument("--batch", type=int, default=4,
@@ -678,6 +679,58 @@ def main():
                                     "bounds: max abs <= 6e-7 * sum|h| * max|x| and relative L2 <= 3e-7"}
         chk.close()
         del yg, got, want
+        # (a') the TIMED FORM itself at its full size: ONE call over B separately allocated buffers of n samples (the
+        # headline's hzsdr_chain_run_batch[_after]: 16 384 passes per launch at B = 4, a pass's buffer by a 32-bit
+        # reciprocal, virtual base pointers), the clock's 2*pi wrap inside the call, then a second call that continues
+        # the stream -- EVERY output of both calls against the oracle (the reference-order stages and the float64
+        # direct form on every host core), per buffer.  Round 5 checked this form at 8 x 2^19 samples only.
+        if B > 1 and n * B >= (1 << 22) and not args.no_full_parity:
+            threads = orc.max_threads()
+            nb = 2 * B
+            ts1 = 6.283185307179586 - 0.6 * B * n / fs  # (the wrap 60 % into the first call)
+            while ts1 < 0.0:
+                ts1 += 6.283185307179586
+            xf = synth_u8(19, nb * n)
+            bf = np.zeros(nb * n, np.complex64)
+            orc.par_u8_to_c64(xf, bf, threads)
+            ts_want = orc.par_shift_gain(ts1, fs, shift, 1.0, bf, threads)  # (gain 1.0: the Shift alone)
+            wantf = np.zeros(nb * n // D, np.complex64)
+            orc.par_fir_decimate_f64(wantf, bf, taps, D)
+            xmaxf = float(np.abs(bf[:1 << 20]).max())
+            del bf
+            xg = [torch.from_numpy(xf[j * n:(j + 1) * n]).cuda() for j in range(nb)]
+            yg = [torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(nb)]
+            del xf
+            chk = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D)
+            if piped:
+                chk.pipeline(True)
+            chk.set_time(ts1)
+            torch.cuda.synchronize()
+            kernels = []
+            for j in range(0, nb, B):
+                chk.run_batch(xg[j:j + B], yg[j:j + B], after=piped)
+                kernels.append(chk.last_fir_kernel())
+            torch.cuda.synchronize()
+            boundf = 6e-7 * float(np.abs(taps).sum()) * xmaxf
+            per_buf = []
+            for j in range(nb):
+                g = yg[j].cpu().numpy().astype(np.complex128)
+                w = wantf[j * (n // D):(j + 1) * (n // D)]
+                per_buf.append((float(np.abs(g - w).max()), float(np.linalg.norm(g - w) / np.linalg.norm(w.astype(np.complex128)))))
+            ok_full = bool(all(e <= boundf and r <= 3e-7 for e, r in per_buf) and chk.time() == ts_want
+                           and all(kq == hz.FIR_KERNEL_MATRIX_PASSES for kq in kernels))
+            result["parity"]["timed_form"] = {
+                "calls": nb // B, "buffers_per_call": B, "samples_per_buffer": n, "overlapped": bool(piped),
+                "checked_outputs": nb * n // D, "max_abs_err": max(e for e, _ in per_buf), "bound": boundf,
+                "rel_l2_err_worst_buffer": max(r for _, r in per_buf), "rel_l2_bound": 3e-7, "clock_start": ts1,
+                "clock_after_equal": bool(chk.time() == ts_want), "one_launch_per_call": bool(all(kq == hz.FIR_KERNEL_MATRIX_PASSES for kq in kernels)),
+                "ok": ok_full,
+                "what": "the benchmarked entry point at the benchmarked size: every output of two consecutive calls over "
+                        "separately allocated buffers (the 2*pi wrap inside the first) against the oracle, per buffer"}
+            result["parity"]["checked_outputs"] += nb * n // D
+            result["parity"]["ok"] = parity_ok = bool(parity_ok and ok_full)
+            chk.close()
+            del xg, yg, wantf
         # (b) CPU baseline: the oracle (scalar port), one thread, bounded sample (N = 1 only)
         if world == 1 and not args.no_cpu_baseline:
             outc = np.zeros(ns // D, np.complex64)

@@ -161,7 +161,13 @@ int chain_launch(hzsdr_chain *c, const void *din, size_t cons, void *dout, size_
     P.n = c->n_ops;
     for (int i = 0; i < c->n_ops; i++) P.op[i] = c->ops[i];
     double ts = c->ts;
-    if (c->has_shift) HZ_TRY(nco_plan(c->ctx, c->sample_rate, &ts, cons, &P.segs));
+    if (c->has_shift) {
+        // (a call over several buffers plans the clock over their concatenation; what fails for THAT length only -- a
+        // clock table too long, no room for it -- is not the call's error: the buffers go one by one, as promised)
+        const int rp = nco_plan(c->ctx, c->sample_rate, &ts, cons, &P.segs);
+        if (rp != HZSDR_OK) return cb && cb->nbuf > 1 ? kBatchFallback : rp;
+        if (cb && cb->nbuf > 1 && P.segs.big_n != 0) return kBatchFallback;  // (mm2_plan would refuse the long table anyway)
+    }
     int rc;
     switch (c->src_fmt) {
     case HZSDR_FMT_C64: rc = run_fmt<HZSDR_FMT_C64>(c, din, cons, dout, outn, P, cb); break;

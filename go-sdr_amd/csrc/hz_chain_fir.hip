@@ -296,30 +296,49 @@ static int mm_launch(hzsdr_chain *c, const void *in, void *out, size_t n, const 
                           (uint8_t *)c->rhist[c->hist_next()], (const float2 *)c->taps_dev, n, c->mmg, P, R, F);
 }
 
-// hz_firmm2.h: the plan of one call for the persistent-pass kernel.  Every clock run with a table gets the
+// What a chain carries from call to call about the RAW history (the last `off` bytes pairs of the previous call): is it
+// valid, how many of its last samples lie in the clock run that call ended in, and that call's last clock value.
+struct RawCarry {
+    bool valid;
+    uint64_t len;
+    double ts;
+};
+// ... after a call of n samples on the matrix path whose clock runs were (first, nr) and whose run 0 continued the
+// carried run (`cont`)
+static void carry_after(const hzsdr_chain *c, RawCarry *k, size_t n, const uint64_t *first, int nr, bool cont, double ts_after) {
+    const bool was = k->valid;
+    k->valid = n >= c->off || was;
+    if (c->has_shift) {
+        const int last = nr - 1;
+        const uint64_t len = n - first[last];
+        k->len = (last == 0 && was && cont) ? k->len + len : len;  // (the samples of the stream's current run so far: it may have begun calls ago)
+    }
+    k->ts = ts_after;
+}
+
+// hz_firmm2.h: the plan of ONE call of n samples whose clock runs are (first, t0, step)[nr] for the persistent-pass
+// kernel.  Every clock run with a table gets the
 // outputs whose whole window lies in it (tile-aligned) and the passes of the call's 512-output grid that hold
 // them -- a pass that straddles a boundary is multiplied once per run, each time with that run's table and
 // valid range (a second short pass costs one wave 6 us; the fix-up tasks it replaces cost ~10 us EACH).  What
 // no run holds -- windows that cross a boundary, the stream's start, runs without a table -- are fix-up tasks
-// of 8 outputs.  false: the call stays on the transform kernels.
-static bool mm2_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in, const void *out, mm2::Plan *L,
-                     mm2::Fix *F, const CallBatch *cb = nullptr) {
-    memset(L, 0, sizeof *L);
-    memset(F, 0, sizeof *F);
-    if (!c->mm_ok || c->mix_in_order || P.segs.big_n != 0 || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) return false;
-    if (cb && cb->nbuf > 1) {  // (a call over several buffers: every one aligned, whole passes per buffer, the history in the last)
-        if (!mm2::batch_ok(cb->n_each, c->factor, cb->nbuf) || cb->n_each < c->mmg.off) return false;
-        for (size_t j = 0; j < cb->nbuf; j++)
-            if ((((uintptr_t)cb->ins[j] | (uintptr_t)cb->outs[j]) & 15) != 0) return false;
-    }
-    for (int i = 0; i < P.n; i++)
-        if (P.op[i].kind == EW_SHIFT && !(fabs(P.op[i].tau_shift) * 6.2832 < 1073741824.0)) return false;
-    const int nr = c->has_shift ? P.segs.n : 1;
+// of 16 outputs.  false: the call stays on the transform kernels.
+static bool mm2_plan_piece(hzsdr_chain *c, const EwProgram &P, const RawCarry &k, size_t n, const uint64_t *first, const double *t0,
+                           const double *step, int nr, mm2::Plan *L, mm2::Fix *F, uint64_t *fix_total) {
     if (nr < 1 || nr > kNcoMaxSegs) return false;
     // the planner itself is host-only code (hz_firmm2_plan.h: sanitizer-built and fuzzed in tests/host/)
     mm2::PlanIn pin{};
     pin.n_in = n, pin.D = c->factor, pin.ntaps = (int)c->ntaps, pin.has_shift = c->has_shift;
-    pin.cont = c->rh_valid && (!c->has_shift || (P.segs.step[0] == c->rh_step && c->rh_len >= c->ntaps && c->rh_next == P.segs.t0[0]));
+    // Does run 0 continue the run the previous call ended in?  The previous call's last sample had the clock k.ts
+    // (committed by the caller when that call returned), this call's first sample has t0[0]: two consecutive points of
+    // one line (hz_firmm2_plan.h: run_line) are in one binade and exactly one step apart.  (Not "equal steps and the
+    // clock the last run predicted": a call that ends ONE sample into a run has no step to compare.)  The raw history
+    // then holds min(len, off) samples of the run in front of the call.
+    pin.back = 0;
+    if (k.valid) {
+        if (!c->has_shift) pin.back = c->off;
+        else if (mm2::continues(k.ts, t0[0], step[0])) pin.back = k.len < c->off ? k.len : c->off;
+    }
     pin.n_ops = P.n;
     pin.max_grid = c->ctx->num_cus;
     pin.shift_op = -1;
@@ -332,16 +351,59 @@ static bool mm2_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *i
     if (n_shift != 1) pin.shift_op = -1;
     else pin.tau = P.op[pin.shift_op].tau_shift;
     const void *tabs[kNcoMaxSegs];
-    const uint64_t zero_first = 0;
-    const double zero = 0.0;
     for (int r = 0; r < nr; r++) {
         void *dev = nullptr;
-        (void)mm_table_for(c, c->has_shift ? P.segs.step[r] : 0.0, 0.0, &dev, false);
+        (void)mm_table_for(c, c->has_shift ? step[r] : 0.0, 0.0, &dev, false);
         tabs[r] = dev;
     }
-    mm2::ClockRuns cr{nr, c->has_shift ? P.segs.first : &zero_first, c->has_shift ? P.segs.t0 : &zero, c->has_shift ? P.segs.step : &zero, tabs};
+    mm2::ClockRuns cr{nr, first, t0, step, tabs};
+    return mm2::plan_call(pin, cr, L, F, fix_total);
+}
+
+static bool mm2_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *in, const void *out, mm2::Plan *L,
+                     mm2::Fix *F, const CallBatch *cb = nullptr) {
+    memset(L, 0, sizeof *L);
+    memset(F, 0, sizeof *F);
+    if (!c->mm_ok || c->mix_in_order || P.segs.big_n != 0 || (((uintptr_t)in | (uintptr_t)out) & 15) != 0) return false;
+    for (int i = 0; i < P.n; i++)
+        if (P.op[i].kind == EW_SHIFT && !(fabs(P.op[i].tau_shift) * 6.2832 < 1073741824.0)) return false;
+    const uint64_t zero_first = 0;
+    const double zero = 0.0;
+    const RawCarry k0{c->rh_valid, c->rh_len, c->ts};
+    if (cb && cb->nbuf > 1) {  // (a call over several buffers: every one aligned, whole passes per buffer, the history in the last)
+        if (!mm2::batch_ok(cb->n_each, c->factor, cb->nbuf) || cb->n_each < c->mmg.off) return false;
+        for (size_t j = 0; j < cb->nbuf; j++)
+            if ((((uintptr_t)cb->ins[j] | (uintptr_t)cb->outs[j]) & 15) != 0) return false;
+        // hzsdr_chain_run_batch promises the results of n_buffers hzsdr_chain_run calls, bit for bit.  What the
+        // matrix path computes for an output does not depend on how the stream is cut (hz_firmm2_plan.h: run_line) --
+        // but WHETHER a call takes the matrix path does (a short call that is mostly clock boundaries keeps the
+        // transform kernels, other arithmetic inside the same error bound).  So the one-launch form is taken only when
+        // every buffer by itself would have taken the matrix path: the single calls are planned here, on the host
+        // (clock runs and planner, a few microseconds per buffer, no device work), and thrown away.
+        RawCarry k = k0;
+        for (size_t j = 0; j < cb->nbuf; j++) {
+            uint64_t first[kNcoMaxSegs];
+            double t0[kNcoMaxSegs], step[kNcoMaxSegs], ts_end = k.ts;
+            int nr = 1;
+            if (c->has_shift) {
+                hzsdr_nco_segment sg[kNcoMaxSegs];
+                size_t need = 0;
+                if (hzsdr_nco_segments(c->sample_rate, k.ts, cb->n_each, sg, kNcoMaxSegs, &need, &ts_end) != HZSDR_OK || need > (size_t)kNcoMaxSegs) return false;
+                nr = (int)need;
+                for (int r = 0; r < nr; r++) first[r] = sg[r].first, t0[r] = sg[r].t0, step[r] = sg[r].step;
+            } else {
+                first[0] = 0, t0[0] = 0.0, step[0] = 0.0;
+            }
+            mm2::Plan Lj;
+            mm2::Fix Fj;
+            if (!mm2_plan_piece(c, P, k, cb->n_each, first, t0, step, nr, &Lj, &Fj, nullptr)) return false;
+            carry_after(c, &k, cb->n_each, first, nr, Lj.cont != 0, ts_end);
+        }
+    }
+    const int nr = c->has_shift ? P.segs.n : 1;
     uint64_t fix_total = 0;
-    const bool ok = mm2::plan_call(pin, cr, L, F, &fix_total);
+    const bool ok = mm2_plan_piece(c, P, k0, n, c->has_shift ? P.segs.first : &zero_first, c->has_shift ? P.segs.t0 : &zero,
+                                   c->has_shift ? P.segs.step : &zero, nr, L, F, &fix_total);
     if (c->debug_mm) {
         fprintf(stderr, "hzsdr mm2: %s: %d of %d runs on the matrix path, cont %d, %d passes, %d fix intervals (%d tasks, %llu outputs)\n",
                 ok ? "matrix path" : "transform kernels", L->n, nr, L->cont, L->n_pass, F->n, F->n_task, (unsigned long long)fix_total);
@@ -623,12 +685,13 @@ int fir_run(hzsdr_chain *c, const void *in, size_t n_cons, void *out, const EwPr
                 c->hist_cur = c->hist_next();
                 c->last_path = HZSDR_FIR_PATH_MATRIX;
                 // the raw history now ends in this call's last clock run
-                const bool was = c->rh_valid;
-                c->rh_valid = n_cons >= c->off || was;
+                RawCarry k{c->rh_valid, c->rh_len, c->ts};
+                const uint64_t zero_first = 0;
+                carry_after(c, &k, n_cons, c->has_shift ? P.segs.first : &zero_first, c->has_shift ? P.segs.n : 1, cont != 0, c->ts);
+                c->rh_valid = k.valid, c->rh_len = k.len;
                 if (c->has_shift) {
                     const int last = P.segs.n - 1;
                     const uint64_t len = n_cons - P.segs.first[last];
-                    c->rh_len = (last == 0 && cont) ? c->rh_len + len : len;
                     c->rh_step = P.segs.step[last];
                     // the clock the run assigns to the NEXT sample: a call that continues the run starts there
                     // (equal steps alone do not say so: with a sample rate whose 1/fs is a power of two every

@@ -19,7 +19,12 @@ constexpr int kHistPer = 64; // samples per history task
 constexpr int kMaxRuns = 16;  // clock runs of a call that take the matrix path (more: the call keeps the transforms)
 constexpr int kMaxClockRuns = 32;  // hz_nco.h: kNcoMaxSegs, the runs of the clock that travel in the kernel arguments
 constexpr int kMaxFix = kMaxClockRuns + 2;
-constexpr uint64_t kShortRun = 2560;  // outputs: a clock run shorter than this is left to the fix-up tasks while they last
+// outputs: a clock run whose WHOLE line (run_line below: the binade's, not the call's piece of it) is shorter than this is
+// left to the fix-up tasks.  (Rounds 3-5: 2560, "while there are workgroups left to take a task each" -- a budget
+// counted over the call, so the same run could go one way in a call over four buffers and the other way in the four
+// single calls.  By the run's own length the choice belongs to the stream: behind a 2 pi wrap the binades double from
+// one sample up, the runs below 1280 outputs add up to ~160 tasks, one per workgroup as before.)
+constexpr uint64_t kShortRun = 1280;
 constexpr int kU = 12;       // 16-byte pieces per lane of a pass image, any window (768 pieces = 12 KB at most)
 
 constexpr bool factor_ok(unsigned D) { return D == 8; }
@@ -124,7 +129,11 @@ inline bool batch_ok(uint64_t n_each, unsigned D, size_t nbuf) {
         return false;
     // pass / ppb as mulhi(pass, floor(2^32 / ppb) + 1): exact for pass < nbuf ppb as long as nbuf ppb^2 < 2^32
     const uint64_t ppb = n_each / D / (uint64_t)pass_out((int)D);
-    return ppb >= 1 && nbuf * ppb * ppb < (1ull << 32);
+    // (ppb = 1: floor(2^32 / 1) + 1 does not fit 32 bits -- the reciprocal came out as 1 and every pass landed in
+    // buffer 0, past its end; such buffers, 512 outputs each, go one by one)
+    // (and a buffer of fewer than 4096 outputs does not take the matrix path by itself -- plan_call -- so a call over
+    // several of them must not either: hzsdr_chain_run_batch promises the bits of single calls)
+    return ppb >= 8 && nbuf * ppb * ppb < (1ull << 32);
 }
 inline Batch make_batch(const void *const *ins, void *const *outs, size_t nbuf, uint64_t n_each, unsigned D) {
     Batch B{};
@@ -140,6 +149,54 @@ inline Batch make_batch(const void *const *ins, void *const *outs, size_t nbuf, 
     return B;
 }
 
+// The LINE a clock run lies on.  Inside one binade [2^e, 2^(e+1)) of the clock every value is a multiple of
+// u = 2^(e-52) and a run advances by step = S u (hz_host.cpp: hzsdr_nco_segments), so the clock values of a run are
+// T u with T = T0 + k S.  Where a CALL first meets the run is the caller's business -- a stream cut into other buffers
+// meets it elsewhere -- but the line is the stream's: its anchor is the line's first point in the binade,
+// T_a = T0 - floor((T0 - 2^52) / S) S, `before` = (T0 - T_a) / S samples in front of t0, and `full` = the samples of
+// the line inside the binade (up to 2 pi in the binade that holds it).  Everything a kernel derives from a run --
+// the mixer's phase, whether the run is worth a table -- is derived from the line, so the results do not depend on
+// how the stream was cut into calls (hzsdr_chain_run_batch == the same buffers through hzsdr_chain_run, bit for
+// bit; the reference's ts recurrence, stream/shifter.go:68-79, does not know about buffers either).
+struct Line {
+    double t_anchor;   // the clock at the anchor (exact)
+    uint64_t before;   // samples between the anchor and t0
+    uint64_t full;     // samples of the line in its binade (1: not a line -- a run of one sample, a clock that stands)
+};
+inline Line run_line(double t0, double step) {
+    Line ln{t0, 0, 1};
+    if (!(step > 0.0) || !isnormal(t0) || !(t0 > 0.0)) return ln;
+    int e2;
+    (void)frexp(t0, &e2);
+    const int e = e2 - 1;  // t0 in [2^e, 2^(e+1))
+    const double u = ldexp(1.0, e - 52);
+    const double Td = t0 / u, Sd = step / u;  // (exact: powers of two)
+    if (!(Sd >= 1.0) || Sd != floor(Sd) || Td != floor(Td) || !(Td < 9007199254740992.0) || !(Sd < 9007199254740992.0)) return ln;
+    const uint64_t T0 = (uint64_t)Td, S = (uint64_t)Sd, Tmin = 1ull << 52;
+    if (T0 < Tmin) return ln;
+    const uint64_t k = (T0 - Tmin) / S, Ta = T0 - k * S;
+    uint64_t Tmax = (1ull << 53) - 1;
+    if (e == 2) {  // (the binade of 2 pi: the clock wraps there)
+        const uint64_t tu = (uint64_t)(6.283185307179586476925286766559 / u);
+        if (tu < Tmax) Tmax = tu;
+    }
+    ln.t_anchor = (double)Ta * u;  // (exact)
+    ln.before = k;
+    ln.full = Tmax >= Ta ? (Tmax - Ta) / S + 1 : 1;
+    return ln;
+}
+
+// (t_prev, t0): the clocks of two consecutive samples of a stream; true when they lie on one line of the clock -- one
+// binade, exactly `step` apart (the difference of two values of one binade is exact).  What a chain asks at a call
+// boundary: does this call's run 0 continue the run the previous call ended in?
+inline bool continues(double t_prev, double t0, double step) {
+    if (!(step > 0.0) || !(t_prev > 0.0) || !(t0 > t_prev)) return false;
+    int ea, eb;
+    (void)frexp(t_prev, &ea);
+    (void)frexp(t0, &eb);
+    return ea == eb && t0 - t_prev == step;
+}
+
 // phase accumulator constants of a run (host): frac(tau step / 2 pi) and frac(tau t0 / 2 pi) - first * the increment,
 // in 2^-64 turns.
 // Extended precision: the increment is multiplied by up to 2^27 samples.
@@ -152,6 +209,17 @@ inline void phase_fix(double tau, double t0, double step, uint64_t first, uint64
     };
     *dphi = fix((long double)tau * (long double)step * inv2pi);
     *phi = fix((long double)tau * (long double)t0 * inv2pi) - first * *dphi;  // (mod 2^64: by the run's line at sample 0)
+}
+// The same constants from the run's LINE (run_line above): the phase at the line's anchor, rounded once, plus whole
+// increments -- the phase of a stream sample is then the same 64-bit number whichever call holds the sample and
+// wherever that call starts.  (phase_fix rounds tau t0 at the CALL's first sample of the run: 2^-37 turns of rounding
+// that differed from cut to cut and moved one pass in thirty across a boundary of sincos_turns32's 2^-32 grid --
+// round 5's "a batch equals single calls within an ulp or two of the factor".)
+inline void phase_line(double tau, double t0, double step, uint64_t first, uint64_t *phi, uint64_t *dphi) {
+    const Line ln = run_line(t0, step);
+    uint64_t pa;
+    phase_fix(tau, ln.t_anchor, step, 0, &pa, dphi);
+    *phi = pa + (ln.before - first) * *dphi;  // (mod 2^64: call sample j of the run is sample before + j - first of the line)
 }
 
 // The mixer's step factors of a clock run (chains with exactly one Shift stage): a lane forms ONE Sincos per pass, for
@@ -203,7 +271,12 @@ struct PlanIn {
     unsigned D;
     int ntaps;
     bool has_shift;
-    bool cont;         // run 0 continues the run the previous call ended in: its windows may reach into the raw history
+    // run 0 continues the run the previous call ended in, and the last `back` samples in front of the call lie in
+    // that run AND in the raw history (at most `off` of them): windows of run 0 may reach that far back.  0: they
+    // may not reach in front of the call at all.  (Rounds 2-5 knew all or nothing -- `cont`, set when the run already
+    // held ntaps samples; a run that starts less than ntaps samples in front of a buffer boundary then gave its first
+    // outputs to the tasks in single calls and to the matrix path in a call over several buffers.)
+    uint64_t back;
     int shift_op;      // the program's only Shift stage (-1: none or several) and its fl(2 pi f)
     double tau;
     int n_ops;
@@ -221,7 +294,7 @@ inline bool plan_call(const PlanIn &in, const ClockRuns &cr, Plan *L, Fix *F, ui
     if (fix_outputs) *fix_outputs = 0;
     if (n_out < 4096 || n_out >= (1ull << 31)) return false;  // (a call this short is launch-bound either way)
     if (cr.n < 1 || cr.n > kMaxClockRuns) return false;
-    L->cont = in.cont ? 1 : 0;
+    L->cont = in.back > 0 ? 1 : 0;
     L->n_ops = in.n_ops;
     L->gain = 1.0f;
     L->shift_op = in.shift_op;
@@ -243,22 +316,25 @@ inline bool plan_call(const PlanIn &in, const ClockRuns &cr, Plan *L, Fix *F, ui
     for (int r = 0; r < cr.n; r++) {
         const uint64_t a = cr.first[r];
         const uint64_t b = r + 1 < cr.n ? cr.first[r + 1] : in.n_in;
-        uint64_t lo = (r == 0 && in.cont) ? 0 : (a + nt - 1 + D - 1) / D, hi = (b + D - 1) / D < n_out ? (b + D - 1) / D : n_out;
+        uint64_t lo = (a + nt - 1 + D - 1) / D, hi = (b + D - 1) / D < n_out ? (b + D - 1) / D : n_out;
+        if (r == 0 && in.back > 0) lo = in.back >= nt - 1 ? 0 : (nt - 1 - in.back + D - 1) / D;  // (a = 0: D m - (nt - 1) >= -back)
         lo = (lo + tile - 1) / tile * tile;
         if (hi < n_out) hi = hi / tile * tile;
-        if (!cr.tab[r] || hi < lo + 64) continue;  // a run without a table, or too short to bother
+        // a run without a table, or nothing of it on the matrix path.  (Rounds 3-5 also left pieces of fewer than 64
+        // outputs to the tasks -- "too short to bother" -- which is a property of the call's cut, not of the run)
+        if (!cr.tab[r] || hi <= lo) continue;
         // A SHORT run -- the binades behind a 2*pi wrap of the clock double from a few samples up -- would put its
         // table and one more multiplication of every pass it shares on ONE workgroup (the call's first: 24 items
         // for its eight waves instead of 16, a whole pass time longer than the rest).  As fix-up tasks its outputs
-        // spread over the workgroups, one task each -- as long as there are workgroups left to take one.
-        if (hi - lo < kShortRun && (uint64_t)F->n_task + (hi - covered + kFixOut - 1) / kFixOut + 8 <= (uint64_t)in.max_grid) continue;
+        // spread over the workgroups, one task each.  Short by the run's LINE, not by the call's piece of it.
+        if (in.has_shift && run_line(cr.t0[r], cr.step[r]).full / D < kShortRun) continue;
         if (L->n >= kMaxRuns) return false;
         Run &u = L->run[L->n];
         u.tab = cr.tab[r], u.m_lo = (uint32_t)lo, u.m_hi = (uint32_t)hi;
         u.pass_first = (int)(lo / pass), u.pass_end = (int)((hi + pass - 1) / pass);
         u.seg = r;
         u.first = a;
-        if (in.shift_op >= 0) phase_fix(in.tau, cr.t0[r], cr.step[r], u.first, &u.phi, &u.dphi);
+        if (in.shift_op >= 0) phase_line(in.tau, cr.t0[r], cr.step[r], u.first, &u.phi, &u.dphi);
         L->pass_first[L->n] = u.pass_first, L->pass_end[L->n] = u.pass_end;
         add_fix(covered, lo);
         L->n++;

@@ -230,7 +230,8 @@ int main(int argc, char **argv) {
         }
         mm2::ClockRuns cr{(int)need, first.data(), t0.data(), step.data(), tab.data()};
         mm2::PlanIn in{};
-        in.n_in = n / D * D, in.D = D, in.ntaps = ntaps, in.has_shift = true, in.cont = rnd() % 2 == 0;
+        in.n_in = n / D * D, in.D = D, in.ntaps = ntaps, in.has_shift = true;
+        in.back = rnd() % 3 == 0 ? 0 : (rnd() % 2 ? (uint64_t)ntaps + rnd() % 64 : 1 + rnd() % (uint64_t)ntaps);  // none, all, part of a window
         in.shift_op = rnd() % 4 ? 0 : -1, in.tau = tau * 2.5e6 * (urand() - 0.5), in.n_ops = 1, in.max_grid = 1 + (int)(rnd() % 256);
         mm2::Plan L;
         mm2::Fix F;
@@ -260,8 +261,9 @@ int main(int argc, char **argv) {
             // every valid output's window lies in the run (run 0 of a continuing call: or in the raw history)
             const uint64_t run_end = (size_t)u.seg + 1 < need ? first[u.seg + 1] : in.n_in;
             const int64_t w_lo = (int64_t)D * u.m_lo - (ntaps - 1);
-            REQUIRE(w_lo >= (int64_t)u.first || (u.seg == 0 && in.cont));
+            REQUIRE(w_lo >= (int64_t)u.first || (u.seg == 0 && w_lo >= -(int64_t)in.back));
             REQUIRE((uint64_t)D * (u.m_hi - 1) < run_end);
+            REQUIRE(mm2::run_line(t0[u.seg], step[u.seg]).full / D >= mm2::kShortRun);  // (short lines go to the tasks)
             for (uint64_t m = u.m_lo; m < u.m_hi; m++) cover[m]++;
             prev_hi = u.m_hi;
         }
@@ -303,7 +305,7 @@ int main(int argc, char **argv) {
         for (size_t k = 0; k < need; k++) first[k] = segs[k].first, t0[k] = segs[k].t0, step[k] = segs[k].step, tab[k] = segs[k].count >= 8 * 1024 ? &dummy2 : nullptr;
         mm2::ClockRuns cr{(int)need, first.data(), t0.data(), step.data(), tab.data()};
         mm2::PlanIn in{};
-        in.n_in = n, in.D = 8, in.ntaps = 1024, in.has_shift = true, in.cont = true, in.shift_op = 0, in.tau = -tau * 2.5e6, in.n_ops = 1, in.max_grid = 256;
+        in.n_in = n, in.D = 8, in.ntaps = 1024, in.has_shift = true, in.back = 1024, in.shift_op = 0, in.tau = -tau * 2.5e6, in.n_ops = 1, in.max_grid = 256;
         mm2::Plan L;
         mm2::Fix F;
         REQUIRE(mm2::plan_call(in, cr, &L, &F, nullptr));
@@ -311,11 +313,115 @@ int main(int argc, char **argv) {
         int with_table = 0;
         for (size_t k = 0; k < need; k++) with_table += tab[k] != nullptr;
         REQUIRE(L.n < with_table);  // some runs with a table went to the tasks ...
-        int short_planned = 0;  // (a short run stays on the matrix path only once the workgroups are used up)
-        for (int r = 0; r < L.n; r++) short_planned += L.run[r].m_hi - L.run[r].m_lo < mm2::kShortRun;
-        REQUIRE(short_planned <= 1);
+        int short_planned = 0;  // (no run whose line is short stays on the matrix path)
+        for (int r = 0; r < L.n; r++) short_planned += mm2::run_line(t0[L.run[r].seg], step[L.run[r].seg]).full / 8 < mm2::kShortRun;
+        REQUIRE(short_planned == 0);
         printf("plan_fuzz wrap call: %zu clock runs, %d with a table, %d on the matrix path (%d of them short), %d fix-up tasks\n", need, with_table, L.n, short_planned, F.n_task);
     }
+    // ---- a stream cut two ways: ONE call over k buffers against k single calls (hzsdr_chain_run_batch against
+    // hzsdr_chain_run).  What the kernel derives from the plan must be the same for every output: matrix path or task,
+    // the run's table (its step), and the mixer's 64-bit phase at the output -- then the two forms agree bit for bit.
+    // The chain's state between calls (hz_chain_fir.hip: fir_run / mm2_plan) is restated here: the clock, and how many
+    // samples of the current run the raw history holds.
+    long cut_cases = 0, cut_outputs = 0;
+    for (g_case = 0; g_case < cases / 4; g_case++) {
+        const uint64_t fs = rates[rnd() % (sizeof rates / sizeof rates[0])];
+        const unsigned D = 8;
+        const int ntaps = 16 + (int)(rnd() % 1140);
+        const unsigned off = (unsigned)((ntaps - 1 + D - 1) / D * D);
+        const size_t nbuf = 2 + rnd() % 7;
+        const uint64_t ppb = 8 + rnd() % 120, n_each = ppb * 512 * D;
+        double ts0;
+        switch (rnd() % 4) {
+        case 0: ts0 = tau - (double)(rnd() % (n_each * nbuf)) / (double)fs; break;  // the wrap somewhere in the stream
+        case 1: ts0 = ldexp(1.0, -(int)(rnd() % 6)) - (double)(rnd() % (n_each * nbuf)) / (double)fs; if (ts0 < 0) ts0 = 0.3; break;  // a binade edge
+        default: ts0 = urand() * tau; break;
+        }
+        const double tsh = tau * 2.5e6 * (urand() - 0.5);
+        struct OutInfo { uint8_t kind; double step; uint64_t phase; };
+        auto plan_piece = [&](double ts_in, uint64_t n, uint64_t back, std::vector<OutInfo> &info, double *ts_out, uint64_t *last_len, bool *last_is_run0, bool *ok) {
+            std::vector<hzsdr_nco_segment> segs(4096);
+            size_t need = 0;
+            REQUIRE(hzsdr_nco_segments(fs, ts_in, n, segs.data(), segs.size(), &need, ts_out) == HZSDR_OK);
+            *ok = false;
+            if (need > (size_t)mm2::kMaxClockRuns) return;
+            std::vector<uint64_t> first(need);
+            std::vector<double> t0(need), step(need);
+            std::vector<const void *> tab(need);
+            static const char dummy3 = 0;
+            for (size_t k = 0; k < need; k++) {
+                first[k] = segs[k].first, t0[k] = segs[k].t0, step[k] = segs[k].step;
+                // (prepare_mm_tables: a table per STEP whose line is long -- a property of the stream, not of the call)
+                tab[k] = mm2::run_line(t0[k], step[k]).full >= 8ull * (uint64_t)ntaps ? &dummy3 : nullptr;
+            }
+            mm2::ClockRuns cr{(int)need, first.data(), t0.data(), step.data(), tab.data()};
+            mm2::PlanIn in{};
+            in.n_in = n, in.D = D, in.ntaps = ntaps, in.has_shift = true, in.shift_op = 0, in.tau = tsh, in.n_ops = 1, in.max_grid = 256;
+            in.back = (back && mm2::continues(ts_in, t0[0], step[0])) ? (back < off ? back : off) : 0;
+            mm2::Plan L;
+            mm2::Fix F;
+            if (!mm2::plan_call(in, cr, &L, &F, nullptr)) return;
+            *ok = true;
+            info.assign(n / D, OutInfo{0, 0.0, 0});
+            for (int r = 0; r < L.n; r++)
+                for (uint64_t m = L.run[r].m_lo; m < L.run[r].m_hi; m++)
+                    info[m] = OutInfo{1, step[L.run[r].seg], L.run[r].phi + (uint64_t)D * m * L.run[r].dphi};
+            const size_t last = need - 1;
+            *last_len = n - first[last];
+            *last_is_run0 = last == 0 && in.back > 0;
+        };
+        // the batch: one call (the chain's state in front of it: nothing -- a fresh stream or a set_time)
+        std::vector<OutInfo> big;
+        double ts_big;
+        uint64_t ll;
+        bool l0, ok_big;
+        if (!mm2::batch_ok(n_each, D, nbuf)) continue;
+        plan_piece(ts0, n_each * nbuf, 0, big, &ts_big, &ll, &l0, &ok_big);
+        if (!ok_big) continue;
+        // the single calls
+        double ts = ts0;
+        uint64_t rh_len = 0;
+        bool all_ok = true;
+        std::vector<OutInfo> cat;
+        for (size_t j = 0; j < nbuf && all_ok; j++) {
+            std::vector<OutInfo> piece;
+            double ts_next;
+            bool okp;
+            plan_piece(ts, n_each, j == 0 ? 0 : rh_len, piece, &ts_next, &ll, &l0, &okp);
+            if (!okp) {
+                all_ok = false;  // (a single call that keeps the transform kernels: other arithmetic, nothing to compare)
+                break;
+            }
+            rh_len = l0 ? rh_len + ll : ll;
+            ts = ts_next;
+            cat.insert(cat.end(), piece.begin(), piece.end());
+        }
+        if (!all_ok) continue;
+        REQUIRE(ts == ts_big && cat.size() == big.size());
+        for (size_t m = 0; m < big.size(); m++) {
+            REQUIRE(big[m].kind == cat[m].kind);
+            if (big[m].kind) REQUIRE(big[m].step == cat[m].step && big[m].phase == cat[m].phase);
+        }
+        cut_cases++, cut_outputs += (long)big.size();
+    }
+    REQUIRE(cut_cases > cases / 16);
+    // ---- a pass's buffer by the host's reciprocal (hz_firmm2.h: buf_of): exact wherever batch_ok says yes
+    for (g_case = 0; g_case < 2000; g_case++) {
+        const size_t nbuf = 1 + rnd() % 8;
+        const uint64_t ppb = g_case < 64 ? 1 + (uint64_t)g_case : 1 + rnd() % 40000, n_each = ppb * 512 * 8;
+        if (!mm2::batch_ok(n_each, 8, nbuf)) {
+            REQUIRE(ppb < 8 || nbuf * ppb * ppb >= (1ull << 32) || n_each * nbuf / 8 >= (1ull << 31));
+            continue;
+        }
+        std::vector<const void *> ins(nbuf, (const void *)(uintptr_t)0x10000000);
+        std::vector<void *> outs(nbuf, (void *)(uintptr_t)0x20000000);
+        const mm2::Batch B = mm2::make_batch(ins.data(), outs.data(), nbuf, n_each, 8);
+        REQUIRE(B.ppb == ppb);
+        const uint64_t np = nbuf * ppb, stride = np > 200000 ? 7 : 1;
+        for (uint64_t p = 0; p < np; p += stride) REQUIRE((((uint64_t)(uint32_t)p * B.rcp) >> 32) == p / ppb);
+        for (uint64_t j = 1; j <= nbuf; j++) REQUIRE((((j * ppb - 1) * B.rcp) >> 32) == j - 1);  // (every buffer's last pass)
+    }
+    printf("plan_fuzz cuts: %ld streams planned as one call and as single calls agree output for output (%ld outputs)\n", cut_cases, cut_outputs);
     printf("plan_fuzz ok: %d cases, %ld planned, %ld kept the transforms; %ld chunk plans, %ld digit tables (%ld refused the int32 plane sum)\n", cases, planned, fell_back, chunks_planned, tables, combine_refused);
     return 0;
 }

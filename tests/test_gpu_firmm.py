@@ -18,7 +18,7 @@ import os
 import numpy as np
 import pytest
 
-from util import assert_fir_close, fir_errors, rand_i8, rand_u8, zeros
+from util import assert_fir_close, bits_equal, fir_errors, rand_i8, rand_u8, zeros
 
 pytestmark = pytest.mark.gpu
 
@@ -570,9 +570,10 @@ def test_pipelined_chain_keeps_the_context_streams_order(hz):
 def test_run_batch_one_launch_equals_the_stream(hz, piped):
     """hzsdr_chain_run_batch: k buffers of the stream in ONE launch of the persistent-pass kernel (separate
     allocations, the first pass of every buffer reaching back into the one before) -- against the oracle over the
-    whole stream, within a float32 ulp or two of the same stream through single calls, batches of 4, 3, 1, 8 in a
-    row across the clock's 2 pi wrap; a batch of buffers too short for whole passes runs one by one and equals
-    single calls bit for bit."""
+    whole stream, and BIT FOR BIT the same stream through single calls (round 6: the mixer's phase and the choice
+    between matrix path and fix-up task belong to the clock run's line, csrc/hz_firmm2_plan.h run_line, not to the
+    call), batches of 4, 3, 1, 8 in a row across the clock's 2 pi wrap; a batch of buffers too short for whole passes
+    runs one by one and equals single calls bit for bit as well."""
     import torch
     import oracle as orc
     n, fs, D = 1 << 18, 20_000_000, 8
@@ -608,15 +609,14 @@ def test_run_batch_one_launch_equals_the_stream(hz, piped):
     want, xmax = oracle(orc, x, fs, [("shift", -fs / 8)], taps, D, ts0=ts0)
     assert_fir_close(got, want, taps, xmax, "batched stream")
     assert_fir_close(ref, want, taps, xmax, "single calls")
-    scale = float(np.abs(ref).max())
-    assert float(np.abs(got - ref).max()) <= 4e-7 * scale  # (the mixer's phase carried through a batch: last-bit differences)
+    assert bits_equal(got, ref), "a call over several buffers differs from single calls in %d outputs" % int((got.view(np.int64) != ref.view(np.int64)).sum())
     # the stream goes on in single calls from the batched chain's state: the history a batch leaves is the last buffer's
     tail_in = torch.from_numpy(rand_u8(78, n)).cuda()
     ya, yb = (torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(2))
     torch.cuda.synchronize()
     assert single.run(tail_in, ya) == (n, n // D) and ch.run(tail_in, yb) == (n, n // D)
     ctx.synchronize()
-    assert float((ya - yb).abs().max()) <= 4e-7 * scale
+    assert torch.equal(torch.view_as_real(ya).view(torch.int32), torch.view_as_real(yb).view(torch.int32))
     # buffers that do not hold whole passes (n / D not a multiple of 512): one by one, the same bits as single calls
     m = n - 8 * 24
     ch.set_time(1.0), single.set_time(1.0)
@@ -630,6 +630,42 @@ def test_run_batch_one_launch_equals_the_stream(hz, piped):
     for q in range(3):
         assert torch.equal(torch.view_as_real(za[q]).view(torch.int32), torch.view_as_real(zb[q]).view(torch.int32)), q
     ch.close(), single.close(), ctx.close()
+
+
+@pytest.mark.parametrize("nbuf,n", [(8, 4096), (2, 8192), (8, 8192), (3, 3 * 4096), (8, 1 << 15)])
+def test_run_batch_of_very_short_buffers(hz, nbuf, n):
+    """Buffers of ONE 512-output pass each (4096 samples at D = 8): the reciprocal the kernel finds a pass's buffer
+    with does not exist for one pass per buffer (2^32 / 1 + 1 overflows: round 5 sent every pass to buffer 0 and wrote
+    past its end -- ADVICE r05), so such a batch goes one by one; from two passes per buffer on it is one launch.
+    Either way: the outputs equal single calls bit for bit, the guard zones behind every output stay untouched."""
+    import torch
+    fs, D = 20_000_000, 8
+    taps = taps_for(1024, 1 / 16, 0.0)
+    ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.current_stream().cuda_stream)
+    xs = [torch.from_numpy(rand_u8(300 + j, n)).cuda() for j in range(nbuf)]
+    guard = 4096
+    outs = {}
+    for form in ("batch", "single"):
+        ch = _north_chain(hz, ctx, taps)
+        ch.set_time(1.0)
+        # (a first call of 2^16 samples: the batch then continues a clock run and a history)
+        warm = torch.from_numpy(rand_u8(299, 1 << 16)).cuda()
+        ch.run(warm, torch.zeros((1 << 16) // D, dtype=torch.complex64, device="cuda"))
+        ys = [torch.full((n // D + guard,), 7.0 + 7.0j, dtype=torch.complex64, device="cuda") for _ in range(nbuf)]
+        if form == "batch":
+            assert ch.run_batch(xs, [y[:n // D] for y in ys]) == (n, n // D)
+        else:
+            for j in range(nbuf):
+                assert ch.run(xs[j], ys[j][:n // D]) == (n, n // D)
+        ctx.synchronize()
+        outs[form] = ([y.cpu().numpy() for y in ys], ch.time())
+        ch.close()
+    assert outs["batch"][1] == outs["single"][1]
+    for j in range(nbuf):
+        a, b = outs["batch"][0][j], outs["single"][0][j]
+        assert np.all(a[n // D:] == np.complex64(7 + 7j)), ("guard zone of output %d written" % j)
+        assert bits_equal(a, b), j
+    ctx.close()
 
 
 def test_run_batch_other_chains_and_errors(hz):

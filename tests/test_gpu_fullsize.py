@@ -107,6 +107,68 @@ def test_north_star_full_size(hz, dev, orc):
     assert np.linalg.norm(d) <= CROSS_REL_L2 * np.linalg.norm(want.astype(np.complex128))
 
 
+def test_north_star_batched_full_size(hz, dev, orc):
+    """The form bench.py times: hzsdr_chain_run_batch(_after) over SEPARATELY ALLOCATED 2^24-sample buffers -- 16 384
+    passes per launch, every pass's buffer found by a 32-bit reciprocal, virtual base pointers per buffer -- at its
+    full size against the oracle, buffer by buffer: a call over four buffers with the clock's 2 pi wrap inside the
+    third, then a call over eight that continues the stream (history, clock run and raw history carried over); plain
+    (stream-ordered) and overlapped (`after`: the chain's two streams, the history kernel beside the call's kernel).
+    And bit for bit against the same twelve buffers through hzsdr_chain_run one at a time: what a call computes for a
+    sample does not depend on how the stream was cut (csrc/hz_firmm2_plan.h: run_line; stream/shifter.go:68-79 knows
+    no buffers either)."""
+    ctx, torch = dev
+    n, fs, D = 1 << 24, 20_000_000, 8
+    shift, taps = -fs / 8, lowpass(1024, 1.0 / 16)
+    batches = (4, 8)
+    total = sum(batches)
+    # 0.84 s of signal per buffer: the clock starts 2.2 s in front of the wrap -> the wrap falls 0.52 s into buffer 2
+    ts0 = TAU - 2.2
+    threads = orc.max_threads()
+    x = rand_u8(19, total * n)
+    xc = zeros("c64", total * n)
+    orc.par_u8_to_c64(x, xc, threads)
+    ts_end = orc.par_shift_gain(ts0, fs, shift, 1.0, xc, threads)  # (gain 1: the reference's Shift alone, on every core)
+    want = zeros("c64", total * n // D)
+    orc.par_fir_decimate_f64(want, xc, taps, D)
+    xmax = float(np.abs(xc[:n]).max())
+    del xc
+    xs = [torch.from_numpy(x[j * n:(j + 1) * n]).cuda() for j in range(total)]  # (twelve allocations)
+    del x
+    no = n // D
+
+    def run(form):
+        ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D)
+        if form == "after":
+            ch.pipeline(True)
+        ch.set_time(ts0)
+        ys = [torch.zeros(no, dtype=torch.complex64, device="cuda") for _ in range(total)]
+        torch.cuda.synchronize()
+        if form == "single":
+            for j in range(total):
+                assert ch.run(xs[j], ys[j]) == (n, no)
+        else:
+            j = 0
+            for k in batches:
+                assert ch.run_batch(xs[j:j + k], ys[j:j + k], after=form == "after") == (n, no)
+                assert ch.last_fir_kernel() == hz.FIR_KERNEL_MATRIX_PASSES
+                j += k
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        assert ch.time() == ts_end  # the clock planner over 4 x 2^24 and 8 x 2^24 samples lands on the serial recurrence's value
+        ch.close()
+        return [y.cpu().numpy() for y in ys]
+
+    single = run("single")
+    for j in range(total):
+        assert_fir_close(single[j], want[j * no:(j + 1) * no], taps, xmax, ("single calls, buffer %d" % j))
+    for form in ("plain", "after"):
+        got = run(form)
+        for j in range(total):
+            assert_fir_close(got[j], want[j * no:(j + 1) * no], taps, xmax, (form, "buffer %d" % j))
+            differing = int((got[j].view(np.int64) != single[j].view(np.int64)).sum())
+            assert differing == 0, (form, "buffer %d: %d outputs differ from the single calls'" % (j, differing))
+
+
 @pytest.mark.parametrize("with_shift", [False, True])
 def test_config3_fir_1024_c64_no_decimation(hz, dev, orc, with_shift):
     """fir_decimate_kernel16<4096, c64, FOLD 0, late>: 1024 taps, D = 1."""
