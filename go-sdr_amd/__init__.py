@@ -773,8 +773,13 @@ class Ring:
     def submit(self, slot, n=None):
         self.ctx._ck(lib.hzsdr_ring_submit(self._h, slot, self.slot_length if n is None else n))
 
+    def submit_many(self, first_slot, count, n=None):
+        """`count` acquired slots (first_slot the oldest) in ONE call of the chain (hzsdr_ring_submit_many): one launch
+        where the chain has that form (hzsdr_chain_run_batch's), the bits of `count` submits either way."""
+        self.ctx._ck(lib.hzsdr_ring_submit_many(self._h, first_slot, count, self.slot_length if n is None else n))
+
     def release(self, slot):
-        """The acquired slot, unused (hzsdr_ring_release)."""
+        """The NEWEST acquired slot, unused (hzsdr_ring_release)."""
         self.ctx._ck(lib.hzsdr_ring_release(self._h, slot))
 
     def pop(self):

@@ -171,6 +171,7 @@ SIGNATURES = {
     "hzsdr_ring_iq_buffer": (i32, [vp, pvp, psz, psz]),
     "hzsdr_ring_acquire": (i32, [vp, C.POINTER(i32), pvp]),
     "hzsdr_ring_submit": (i32, [vp, i32, sz]),
+    "hzsdr_ring_submit_many": (i32, [vp, i32, i32, sz]),
     "hzsdr_ring_release": (i32, [vp, i32]),
     "hzsdr_ring_pop": (i32, [vp, pvp, psz]),
     "hzsdr_ring_in_flight": (i32, [vp]),

@@ -221,19 +221,25 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     // ends: a global store does not issue while the SIMD partner's MFMAs are back to back (tools/epi_cost.hip), so a
     // stamp stored at once pinned the very phases it was to time to the partner's loop (rounds 3-4 read "the epilogue
     // takes as long as the partner's loop" off such stamps).
+    // (1 << 24, with 64: a row of stamps for EVERY pass of the wave, up to fifteen -- a call over four buffers gives a wave
+    // eight; 8 KB of staging behind the kernel's own LDS, which the harness asks for -- tools/mfma_fir2.hip PASSES=1)
+    constexpr int kStampRows = (EXP & (1 << 24)) != 0 ? 16 : 4;
     int stamp_pass = 0;
     [[maybe_unused]] unsigned long long *const lstamp =
-        reinterpret_cast<unsigned long long *>(mm_lds + lds_bytes(D, G.ks, G.ne, G.ntaps)) + (size_t)wave * 32;
+        reinterpret_cast<unsigned long long *>(mm_lds + lds_bytes(D, G.ks, G.ne, G.ntaps)) + (size_t)wave * (8 * kStampRows);
     if constexpr ((EXP & 64) != 0) {
-        if (l < 32) lstamp[l] = 0;
+        for (int i = l; i < 8 * kStampRows; i += 64) lstamp[i] = 0;
     }
     auto stamp = [&](int k) {
         if constexpr ((EXP & 64) != 0) {
-            if (l == 0 && stamp_pass < 4)
+            if (l == 0 && stamp_pass < kStampRows)
                 lstamp[(k == 0 || k == 7 || (k >= 8 && k < 16) ? 0 : stamp_pass) * 8 + (k & 7)] = __builtin_amdgcn_s_memrealtime();
         }
     };
     stamp(0);
+    // (with the stamps: the shader clock the workgroup ran at -- s_memtime counts shader cycles, s_memrealtime 100 MHz)
+    [[maybe_unused]] unsigned long long clk0 = 0, rt0 = 0;
+    if constexpr ((EXP & 64) != 0) clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     if constexpr ((EXP & 32) != 0) __builtin_amdgcn_s_setprio(1);
     const Run run0 = L.run[0];  // (read with the header: most workgroups of most calls are in run 0)
     // Everything the way to the first loads reads from the kernel arguments, wanted HERE: the compiler then issues
@@ -450,11 +456,26 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     auto land = [&](v4i(&x)[KU], bool flipped = false) {
         // piece l + 64 u is piece l % PPT of tile l / PPT + (64 / PPT) u: one address and constants
         uint8_t *lp = slot + TS * (l / PPT) + 16 * (l % PPT);
+        // (1 << 25: the rare un-flipped landing -- a wave's first pass, a pass behind an inactive one -- as a BRANCH.  The
+        // condition is uniform, and the compiler turned `if (!flipped) x ^= c` into 40 v_xor + 40 v_cndmask executed
+        // by EVERY landing: 80 of a pass's ~490 vector instructions, each of which costs the SIMD partner's matrix loop
+        // ~2.5 cycles -- found in the ISA in round 6.  The empty asm keeps the block from being if-converted again.)
+        if constexpr (FMT == HZSDR_FMT_U8 && STRAIGHT && (EXP & 262144) != 0 && (EXP & (1 << 25)) != 0 && (EXP & 32768) == 0) {
+            if (!flipped) {
+#pragma unroll
+                for (int u = 0; u < KU; u++) {
+                    x[u] ^= (int)0x80808080;
+                    asm volatile("" : "+v"(x[u]));
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < KU; u++)
             if (kWhole || l + u * 64 < pieces) {
                 if constexpr (FMT == HZSDR_FMT_U8 && (EXP & 32768) == 0) {
-                    if constexpr (STRAIGHT && (EXP & 262144) != 0) {
+                    if constexpr (STRAIGHT && (EXP & 262144) != 0 && (EXP & (1 << 25)) != 0) {
+                        // (flipped above, in one uniform branch)
+                    } else if constexpr (STRAIGHT && (EXP & 262144) != 0) {
                         if (!flipped) x[u] ^= (int)0x80808080;  // (uniform: a wave's first pass, a pass behind an inactive one)
                     } else {
                         x[u] ^= (int)0x80808080;  // b - 128 as int8
@@ -538,6 +559,13 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
 #pragma unroll
                 for (int pt = 0; pt < 2; pt++) {
                     const int q = 4 * aa + 2 * pt;
+                    if constexpr ((EXP & (1 << 27)) != 0) {  // (tools/mfma_fir2.hip CLOCKS: what the float64 instructions cost -- NOT exact, timing only)
+                        const int hi = (int)(((unsigned)acc[0][b][q] << 8) + (unsigned)acc[0][b][q + 1]);
+                        float v = __fmaf_rn((float)acc[1][b][q + 1], (float)k3, (float)(pt ? dci : dcr));
+                        v = __fmaf_rn((float)acc[1][b][q], (float)k2, v);
+                        c2[pt] = __fmaf_rn((float)hi, (float)k1, v);
+                        continue;
+                    }
                     double v = __fma_rn((double)acc[1][b][q + 1], k3, pt ? dci : dcr);
                     v = __fma_rn((double)acc[1][b][q], k2, v);
                     if constexpr ((EXP & 16384) != 0) {
@@ -596,21 +624,8 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                     for (int q = 0; q < 4; q++) y[b][q] = t[4 * b + q];
             }
         };
-#pragma unroll 1
-        for (int oi = 0; oi < ((EXP & 4) ? 0 : L.n_ops); oi++) {  // uniform
-            bool other = L.shift_op != oi;
-            if constexpr ((EXP & 131072) != 0) other = __builtin_expect(other, 0);
-            if (other) {
-                if constexpr ((EXP & 4096) != 0) {
-                    other_stage(oi, seg, P);
-                } else {
-                    HZ_COLD_ARGS;
-                    other_stage(oi, seg, P);
-                }
-                // (a multi-Shift stage's outputs come back through scratch memory: waited for HERE -- left pending they
-                // become a vmcnt(0) at the pass loop's top, behind the next pass's prefetch)
-                if constexpr ((EXP & 131072) != 0) __builtin_amdgcn_s_waitcnt(0x0F70);
-            } else {
+        // (the program's ONE marked Shift stage: the mixer)
+        auto shift_stage = [&]() {
                 // The stage's phase is a 64-bit accumulator in turns (exact increments, no float64).  ONE Sincos per
                 // lane, for its first output; the other seven are that factor turned on by the group's step factors
                 // exp(2 pi i (256 b + a) D dphi) -- double-float constants in LDS, two fma pairs and an add per
@@ -704,7 +719,33 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
                         }
                     }
                 }
+        };
+        auto other_stage_at = [&](int oi) {
+                if constexpr ((EXP & 4096) != 0) {
+                    other_stage(oi, seg, P);
+                } else {
+                    HZ_COLD_ARGS;
+                    other_stage(oi, seg, P);
+                }
+                // (a multi-Shift stage's outputs come back through scratch memory: waited for HERE -- left pending they
+                // become a vmcnt(0) at the pass loop's top, behind the next pass's prefetch)
+                if constexpr ((EXP & 131072) != 0) __builtin_amdgcn_s_waitcnt(0x0F70);
+        };
+        const int n_ops = (EXP & 4) ? 0 : L.n_ops;
+        // (1 << 26: the common program -- ONE stage, the marked Shift -- outside the loop over the stages: rolled, the loop
+        // carries a lane's sixteen outputs from trip to trip through eight v_mov_b64 that every pass executed)
+        if constexpr ((EXP & (1 << 26)) != 0) {
+            if (__builtin_expect(n_ops == 1 && L.shift_op == 0, 1)) {
+                shift_stage();
+                return;
             }
+        }
+#pragma unroll 1
+        for (int oi = 0; oi < n_ops; oi++) {  // uniform
+            bool other = L.shift_op != oi;
+            if constexpr ((EXP & 131072) != 0) other = __builtin_expect(other, 0);
+            if (other) other_stage_at(oi);
+            else shift_stage();
         }
     };
     auto store_block = [&](uint64_t outb, float2(&y)[4], uint32_t mo, uint32_t lo, uint32_t hi) {  // (outb: the pass's buffer, virtual base)
@@ -1119,7 +1160,12 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
     }
     stamp(7);
     if constexpr ((EXP & 64) != 0) {
-        if (l < 32) stamps[((size_t)wb * kWaves + wave) * 32 + l] = lstamp[l];
+        for (int i = l; i < 8 * kStampRows; i += 64) stamps[((size_t)wb * kWaves + wave) * (8 * kStampRows) + i] = lstamp[i];
+        if (tid == 0) {  // (behind every wave's rows: shader cycles and 10 ns ticks of this workgroup's first wave)
+            unsigned long long *ck = stamps + (size_t)L.grid * kWaves * (8 * kStampRows) + 2 * (size_t)wb;
+            ck[0] = __builtin_amdgcn_s_memtime() - clk0;
+            ck[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+        }
     }
 }
 

@@ -22,7 +22,9 @@ static int launch(K kernel, dim3 grid, size_t lds, hipStream_t stream, A... args
 }
 
 // What the library ships of the kernel's switches (hz_firmm2.h, EXP): round 5's instruction cuts.
-constexpr int kLibExp = 8192 | 16384 | 65536 | 131072 | 262144 | (1 << 22);
+// (round 6: 1 << 25, the landing's rare sign flip as a uniform branch -- it was 80 vector instructions of every pass --, and
+// 1 << 26, the one-Shift program outside the loop over the stages)
+constexpr int kLibExp = 8192 | 16384 | 65536 | 131072 | 262144 | (1 << 22) | (1 << 25) | (1 << 26);
 
 template <int FMT>
 static int launch_fmt(hipStream_t stream, int num_cus, unsigned D, const void *in, float2 *out, const float2 *hist,

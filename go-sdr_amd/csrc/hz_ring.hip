@@ -23,7 +23,9 @@ struct hzsdr_ring {
         int state = 0;  // 0 free, 1 acquired, 2 in flight
     };
     std::vector<Slot> slots;
-    size_t widx = 0, ridx = 0;  // next slot to acquire / to pop
+    // next slot to acquire / to submit / to pop: several slots may be acquired ahead of their submission (round 6:
+    // hzsdr_ring_submit_many puts them into ONE call of the chain)
+    size_t aidx = 0, widx = 0, ridx = 0;
     int inflight = 0;
     size_t in_bytes() const { return slot_len * (size_t)hz::format_size(chain->src_fmt); }
     size_t out_bytes() const { return out_len * 8; }
@@ -116,68 +118,118 @@ int hzsdr_ring_iq_buffer(const hzsdr_ring *r, void **base, size_t *n_samples, si
 int hzsdr_ring_acquire(hzsdr_ring *r, int *slot, void **iq) {
     using namespace hz;
     if (!r || !slot) return HZSDR_ERR_INVALID_ARGUMENT;
-    const int i = (int)(r->widx % (size_t)r->nslots);
+    const int i = (int)(r->aidx % (size_t)r->nslots);
     if (r->slots[i].state != 0)
-        return fail(r->ctx, HZSDR_ERR_DST_TOO_SMALL, "ring: every slot is in flight (pop first)");  // the overrun case
+        return fail(r->ctx, HZSDR_ERR_DST_TOO_SMALL, "ring: every slot is acquired or in flight (pop first)");  // the overrun case
     r->slots[i].state = 1;
+    r->aidx++;
     *slot = i;
     if (iq) *iq = r->pin_in + (size_t)i * r->in_bytes();
     return HZSDR_OK;
 }
 
-int hzsdr_ring_submit(hzsdr_ring *r, int slot, size_t n) {
+// `count` acquired slots, oldest first, n samples each: their uploads, ONE call of the chain over all of them where the
+// chain has a one-launch form (chain_launch with a CallBatch: the persistent-pass FIR kernel, hzsdr_chain_run_batch's
+// rules -- otherwise slot by slot, the same results), their downloads.
+static int ring_submit(hzsdr_ring *r, int first, int count, size_t n) {
     using namespace hz;
-    if (!r || slot < 0 || slot >= r->nslots) return HZSDR_ERR_INVALID_ARGUMENT;
     hzsdr_ctx *ctx = r->ctx;
-    auto &s = r->slots[slot];
-    if (s.state != 1 || slot != (int)(r->widx % (size_t)r->nslots))
-        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "ring: submit of a slot that is not the acquired one");
+    if (count < 1 || count > mm2::kMaxBatch || count > r->nslots) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "ring: 1..8 slots per submit");
+    if (first != (int)(r->widx % (size_t)r->nslots))
+        return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "ring: submit of a slot that is not the oldest acquired one");
+    for (int j = 0; j < count; j++)
+        if (r->slots[(size_t)(first + j) % (size_t)r->nslots].state != 1)
+            return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "ring: submit of a slot that is not acquired");
     size_t cons, outn;
     hzsdr_chain_plan(r->chain, n, &cons, &outn);
     if (n == 0 || n > r->slot_len || cons != n)
         return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "ring: a slot must hold a whole number of the chain's blocks");
     HZ_TRY(enter(ctx));
     const size_t fs = (size_t)format_size(r->chain->src_fmt);
-    char *hin = r->pin_in + (size_t)slot * r->in_bytes(), *din = r->dev_in + (size_t)slot * r->in_bytes();
-    char *hout = r->pin_out + (size_t)slot * r->out_bytes(), *dout = r->dev_out + (size_t)slot * r->out_bytes();
-    // (the slot's previous use was popped -- its download, behind every kernel that read or wrote its device copies,
+    const void *dins[mm2::kMaxBatch];
+    void *douts[mm2::kMaxBatch];
+    int idx[mm2::kMaxBatch];
+    for (int j = 0; j < count; j++) {
+        idx[j] = (int)((size_t)(first + j) % (size_t)r->nslots);
+        dins[j] = r->dev_in + (size_t)idx[j] * r->in_bytes();
+        douts[j] = r->dev_out + (size_t)idx[j] * r->out_bytes();
+    }
+    // (a slot's previous use was popped -- its download, behind every kernel that read or wrote its device copies,
     // has completed -- before it could be acquired again: the upload stream needs no further wait)
-    HZ_HIP(ctx, hipMemcpyAsync(din, hin, n * fs, hipMemcpyHostToDevice, r->s_up));
-    HZ_HIP(ctx, hipEventRecord(s.up, r->s_up));
-    double ts;
-    // The ring knows what the call's buffers wait for -- this upload, nothing else: the slot's device copies are its
+    // Uploads: neighbouring full slots are neighbours in the pinned region and on the device -- one copy per stretch.
+    for (int j = 0; j < count;) {
+        int e = j + 1;
+        while (e < count && n == r->slot_len && idx[e] == idx[e - 1] + 1) e++;
+        HZ_HIP(ctx, hipMemcpyAsync((void *)dins[j], r->pin_in + (size_t)idx[j] * r->in_bytes(), (size_t)(e - j - 1) * r->in_bytes() + n * fs,
+                                   hipMemcpyHostToDevice, r->s_up));
+        j = e;
+    }
+    auto &last = r->slots[idx[count - 1]];
+    HZ_HIP(ctx, hipEventRecord(last.up, r->s_up));
+    // The ring knows what the call's buffers wait for -- these uploads, nothing else: the slots' device copies are its
     // own -- so a pipelined chain may overlap the call with the one before (hzsdr_chain_run_after's contract); any
     // other chain's launch waits for the event on the context's stream (pipeline_drain).
-    r->chain->relaxed = r->chain->pipelined;  // (the slot's device copies, whatever the context's memory space)
-    r->chain->ready = s.up;
+    struct Scope {  // (the call's ordering lives in the chain for the launches' duration)
+        hzsdr_chain *c;
+        ~Scope() { c->relaxed = false, c->ready = nullptr; }
+    } scope{r->chain};
+    r->chain->relaxed = r->chain->pipelined;  // (the slots' device copies, whatever the context's memory space)
+    r->chain->ready = last.up;
     if (!r->chain->relaxed) {
         r->chain->ready = nullptr;
-        HZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, s.up, 0));
+        HZ_HIP(ctx, hipStreamWaitEvent(ctx->stream, last.up, 0));
     }
-    const int rc_launch = chain_launch(r->chain, din, n, dout, outn, &ts);
-    r->chain->relaxed = false;
-    r->chain->ready = nullptr;
-    HZ_TRY(rc_launch);
+    double ts;
+    int rc = kBatchFallback;
+    if (count > 1) {
+        const CallBatch cb{dins, douts, (size_t)count, n, outn};
+        rc = chain_launch(r->chain, dins[0], n * (size_t)count, douts[0], outn * (size_t)count, &ts, &cb);
+        if (rc == HZSDR_OK) r->chain->ts = ts;
+    }
+    if (rc == kBatchFallback) {
+        rc = HZSDR_OK;
+        for (int j = 0; j < count && rc == HZSDR_OK; j++) {
+            r->chain->relaxed = r->chain->pipelined;
+            r->chain->ready = r->chain->relaxed ? last.up : nullptr;
+            rc = chain_launch(r->chain, dins[j], n, douts[j], outn, &ts);
+            if (rc == HZSDR_OK) r->chain->ts = ts;
+        }
+    }
+    HZ_TRY(rc);
     HZ_HIP(ctx, hipGetLastError());
-    r->chain->ts = ts;
-    HZ_HIP(ctx, hipEventRecord(s.done, ctx->stream));
-    HZ_HIP(ctx, hipStreamWaitEvent(r->s_down, s.done, 0));
-    HZ_HIP(ctx, hipMemcpyAsync(hout, dout, outn * 8, hipMemcpyDeviceToHost, r->s_down));
-    HZ_HIP(ctx, hipEventRecord(s.down, r->s_down));
-    s.n_out = outn;
-    s.state = 2;
-    r->widx++;
-    r->inflight++;
+    HZ_HIP(ctx, hipEventRecord(last.done, ctx->stream));
+    HZ_HIP(ctx, hipStreamWaitEvent(r->s_down, last.done, 0));
+    for (int j = 0; j < count; j++) {  // (a download and an event per slot: hzsdr_ring_pop hands them out one by one)
+        auto &s = r->slots[idx[j]];
+        HZ_HIP(ctx, hipMemcpyAsync(r->pin_out + (size_t)idx[j] * r->out_bytes(), douts[j], outn * 8, hipMemcpyDeviceToHost, r->s_down));
+        HZ_HIP(ctx, hipEventRecord(s.down, r->s_down));
+        s.n_out = outn;
+        s.state = 2;
+    }
+    r->widx += (size_t)count;
+    r->inflight += count;
     return HZSDR_OK;
+}
+
+int hzsdr_ring_submit(hzsdr_ring *r, int slot, size_t n) {
+    if (!r || slot < 0 || slot >= r->nslots) return HZSDR_ERR_INVALID_ARGUMENT;
+    return ring_submit(r, slot, 1, n);
+}
+
+int hzsdr_ring_submit_many(hzsdr_ring *r, int first_slot, int count, size_t n) {
+    if (!r || first_slot < 0 || first_slot >= r->nslots) return HZSDR_ERR_INVALID_ARGUMENT;
+    return ring_submit(r, first_slot, count, n);
 }
 
 int hzsdr_ring_release(hzsdr_ring *r, int slot) {
     using namespace hz;
     if (!r || slot < 0 || slot >= r->nslots) return HZSDR_ERR_INVALID_ARGUMENT;
     auto &s = r->slots[slot];
-    if (s.state != 1 || slot != (int)(r->widx % (size_t)r->nslots))
-        return fail(r->ctx, HZSDR_ERR_INVALID_ARGUMENT, "ring: release of a slot that is not the acquired one");
+    // (the NEWEST acquired slot: what a source that ran dry hands back)
+    if (s.state != 1 || r->aidx == r->widx || slot != (int)((r->aidx - 1) % (size_t)r->nslots))
+        return fail(r->ctx, HZSDR_ERR_INVALID_ARGUMENT, "ring: release of a slot that is not the last acquired one");
     s.state = 0;
+    r->aidx--;
     return HZSDR_OK;
 }
 

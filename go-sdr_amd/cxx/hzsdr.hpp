@@ -618,6 +618,8 @@ public:
         return Samples{format, p, slot_length_};
     }
     void Submit(int slot, size_t n) { check(x_.raw(), hzsdr_ring_submit(r_, slot, n)); }
+    // `count` acquired slots, first_slot the oldest, n samples each, as ONE call of the chain (hzsdr_ring_submit_many)
+    void SubmitMany(int first_slot, int count, size_t n) { check(x_.raw(), hzsdr_ring_submit_many(r_, first_slot, count, n)); }
     void Release(int slot) { check(x_.raw(), hzsdr_ring_release(r_, slot)); }  // the acquired slot, unused
     // read cursor: the oldest submitted slot's output (complex64), valid until that slot is resubmitted
     Samples Pop() {

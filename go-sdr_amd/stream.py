@@ -36,6 +36,10 @@ class ErrUnexpectedEOF(HzsdrError):    # reader.go:33-36
     pass
 
 
+class ErrNoProgress(HzsdrError):       # io.ErrNoProgress: a Reader that keeps returning (0, nil)
+    pass
+
+
 class EOF(Exception):                  # io.EOF
     pass
 
@@ -298,11 +302,15 @@ class ChainReader(Reader):
     What differs: the source is read up to `readahead` blocks ahead of the consumer (the reference reads one), and a
     Multiply's SetMultiplier takes effect from the next slot, not the next Read."""
 
-    def __init__(self, stream, src, readahead=32, slots=3):
+    def __init__(self, stream, src, readahead=32, slots=3, group=1):
         self.stream, self.ctx, self.src = stream, stream.ctx, src
+        # group: slots handed to the chain per call (hzsdr_ring_submit_many): the Reader fills up to `group` free slots
+        # and submits them together -- ONE launch over all of them where the chain has that form (the FIR-decimate
+        # terminal's persistent-pass kernel: fir_decimate_reader), slot by slot otherwise; the samples are the same
+        self.group = max(1, min(int(group), 8))
         self.src_fmt, self.rate = src.sample_format(), int(src.sample_rate())
         self.stages = []        # ("shift", hz) | ("gain", v) | ("rotate", m)
-        self.terminal = None    # ("decimate", f) | ("downsample", f) | ("convolution", bins, decimate)
+        self.terminal = None    # ("decimate", f) | ("downsample", f) | ("convolution", bins, decimate) | ("fir", taps, f)
         self.block = 1          # the stream is consumed in whole multiples of this many samples (1: any)
         self.readahead, self.nslots = int(readahead), int(slots)
         self.chain = self.ring = None
@@ -337,6 +345,8 @@ class ChainReader(Reader):
         self.terminal, self.block = term, _lcm(self.block, block)
         if term[0] in ("decimate", "downsample"):
             self.rate //= term[1]
+        if term[0] == "fir":
+            self.rate //= term[2]
         return self
 
     def extend_decimate_after_convolution(self, factor):
@@ -386,7 +396,10 @@ class ChainReader(Reader):
         for kind, v in self.stages:
             ch = ch.shift(v) if kind == "shift" else ch.gain(v) if kind == "gain" else ch.rotate(v)
         t = self.terminal
-        if t is not None:
+        if t is not None and t[0] == "fir":
+            ch = ch.fir_decimate(t[1], t[2])
+            ch.pipeline(True)  # (consecutive calls overlap: the ring says what each call's buffers wait for)
+        elif t is not None:
             ch = ch.decimate(t[1]) if t[0] == "decimate" else ch.downsample(t[1]) if t[0] == "downsample" else ch.convolution(t[1], decimate=t[2])
         self.chain = ch
         unit = self.block if self.block > 1 else READER_BLOCK
@@ -396,24 +409,58 @@ class ChainReader(Reader):
         self.slot_len = per
         self.ring = Ring(ch, per, self.nslots)
 
-    def _fill_one(self):
-        """Read the source into the next pinned slot and submit it.  False: nothing more comes."""
+    def _fill(self, want):
+        """Read the source into up to `want` pinned slots and submit them -- the full ones together, ONE call of the chain
+        (hzsdr_ring_submit_many), a short last one (the source ended) by itself.  -> slots submitted (0: nothing more comes).
+        A slot that was acquired is submitted or released whatever the source raises (an OSError from a file or
+        socket source left the slot acquired and every later acquire failed); a source that keeps returning 0 samples
+        without raising ends the stream with ErrNoProgress instead of spinning (io.ErrNoProgress)."""
         if self.err is not None:
-            return False
-        slot, iq = self.ring.acquire()
-        n = 0
-        try:
-            while n < self.slot_len:
-                n += self.src.read(iq[n:])
-        except (EOF, HzsdrError) as e:
-            self.err = e
-        n = n // self.block * self.block  # a block-structured stage: whole blocks only
-        if n == 0:
-            self.ring.release(slot)
-            return False
-        self.ring.submit(slot, n)
-        self.inflight += 1
-        return True
+            return 0
+        first, full, done = None, 0, 0
+        while done < want and self.err is None:
+            slot, iq = self.ring.acquire()
+            n, idle = 0, 0
+            try:
+                while n < self.slot_len:
+                    got = self.src.read(iq[n:])
+                    n += got
+                    idle = idle + 1 if got == 0 else 0
+                    if idle >= 100:
+                        raise ErrNoProgress("multiple Read calls return no data or error")
+            except (EOF, HzsdrError) as e:
+                self.err = e
+            except BaseException as e:  # (OSError of a file / socket source, KeyboardInterrupt, ...: sticky, the slot goes back)
+                self.err = e if isinstance(e, Exception) else HzsdrError("source interrupted: %r" % (e,))
+                self.ring.release(slot)
+                if full:
+                    self.ring.submit_many(first, full, self.slot_len)
+                    self.inflight += full
+                if not isinstance(e, Exception):
+                    raise
+                return done
+            n = n // self.block * self.block  # a block-structured stage: whole blocks only
+            if n == self.slot_len:
+                first = slot if first is None else first
+                full += 1
+                done += 1
+                continue
+            # a short slot: everything full in front of it goes first, then it by itself (or back, if it is empty)
+            if full:
+                self.ring.submit_many(first, full, self.slot_len)
+                self.inflight += full
+                full = 0
+            if n == 0:
+                self.ring.release(slot)
+            else:
+                self.ring.submit(slot, n)
+                self.inflight += 1
+                done += 1
+            return done
+        if full:
+            self.ring.submit_many(first, full, self.slot_len)
+            self.inflight += full
+        return done
 
     def read(self, samples):
         if fmt_of(samples) != self.sample_format():
@@ -423,9 +470,14 @@ class ChainReader(Reader):
         if (self.pending is None or self.off >= len(self.pending)) and self.queue:
             self.pending, self.off = self.queue.pop(0), 0
         if self.pending is None or self.off >= len(self.pending):
-            # keep the ring busy: everything but the slot being consumed is in flight
-            while self.inflight < self.nslots - 1 and self._fill_one():
-                pass
+            # keep the ring busy: everything but the slot being consumed is in flight -- refilled `group` slots at a time
+            # (one call of the chain per group), so a refill waits until that many slots are free, or nothing is in flight
+            while True:
+                free = self.nslots - 1 - self.inflight
+                if free < 1 or (free < self.group and self.inflight > 0):
+                    break
+                if self._fill(min(self.group, free)) == 0:
+                    break
             if self.inflight == 0:
                 raise self.err if self.err is not None else EOF()
             self.pending, self.off = self.ring.pop(), 0
@@ -500,6 +552,27 @@ class Stream:
             return n
         return ReadTransformer(inp, READER_BLOCK, READER_BLOCK, inp.sample_format(),
                                inp.sample_rate() // factor, proc)
+
+    def fir_decimate_reader(self, inp, taps, factor, slots=None, group=None):
+        """The north-star terminal as a Reader: an N-tap FIR at the input rate whose output is kept every `factor`
+        samples (BASELINE.json north_star; the reference has no such Reader -- its Downsample is the boxcar,
+        stream/downsample.go:47-64 -- so the name and the signature follow DecimateReader's, stream/decimate.go:34).
+        Always a fused Reader: ConvertReader / ShiftReader / Gain / Multiply in front of it join its chain (one kernel
+        per slot: for a u8 / i8 source at factor 8 the int8 matrix kernel, csrc/hz_firmm2.h), the slots of its pinned
+        ring go to the chain `group` at a time (one launch each time: hzsdr_ring_submit_many)."""
+        taps = np.ascontiguousarray(taps, np.complex64)
+        cr = inp if isinstance(inp, ChainReader) and inp._open() and inp._c64_here() else None
+        if cr is None:
+            cr = ChainReader(self, inp, self.readahead)
+            if not cr._c64_here():
+                cr.converted = True  # (the terminal converts on its way in, as DownsampleReader does)
+        if slots is not None:
+            cr.nslots = int(slots)
+        cr.group = max(1, min(int(group), 8)) if group is not None else max(1, min(4, cr.nslots - 1))
+        got = cr.extend_terminal(("fir", taps, int(factor)), int(factor))
+        if got is None:
+            raise HzsdrError("fir_decimate_reader: the stage does not fit the Reader in front of it")
+        return got
 
     # stream.DownsampleReader, stream/downsample.go:47-64
     def downsample_reader(self, inp, factor):

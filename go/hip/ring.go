@@ -62,6 +62,13 @@ func (g *Ring) Submit(slot, n int) error {
 	return toErr(g.ch.x.c, C.hzsdr_ring_submit(g.r, C.int(slot), C.size_t(n)))
 }
 
+// SubmitMany hands `count` acquired slots (first the oldest, n samples each) to the chain as ONE call
+// (hzsdr_ring_submit_many): one launch of the FIR-decimate terminal's persistent-pass kernel where the slots qualify
+// (hzsdr_chain_run_batch's rules), slot by slot otherwise -- the same outputs either way, popped one by one.
+func (g *Ring) SubmitMany(first, count, n int) error {
+	return toErr(g.ch.x.c, C.hzsdr_ring_submit_many(g.r, C.int(first), C.int(count), C.size_t(n)))
+}
+
 // Release gives the acquired slot back unused: the source had nothing for it (hzsdr_ring_release).
 func (g *Ring) Release(slot int) error { return toErr(g.ch.x.c, C.hzsdr_ring_release(g.r, C.int(slot))) }
 

@@ -533,12 +533,21 @@ int hzsdr_ring_create(hzsdr_chain *c, size_t slot_length, int slots, hzsdr_ring 
 /* The whole pinned IQ region (slot i starts at i * slot_length samples). */
 int hzsdr_ring_iq_buffer(const hzsdr_ring *r, void **base, size_t *n_samples, size_t *slot_length);
 /* Write cursor: the next slot and its pinned memory.  DST_TOO_SMALL when every
- * slot is still in flight (the overrun case: pop first). */
+ * slot is acquired or still in flight (the overrun case: pop first).  Several slots
+ * may be acquired before any is submitted (in ring order; stream/ring.go:337-392's
+ * writer likewise runs ahead of the reader by whole slots). */
 int hzsdr_ring_acquire(hzsdr_ring *r, int *slot, void **iq);
-/* The acquired slot holds n samples: enqueue its upload, kernel and download.
+/* The OLDEST acquired slot holds n samples: enqueue its upload, kernel and download.
  * Returns without waiting. */
 int hzsdr_ring_submit(hzsdr_ring *r, int slot, size_t n);
-/* Give the acquired slot back unused (the source had nothing for it: the end of a stream): the next
+/* `count` (1..8) acquired slots, first_slot the oldest, n samples each, as ONE call of the chain: their uploads,
+ * hzsdr_chain_run_batch_after's launch over the slots' device copies (one launch of the FIR-decimate terminal's
+ * persistent-pass kernel where that form applies -- hzsdr_chain_run_batch's conditions --, slot by slot otherwise),
+ * their downloads; hzsdr_ring_pop hands the outputs out slot by slot as before.  The results are those of `count`
+ * hzsdr_ring_submit calls, bit for bit.  What a driver callback that fills slots faster than one launch per slot
+ * pays for does: submit what has accumulated (stream/ring.go:337-392 has no counterpart -- its reader copies). */
+int hzsdr_ring_submit_many(hzsdr_ring *r, int first_slot, int count, size_t n);
+/* Give the NEWEST acquired slot back unused (the source had nothing for it: the end of a stream): the next
  * hzsdr_ring_acquire hands out the same slot.  No reference counterpart (stream.RingBuffer's writer simply does not
  * advance: stream/ring.go:337-392). */
 int hzsdr_ring_release(hzsdr_ring *r, int slot);

@@ -327,6 +327,30 @@ static void chain_and_ring(void) { /* go/hip/stream.go Chain, go/hip/ring.go */
         /* the stream through the ring equals the synchronous run of the same samples */
         if (k == 0) CHECK(memcmp(o, y, 64) != 0 || 1);
     }
+    {   /* several slots acquired ahead and handed over as ONE call of the chain (hzsdr_ring_submit_many); the newest
+           acquired slot can be given back, an older one cannot; outputs pop slot by slot */
+        int s0 = -1, s1 = -1, s2 = -1;
+        void *iq = NULL;
+        OK(hzsdr_ring_acquire(r, &s0, &iq));
+        memcpy(iq, x, 2 * slot_len);
+        OK(hzsdr_ring_acquire(r, &s1, &iq));
+        memcpy(iq, x + 2 * slot_len, 2 * slot_len);
+        OK(hzsdr_ring_acquire(r, &s2, &iq));
+        CHECK(s1 == (s0 + 1) % 4 && s2 == (s0 + 2) % 4);
+        CHECK(hzsdr_ring_release(r, s1) == HZSDR_ERR_INVALID_ARGUMENT);
+        OK(hzsdr_ring_release(r, s2));
+        CHECK(hzsdr_ring_submit_many(r, s1, 1, slot_len) == HZSDR_ERR_INVALID_ARGUMENT); /* not the oldest */
+        CHECK(hzsdr_ring_submit_many(r, s0, 3, slot_len) == HZSDR_ERR_INVALID_ARGUMENT); /* the third is not acquired */
+        CHECK(hzsdr_ring_submit_many(r, s0, 9, slot_len) == HZSDR_ERR_INVALID_ARGUMENT);
+        OK(hzsdr_ring_submit_many(r, s0, 2, slot_len));
+        CHECK(hzsdr_ring_in_flight(r) == 2);
+        for (int k = 0; k < 2; k++) {
+            const void *o = NULL;
+            size_t no = 0;
+            OK(hzsdr_ring_pop(r, &o, &no));
+            CHECK(no == slot_len / D);
+        }
+    }
     {   /* a slot acquired and given back unused: the next acquire hands out the same one */
         int slot = -1, again = -2;
         void *iq = NULL;

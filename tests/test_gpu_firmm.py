@@ -387,8 +387,8 @@ def test_pipelined_chain_is_bit_identical_to_the_plain_one(hz):
 
 @pytest.mark.parametrize("sets", [2, 3, 5])
 def test_pipelined_chain_over_a_small_rotation_of_buffers(hz, sets):
-    """A caller that rotates two, three or five (input, output) sets under hzsdr_chain_run_after with nothing to wait
-    for: a call writes the output a call two, three or five places back wrote.  Two back is the chain's own stream,
+    """A caller that rotates two, three or five (input, output) sets under hzsdr_chain_run_after, each call waiting for
+    the consumer of its output set's previous contents only: a call writes the output a call two, three or five places back wrote.  Two back is the chain's own stream,
     three back its OTHER stream (the call's stream waits for that kernel: csrc/hz_chain_fir.hip, pipeline_begin), one
     back and the history kernels are found by buffer span.  Each output is copied away on the context's stream right
     behind its call (ordered there, like any consumer) and compared with the plain chain's, bit for bit."""
@@ -406,12 +406,20 @@ def test_pipelined_chain_over_a_small_rotation_of_buffers(hz, sets):
         xs = [torch.from_numpy(rand_u8(500 + i, n)).cuda() for i in range(sets)]
         ys = [torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(sets)]
         keep = [torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(24)]
+        copied = [torch.cuda.Event() for _ in range(sets)]
         torch.cuda.synchronize()
         with torch.cuda.stream(s):
             for i in range(24):
-                run = ch.run_after if piped else ch.run
-                assert run(xs[i % sets], ys[i % sets]) == (n, n // D)
-                keep[i].copy_(ys[i % sets])  # (on the context's stream: behind the call, in front of the next writer)
+                # (hzsdr_chain_run_after's contract: the call's buffers -- the OUTPUT too -- are free when the event has
+                # fired.  The consumer of the set's previous output is the copy below, on the context's stream, which an
+                # overlapped call is not ordered behind: the call is told.  Round 5's test passed "nothing to wait for"
+                # here and raced that copy -- it lost once on a fast box in round 6, the tail of keep[0] held call 3's outputs.)
+                if piped:
+                    assert ch.run_after(xs[i % sets], ys[i % sets], copied[i % sets] if i >= sets else None) == (n, n // D)
+                else:
+                    assert ch.run(xs[i % sets], ys[i % sets]) == (n, n // D)
+                keep[i].copy_(ys[i % sets])  # (on the context's stream: behind the call)
+                copied[i % sets].record(s)
         ctx.synchronize()
         res.append([torch.view_as_real(k).view(torch.int32).cpu().numpy() for k in keep])
         ch.close()

@@ -24,6 +24,113 @@ static void pct(const char *name, std::vector<double> v) {
            v[v.size() / 2] / 100, v[v.size() * 9 / 10] / 100, v.back() / 100);
 }
 
+// PASSES=1: a row of stamps for every pass of every wave (EXP 64 | 1 << 24; s_memrealtime, 10 ns ticks, staged in LDS and
+// written out at the wave's end).  Row p of a wave: [0] the pass's top, [7] queue read, [1] the next pass's loads issued =
+// the matrix loop's start, [2] its end, [3] the next pass landed, [4] planes combined, [5] mixer done, [6] stores issued.
+// Reduced to what VERDICT r05 asked for: a per-phase table over all passes of the launch, the same split by whether the
+// SIMD partner (wave w ^ 4 of the workgroup) was inside ITS matrix loop for most of the phase, and per SIMD the share
+// of its busy window in which both / one / neither wave was inside a matrix loop.
+static void analyze_passes(unsigned grid) {
+    constexpr int R = 16;
+    const size_t nw = (size_t)grid * mm2::kWaves;
+    std::vector<unsigned long long> st(nw * 8 * R);
+    CK(hipMemcpy(st.data(), g_stamps, st.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (size_t w = 0; w < nw; w++) t0 = std::min(t0, st[w * 8 * R]);
+    struct Iv { double a, b; };
+    auto loops_of = [&](size_t w) {
+        std::vector<Iv> v;
+        for (int p = 1; p < R; p++) {
+            const unsigned long long *q = &st[(w * R + p) * 8];
+            if (q[1] && q[2]) v.push_back({(double)(q[1] - t0), (double)(q[2] - t0)});
+        }
+        return v;
+    };
+    auto overlap = [](const std::vector<Iv> &v, double a, double b) {
+        double s = 0;
+        for (const Iv &i : v) s += std::max(0.0, std::min(b, i.b) - std::max(a, i.a));
+        return s;
+    };
+    const char *names[7] = {"queue + next pass's loads issued", "matrix loop", "landing the next pass", "planes -> float32", "mixer", "stores issued", "whole pass (top to stores)"};
+    std::vector<double> all[7], with[7], without[7];
+    std::vector<double> first_loop, last_end, passes_per_wave;
+    double sum_window = 0, sum_both = 0, sum_one = 0, sum_none = 0, sum_loop = 0;
+    size_t simds = 0;
+    for (size_t wg = 0; wg < grid; wg++)
+        for (int w = 0; w < mm2::kWaves; w++) {
+            const size_t me = wg * mm2::kWaves + w, pa = wg * mm2::kWaves + (w ^ 4);
+            const std::vector<Iv> mine = loops_of(me), theirs = loops_of(pa);
+            passes_per_wave.push_back((double)mine.size());
+            for (int p = 1; p < R; p++) {
+                const unsigned long long *q = &st[(me * R + p) * 8];
+                if (!q[1] || !q[2] || !q[6]) continue;
+                const double tq[7] = {(double)(q[0] - t0), (double)(q[1] - t0), (double)(q[2] - t0), (double)(q[3] - t0), (double)(q[4] - t0), (double)(q[5] - t0), (double)(q[6] - t0)};
+                for (int k = 0; k < 7; k++) {
+                    const double a = k == 6 ? tq[0] : tq[k], b = k == 6 ? tq[6] : tq[k + 1];
+                    if (!(b >= a) || (k >= 3 && k <= 5 && q[4] == 0)) continue;
+                    all[k].push_back(b - a);
+                    const double ov = b > a ? overlap(theirs, a, b) / (b - a) : 0.0;
+                    (ov >= 0.5 ? with[k] : without[k]).push_back(b - a);
+                }
+            }
+            if (w < 4 && !mine.empty() && !theirs.empty()) {  // one SIMD: the pair's window from its first loop's start to its last loop's end
+                const double a = std::min(mine[0].a, theirs[0].a), b = std::max(mine.back().b, theirs.back().b);
+                // sweep
+                std::vector<std::pair<double, int>> ev;
+                for (const Iv &i : mine) ev.push_back({i.a, 1}), ev.push_back({i.b, -1});
+                for (const Iv &i : theirs) ev.push_back({i.a, 1}), ev.push_back({i.b, -1});
+                std::sort(ev.begin(), ev.end());
+                double t = a, both = 0, one = 0, none = 0;
+                int in = 0;
+                for (auto &e : ev) {
+                    const double dt = e.first - t;
+                    (in >= 2 ? both : in == 1 ? one : none) += dt;
+                    t = e.first, in += e.second;
+                }
+                sum_window += b - a, sum_both += both, sum_one += one, sum_none += none;
+                for (const Iv &i : mine) sum_loop += i.b - i.a;
+                for (const Iv &i : theirs) sum_loop += i.b - i.a;
+                first_loop.push_back(a), last_end.push_back(b);
+                simds++;
+            }
+        }
+    auto row = [&](const char *nm, std::vector<double> v) {
+        if (v.empty()) { printf("    %-36s (none)\n", nm); return; }
+        std::sort(v.begin(), v.end());
+        double m = 0;
+        for (double x : v) m += x;
+        printf("    %-36s n %7zu  mean %6.2f  p10 %6.2f  median %6.2f  p90 %6.2f us\n", nm, v.size(), m / v.size() / 100, v[v.size() / 10] / 100, v[v.size() / 2] / 100, v[v.size() * 9 / 10] / 100);
+    };
+    printf("  per-pass phases over ALL passes of the launch (every wave of every workgroup):\n");
+    for (int k = 0; k < 7; k++) row(names[k], all[k]);
+    printf("  ... the same, phases during which the SIMD partner was inside its matrix loop (>= half of the phase):\n");
+    for (int k = 0; k < 7; k++) row(names[k], with[k]);
+    printf("  ... and phases during which it was not:\n");
+    for (int k = 0; k < 7; k++) row(names[k], without[k]);
+    row("passes per wave (x 0.01)", passes_per_wave);
+    printf("  per SIMD (%zu pairs of waves), from the pair's first loop start to its last loop end: window %.2f us mean;\n"
+           "    both waves inside a matrix loop %.1f %%, exactly one %.1f %%, NEITHER %.1f %% of the window; the two waves' loop time adds up to %.2f us per SIMD\n",
+           simds, sum_window / simds / 100, 100 * sum_both / sum_window, 100 * sum_one / sum_window, 100 * sum_none / sum_window, sum_loop / simds / 100);
+    row("SIMD: first loop starts at", first_loop);
+    row("SIMD: last loop ends at", last_end);
+    std::vector<double> ends;
+    for (size_t w = 0; w < nw; w++) ends.push_back((double)(st[w * 8 * R + 7] - t0));
+    row("wave end", ends);
+    {   // the shader clock under this kernel: s_memtime cycles per 10 ns tick of s_memrealtime, per workgroup
+        std::vector<unsigned long long> ck(2 * (size_t)grid);
+        CK(hipMemcpy(ck.data(), g_stamps + nw * 8 * R, ck.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> ghz;
+        for (unsigned wg = 0; wg < grid; wg++)
+            if (ck[2 * wg + 1]) ghz.push_back((double)ck[2 * wg] / (double)ck[2 * wg + 1] / 10.0);
+        std::sort(ghz.begin(), ghz.end());
+        if (!ghz.empty())
+            printf("  shader clock over the workgroups' lives (s_memtime / s_memrealtime): min %.3f  median %.3f  max %.3f GHz;\n"
+                   "    at the median clock a pass's 272 MFMAs x 32 cycles are %.2f us, a SIMD's %d passes %.1f us of matrix pipe\n",
+                   ghz[0], ghz[ghz.size() / 2], ghz.back(), 8704.0 / ghz[ghz.size() / 2] / 1000.0, (int)(all[1].size() / (4 * (size_t)grid)),
+                   (double)(all[1].size() / (4 * (size_t)grid)) * 8704.0 / ghz[ghz.size() / 2] / 1000.0);
+    }
+}
+
 static int g_batch = 1;  // buffers per launch (BATCH=k: the kernel over k of the 12 buffers as one call, hzsdr_chain_run_batch's form)
 
 template <int EXP, int MIXT = 1, int NGT = 17> static void run(void *const *in, float2 *out, const float2 *taps, const void *tab, size_t n_each, int ntaps,
@@ -66,7 +173,7 @@ template <int EXP, int MIXT = 1, int NGT = 17> static void run(void *const *in, 
         F.m_b[0] = 4096 + mm2::kFixOut * F.n_task;
         R.n_task = F.n_task;
     }
-    const size_t lds = mm2::lds_bytes(D, g.ks, g.ne, g.ntaps) + ((EXP & 64) ? 2048 : 0);  // (+ the stamps' staging area)
+    const size_t lds = mm2::lds_bytes(D, g.ks, g.ne, g.ntaps) + ((EXP & 64) ? ((EXP & (1 << 24)) ? 8192 : 2048) : 0);  // (+ the stamps' staging area)
     const unsigned grid = (unsigned)g_grid;
     auto k = mm2::fir_mm2_kernel<HZSDR_FMT_U8, D, NGT, EXP>;
     CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -94,6 +201,10 @@ template <int EXP, int MIXT = 1, int NGT = 17> static void run(void *const *in, 
     std::sort(all.begin(), all.end());
     printf("MIX %d EXP %6d%s: grid %u, LDS %zu, ks %d, passes %d, %d buffer(s) per launch: min %.1f us  median %.1f us  avg %.1f us PER BUFFER\n", MIXT, EXP, shift ? " +Shift" : "       ", grid, lds,
            g.ks, R.n_pass, g_batch, best * 1e3f / g_batch, all[all.size() / 2] * 1e3f / g_batch, sum / reps * 1e3f / g_batch);
+    if constexpr ((EXP & 64) != 0 && (EXP & (1 << 24)) != 0) {
+        analyze_passes(grid);
+        return;
+    }
     if (EXP & 64) {
         const size_t nw = (size_t)grid * mm2::kWaves;
         std::vector<unsigned long long> st(nw * 32);
@@ -217,18 +328,66 @@ int main(int argc, char **argv) {
         for (size_t i = 0; i < h.size(); i++) h[i] = (unsigned char)((i + b) * 2654435761u >> 24);
         CK(hipMemcpy(in[b], h.data(), h.size(), hipMemcpyHostToDevice));
     }
+    if (getenv("ZERO") || getenv("ZERO_IN")) {  // quiet data: every sample 0x80 (0 behind the u8 sign flip), the table below all zeros -- the same instruction stream, no toggling operands
+        std::fill(h.begin(), h.end(), (unsigned char)0x80);
+        for (int b = 0; b < 12; b++) CK(hipMemcpy(in[b], h.data(), h.size(), hipMemcpyHostToDevice));
+    }
     if (getenv("BATCH")) g_batch = atoi(getenv("BATCH"));
     if (g_batch < 1 || g_batch > mm2::kMaxBatch) g_batch = 1;
     CK(hipMalloc(&out, ((size_t)g_batch * n / 8 + 8192) * 8));
     CK(hipMalloc(&taps, ntaps * 8 + 65536));
     CK(hipMemset(taps, 0, ntaps * 8 + 65536));
     std::vector<unsigned char> t(1 << 20);
-    for (size_t i = 0; i < t.size(); i++) t[i] = (unsigned char)(i * 40503u >> 8);
+    for (size_t i = 0; i < t.size(); i++) t[i] = (getenv("ZERO") || getenv("ZERO_TAB")) ? 0 : (unsigned char)(i * 40503u >> 8);
     CK(hipMalloc(&tab, t.size()));
     CK(hipMemcpy(tab, t.data(), t.size(), hipMemcpyHostToDevice));
-    CK(hipMalloc(&g_stamps, 8 * 32 * 8 * 1024));
-    CK(hipMemset(g_stamps, 0, 8 * 32 * 8 * 1024));
+    CK(hipMalloc(&g_stamps, 8 * 128 * 8 * 1024));
+    CK(hipMemset(g_stamps, 0, 8 * 128 * 8 * 1024));
     printf("fir_mm2_kernel<u8, 8>, 2^24 samples, %d taps; EXP 1 = no input loads, 2 = no matrix loop, 4 = no mixer, 8 = no stores, 32 = wave priorities, 128 = no explicit vmcnt(0)\n", ntaps);
+    constexpr int LIB5 = 8192 | 16384 | 65536 | 131072 | 262144 | (1 << 22);  // round 5's library
+    constexpr int LIB6 = LIB5 | (1 << 25) | (1 << 26);                          // round 6: the landing's flip as a branch, the one-Shift program peeled
+    if (getenv("PASSES")) {  // the per-pass stamp table (BATCH=4 for the benchmarked form)
+        run<LIB6, 0>(in, out, taps, tab, n, ntaps, true);
+        run<LIB6 | 64 | (1 << 24), 0>(in, out, taps, tab, n, ntaps, true);
+        if (getenv("SPLIT")) {  // where the power goes: the same launch without its mixer, without its stores, without both, without the input
+            run<LIB6 | 4, 0>(in, out, taps, tab, n, ntaps, true);
+            run<LIB6 | 8, 0>(in, out, taps, tab, n, ntaps, true);
+            run<LIB6 | 4 | 8, 0>(in, out, taps, tab, n, ntaps, true);
+            run<LIB6 | 1, 0>(in, out, taps, tab, n, ntaps, true);
+            run<LIB6 | 2, 0>(in, out, taps, tab, n, ntaps, true);
+            run<LIB6, 0>(in, out, taps, tab, n, ntaps, true);
+        }
+        return 0;
+    }
+    if (getenv("CLOCKS")) {  // the shader clock the chip holds under the kernel and under the kernel without one of its parts
+        constexpr int ST = 64 | (1 << 24);
+        for (int r = 0; r < 2; r++) {
+            run<LIB6 | ST, 0>(in, out, taps, tab, n, ntaps, true);
+            run<LIB6 | ST | 4, 0>(in, out, taps, tab, n, ntaps, true);       // no mixer
+            run<LIB6 | ST | 8, 0>(in, out, taps, tab, n, ntaps, true);       // no stores
+            run<LIB6 | ST | (1 << 27), 0>(in, out, taps, tab, n, ntaps, true);  // the planes' combination in float32 (timing only: not exact)
+            run<LIB6 | ST, 0>(in, out, taps, tab, n, ntaps, false);          // no Shift stage at all
+        }
+        return 0;
+    }
+    if (getenv("AB7")) {  // what the float64 plane combination costs in the benchmarked form: the same kernel with a float32 one (NOT exact: timing only)
+        for (int r = 0; r < 5; r++) {
+            run<LIB6, 0>(in, out, taps, tab, n, ntaps, true);
+            run<LIB6 | (1 << 27), 0>(in, out, taps, tab, n, ntaps, true);
+            run<LIB6 | 4, 0>(in, out, taps, tab, n, ntaps, true);
+            run<LIB6 | 4 | (1 << 27), 0>(in, out, taps, tab, n, ntaps, true);
+        }
+        return 0;
+    }
+    if (getenv("AB6")) {  // round 6's instruction cuts against round 5's library, interleaved (BATCH=4 for the benchmarked form)
+        for (int r = 0; r < 4; r++) {
+            run<LIB5, 0>(in, out, taps, tab, n, ntaps, true);
+            run<LIB5 | (1 << 25), 0>(in, out, taps, tab, n, ntaps, true);
+            run<LIB5 | (1 << 26), 0>(in, out, taps, tab, n, ntaps, true);
+            run<LIB6, 0>(in, out, taps, tab, n, ntaps, true);
+        }
+        return 0;
+    }
     if (getenv("AB")) {  // A/B of the build's switches on one box, interleaved
         // round 5: the instruction cuts one by one and together (hz_firmm2.h, EXP): 8192 packed mixer, 16384 int32 plane
         // pair, 32768 sign flip by the LDS, 65536 constant-C first step, 131072 cold path fenced; 4 = no mixer at all
