@@ -37,13 +37,25 @@ void nco_shift_ulp1_map4(hzsdr_ctx *ctx, void *buf, size_t nvec4, uint64_t base,
 // the kernel is bound by its float64 instructions at ~46 us either way; tools/nco_ablate.hip, "rotation").
 static bool shift_streams_past_cache(size_t bytes) { return bytes >= ((size_t)96 << 20); }
 
+// shift_exact_kernel's launch: its workgroups walk the tiles (hz_chain_dev.h) -- as many workgroups as fit the chip at
+// once (80 registers: six waves per SIMD, twelve two-wave workgroups per CU), fewer for a short call
+#ifndef HZ_SHIFT_WGS
+#define HZ_SHIFT_WGS 12
+#endif
+static unsigned shift_grid(const hzsdr_ctx *ctx, size_t nvec) {
+    const size_t tiles = (nvec + (size_t)kShiftU * kShiftThreads - 1) / ((size_t)kShiftU * kShiftThreads);
+    if (!kShiftPrefetch) return blocks_for(ctx, (nvec + kShiftU - 1) / kShiftU, kShiftThreads);
+    const size_t cap = (size_t)ctx->num_cus * HZ_SHIFT_WGS;
+    return (unsigned)(tiles < cap ? (tiles ? tiles : 1) : cap);
+}
+
 void nco_shift_exact_map2(hzsdr_ctx *ctx, void *buf, size_t nvec2, uint64_t base, double tau_shift, const NcoSegs &sg) {
     EwProgram P{};
     P.n = 1;
     P.op[0].kind = EW_SHIFT;
     P.op[0].tau_shift = tau_shift;
     P.segs = sg;
-    const dim3 grid(blocks_for(ctx, (nvec2 + kShiftU - 1) / kShiftU, kShiftThreads)), block(kShiftThreads);
+    const dim3 grid(shift_grid(ctx, nvec2)), block(kShiftThreads);
     if (shift_streams_past_cache(nvec2 * 16))
         hipLaunchKernelGGL((shift_exact_kernel<HZSDR_FMT_C64, false, true>), grid, block, 0, ctx->stream, (const void *)buf, (float4 *)buf, nvec2, base, P);
     else
@@ -64,7 +76,7 @@ static void launch_map(hzsdr_ctx *ctx, const void *in, void *out, size_t n, cons
     if (!ulp1 && (shape == SHAPE_SHIFT || shape == SHAPE_SHIFT_GAIN) && ok(2) && n >= 2) {
         // the bit-exact Shift (+ Gain): two samples per vector, the factor by sincos_narrow (shift_exact_kernel)
         const size_t nvec = n / 2;
-        const dim3 grid(blocks_for(ctx, (nvec + kShiftU - 1) / kShiftU, kShiftThreads)), block(kShiftThreads);
+        const dim3 grid(shift_grid(ctx, nvec)), block(kShiftThreads);
         const bool nt = shift_streams_past_cache(in == out ? 8 * n : (sizeof(R) + 8) * n);
         if (shape == SHAPE_SHIFT_GAIN && nt)
             hipLaunchKernelGGL((shift_exact_kernel<FMT, true, true>), grid, block, 0, ctx->stream, in, (float4 *)out, nvec, (uint64_t)0, P);

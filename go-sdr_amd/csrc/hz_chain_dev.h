@@ -251,7 +251,11 @@ __global__ __launch_bounds__(kThreads) void chain_map_kernel(const void *__restr
     struct alignas(8 * W) OV { float2 v[W]; };
     // a workgroup owns a contiguous tile per trip and issues its U loads per lane
     // back to back before the arithmetic (memory-level parallelism, see hz_nco.hip)
+#ifdef HZ_MAP_U4
+    constexpr int U = W >= 4 ? HZ_MAP_U4 : 2;
+#else
     constexpr int U = W >= 4 ? 1 : 2;
+#endif
     const size_t tile = (size_t)kThreads * U;
     for (size_t t0 = (size_t)blockIdx.x * tile; t0 < nvec; t0 += (size_t)gridDim.x * tile) {
         const uint64_t j_lo = base + t0 * W;
@@ -287,7 +291,23 @@ __global__ __launch_bounds__(kThreads) void chain_map_kernel(const void *__restr
 // wave works the queue off behind the tile through ONE rolled copy of go_sincos.  (With go_sincos inline behind
 // each check the straight path lost more to the compiler's register and code layout than the check saves;
 // tools/nco_ablate.hip.)
-constexpr int kShiftU = 4, kShiftThreads = 128;  // (two waves per workgroup: 46.5 us where four take 47.8, tools/nco_ablate.hip)
+#ifndef HZ_SHIFT_U
+#define HZ_SHIFT_U 4
+#endif
+#ifndef HZ_SHIFT_TPB
+#define HZ_SHIFT_TPB 128
+#endif
+constexpr int kShiftU = HZ_SHIFT_U, kShiftThreads = HZ_SHIFT_TPB;  // (two waves per workgroup: 46.5 us where four take 47.8, tools/nco_ablate.hip)
+// Round 6, measured and left off (-DHZ_SHIFT_PF builds it: csrc/Makefile EXTRA): a workgroup WALKS several tiles and
+// asks for the NEXT tile's vectors before it works on the ones it holds.  From HBM (a rotation of six buffer pairs,
+// tools/shift_time.py, profiles/r06_shift_time.txt) 55-57 us per 2^24 samples with 12 walking workgroups per CU, 59
+// with 6, 51-53 with 24 -- against 51.7-53 for one tile per workgroup: what the map lacks from HBM is not overlap
+// inside a wave but workgroups in flight, and a walk has fewer.
+#ifdef HZ_SHIFT_PF
+constexpr bool kShiftPrefetch = true;
+#else
+constexpr bool kShiftPrefetch = false;
+#endif
 template <int FMT, bool GAIN, bool NT = false>
 __global__ __launch_bounds__(kShiftThreads) void shift_exact_kernel(const void *in, float4 *out, size_t nvec, uint64_t base, EwProgram P) {
     using R = typename Raw<FMT>::t;
@@ -298,8 +318,18 @@ __global__ __launch_bounds__(kShiftThreads) void shift_exact_kernel(const void *
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) q_n[wave] = 0;
     const double tau_shift = P.op[0].tau_shift;
-    const size_t tile = (size_t)TPB * U;
-    for (size_t t0 = (size_t)blockIdx.x * tile; t0 < nvec; t0 += (size_t)gridDim.x * tile) {
+    const size_t tile = (size_t)TPB * U, hop = (size_t)gridDim.x * tile;
+    auto fetch = [&](RV(&a)[U], size_t t0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const RV *const p = (const RV *)in + (t0 + (size_t)u * TPB + threadIdx.x);
+            a[u] = NT ? nt_load(p) : *p;
+        }
+    };
+    RV a[U], nx[U];
+    size_t t0 = (size_t)blockIdx.x * tile;
+    if (kShiftPrefetch && t0 + tile <= nvec) fetch(a, t0);  // (whole tiles only: the ragged last one goes to the queue)
+    for (; t0 < nvec; t0 += hop) {
         const uint64_t j_lo = base + 2 * t0;
         const NcoWin w = nco_window(P.segs, j_lo, j_lo + 2 * tile - 1);
         const uint64_t d0 = j_lo - nco_first(P.segs, w.lo);
@@ -313,13 +343,12 @@ __global__ __launch_bounds__(kShiftThreads) void shift_exact_kernel(const void *
             const double x_lo = fabs(__dmul_rn(tau_shift, ts_lo > 0.0 ? ts_lo : ts_1)), x_hi = fabs(__dmul_rn(tau_shift, ts_hi));
             straight = ts_lo >= 0.0 && step > 0.0 && (x_lo >= 8.673617379884035e-19 || tau_shift == 0.0) && x_hi < 536870912.0;  // 2^-60, 2^29
         }
+        // (the next tile of this workgroup's walk, in flight under this tile's arithmetic: a whole tile, so that the
+        // loads need no mask -- the map may be in place, but tiles do not overlap)
+        const bool more = kShiftPrefetch && t0 + hop + tile <= nvec;  // uniform
+        if (more) fetch(nx, t0 + hop);
         if (__builtin_amdgcn_readfirstlane((int)straight)) {
-            RV a[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const RV *const p = (const RV *)in + (t0 + (size_t)u * TPB + threadIdx.x);
-                a[u] = NT ? nt_load(p) : *p;
-            }
+            if constexpr (!kShiftPrefetch) fetch(a, t0);
             const double k0 = (double)((uint32_t)d0 + 2u * threadIdx.x);
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -360,6 +389,12 @@ __global__ __launch_bounds__(kShiftThreads) void shift_exact_kernel(const void *
                 }
             }
             if (lane == 0) q_n[wave] = 0;
+        }
+        if constexpr (kShiftPrefetch) {
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < U; u++) a[u] = nx[u];
+            }
         }
     }
 }

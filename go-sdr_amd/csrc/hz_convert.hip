@@ -386,6 +386,54 @@ __global__ __launch_bounds__(kThreads) void downsample_kernel(
     }
 }
 
+// Round 6, the large-call form for windows of exactly G vectors (i16 / 8: two; u8 / 8: one; i16 / 16: four): a lane
+// holds M windows at a time -- i, i + stride, ... as the in-place maps do (hz_vector.hip) -- and ALL their vectors are in
+// flight before the first sum: M G x 16 bytes per lane at once instead of G x 16, a quarter of the workgroups.  A
+// 15 us kernel spends 2-3 us getting its first bytes; more of them per lane at that moment looked like what was left to
+// gain.  MEASURED AND LEFT OFF (HZ_DOWNSAMPLE_M = 1 launches the one-window kernel below as before;
+// tools/downsample_time.py over a rotation of six buffer pairs, profiles/r06_downsample_time.txt): i16 / 8 per call
+// 17.6-17.8 us with one window per lane, 18.2-18.3 with two, 18.4-18.5 with four or eight (back to back 15.4-15.6 /
+// 16.0 / 16.3).  The sums are the same additions in the same order.
+#ifndef HZ_DOWNSAMPLE_M
+#define HZ_DOWNSAMPLE_M 1
+#endif
+template <int FMT, int W, int G, int M>
+__global__ __launch_bounds__(kThreads) void downsample_multi_kernel(
+    const typename SrcSample<FMT>::raw_t *__restrict__ from, float2 *to, size_t count) {
+    using R = typename SrcSample<FMT>::raw_t;
+    constexpr unsigned factor = W * G;
+    const float div = (float)factor;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto finish = [&](const Vec<R, W>(&v)[G], size_t o) {
+        float sr = 0.0f, si = 0.0f;
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                float2 c = SrcSample<FMT>::cvt(v[g].v[k]);
+                sr = __fadd_rn(sr, c.x);
+                si = __fadd_rn(si, c.y);
+            }
+        st_stream<true>(to + o, make_float2(__fdiv_rn(sr, div), __fdiv_rn(si, div)));
+    };
+    for (; i + (M - 1) * stride < count; i += M * stride) {
+        Vec<R, W> v[M][G];
+#pragma unroll
+        for (int m = 0; m < M; m++)
+#pragma unroll
+            for (int g = 0; g < G; g++) v[m][g] = ld_stream<true>(reinterpret_cast<const Vec<R, W> *>(from + (i + m * stride) * factor) + g);
+#pragma unroll
+        for (int m = 0; m < M; m++) finish(v[m], i + m * stride);
+    }
+    for (; i < count; i += stride) {
+        Vec<R, W> v[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) v[g] = ld_stream<true>(reinterpret_cast<const Vec<R, W> *>(from + i * factor) + g);
+        finish(v, i);
+    }
+}
+
 template <int FMT>
 static void launch_downsample(hzsdr_ctx *ctx, const void *from, void *to, size_t count,
                               unsigned factor) {
@@ -399,7 +447,15 @@ static void launch_downsample(hzsdr_ctx *ctx, const void *from, void *to, size_t
     const unsigned nv = factor / W;  // 16-byte vectors per window
     const bool past = count * ((size_t)factor * sizeof(R) + 8) >= ((size_t)64 << 20);
     // non-temporal only where a window's vectors travel together (see the kernel): windows of 1, 2 or 4k vectors
-    if (vec && past && nv % 4 == 0)
+    constexpr int M = HZ_DOWNSAMPLE_M;
+    const dim3 gm(blocks_for(ctx, (count + M - 1) / M));
+    if (M > 1 && vec && past && nv == 4)
+        hipLaunchKernelGGL((downsample_multi_kernel<FMT, W, 4, (M > 2 ? M / 2 : 1)>), dim3(blocks_for(ctx, (count + M / 2 - 1) / (M > 2 ? M / 2 : 1))), b, 0, ctx->stream, (const R *)from, (float2 *)to, count);
+    else if (M > 1 && vec && past && nv == 2)
+        hipLaunchKernelGGL((downsample_multi_kernel<FMT, W, 2, M>), gm, b, 0, ctx->stream, (const R *)from, (float2 *)to, count);
+    else if (M > 1 && vec && past && nv == 1)
+        hipLaunchKernelGGL((downsample_multi_kernel<FMT, W, 1, M>), gm, b, 0, ctx->stream, (const R *)from, (float2 *)to, count);
+    else if (vec && past && nv % 4 == 0)
         hipLaunchKernelGGL((downsample_kernel<FMT, W, true, 4>), g, b, 0, ctx->stream, (const R *)from, (float2 *)to, count, factor);
     else if (vec && past && nv == 2)
         hipLaunchKernelGGL((downsample_kernel<FMT, W, true, 2>), g, b, 0, ctx->stream, (const R *)from, (float2 *)to, count, factor);

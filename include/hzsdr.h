@@ -373,7 +373,15 @@ int hzsdr_chain_fir_decimate(hzsdr_chain *c, const float *taps_c64, size_t n_tap
  * stream edges, across a run boundary or across the clock's 2*pi wrap keep reference
  * order.  The two orders agree to float32 rounding (the FIR itself is held to an error
  * bound, not to bits).  in_order = 1: every block mixes each input sample before the
- * filter, exactly as nested stream.ShiftReader -> filter Readers would. */
+ * filter, exactly as nested stream.ShiftReader -> filter Readers would.
+ * A VERIFICATION SWITCH, not a mode to run a stream in: it exists so that the default order can be
+ * checked against the reference's own order on the same kernels (tests/test_gpu_latemix.py,
+ * tests/test_gpu_fullsize.py hold the two to 3e-7 of each other and each to the oracle).  It keeps a
+ * chain on the transform kernels and evaluates the mixer at the INPUT rate -- 2^24 Sincos per 2^24
+ * samples where the default evaluates 2^21: 130 us per buffer against 28-36, and no faster form is
+ * planned (round 6 closed the item: the outputs it produces are inside the same error bound as the
+ * default's, so there is nothing a stream gains from it).  Results with it on are as well defined
+ * and as tested as with it off. */
 int hzsdr_chain_mix_in_order(hzsdr_chain *c, int in_order);
 /* Measurement and test aid, in front of hzsdr_chain_fir_decimate: WHICH implementation the FIR-decimate
  * terminal takes -- all of them compute the same filter (stream/downsample.go:47-64 / a Reader that
