@@ -344,12 +344,21 @@ def main():
                            "an implementation figure, not algorithmic work",
                 "achieved": round(exe_ops / t_s / 1e12, 1), "peak": I8_PEAK_TOPS, "unit": "Top/s",
                 "frac": round(exe_ops / t_s / 1e12 / I8_PEAK_TOPS, 4),
+                # (round 6, tools/mfma_power.hip -> profiles/r06_mfma_power.txt: what the chip SUSTAINS of this instruction on
+                # every SIMD -- the nominal peak assumes 2.4 GHz; under random int8 operands the chip holds 1.7 GHz)
+                "sustained_peak_random_operands": 3400.0, "frac_of_sustained": round(exe_ops / t_s / 1e12 / 3400.0, 4),
+                "sustained_peak_is": "bare back-to-back v_mfma_i32_32x32x32_i8 on all 1024 SIMDs, random operands: 19.5 ns per "
+                                     "MFMA per SIMD at the 1.7 GHz the chip then holds (4.4-4.9 Pop/s on zero operands at 2.2-2.4 GHz); "
+                                     "measured by tools/mfma_power.hip, not in this run",
             },
             "note": "3 B/sample puts the chain far above the HBM ridge (the 50 MB of a buffer are 8 us at 6.3 TB/s): "
-                    "what binds is the issue of int8 MFMAs at the clock the chip holds under them (~1.55 GHz: the "
-                    "1088 MFMAs per SIMD of a 2^24-sample buffer are 22.4 us, profiles/r04_mfma_fir2.txt), then the "
-                    "kernel's first ~5.5 us (cold instruction and scalar caches, the first bytes from HBM) and the "
-                    "vector instructions of the epilogues, which run beside the SIMD partner's matrix loop",
+                    "what binds is the issue of int8 MFMAs at the clock the chip's power management holds under TOGGLING "
+                    "matrix operands -- measured inside the kernel (tools/mfma_fir2.hip PASSES=1, profiles/r06_pass_breakdown*.txt): "
+                    "1.25-1.41 GHz over random bytes, 2.10 GHz over constant input, same instruction stream, 28-31 against 22 us per "
+                    "buffer (`extra.power` repeats the comparison in this run).  In CYCLES the matrix pipe is busy 79 % of a "
+                    "four-buffer launch (139 k of 175 k per SIMD, profiles/r05_sq_counters.txt); the rest is the launch's first "
+                    "~4.5 us, the workgroups' uneven ends, and the share of a matrix loop that runs alone on its SIMD at 93 % "
+                    "(per-pass stamps: profiles/r06_pass_breakdown.txt)",
         })
     else:
         roof = dict(hbm,
@@ -448,6 +457,43 @@ def main():
         extra["chain_adc_like_u8"] = rate(n, float(np.median(ms)), 2 + 8 / D)
         ch.close()
         del xa
+        # What the chip's POWER management does to this kernel (round 6, DESIGN.md section 4 "Round 6"): the benchmarked
+        # form -- B buffers per call, overlapped -- over CONSTANT input (every byte 0x80: zero behind the u8 sign flip).
+        # Same instruction stream, same bytes moved, same MFMA count; the matrix operands do not toggle, the chip holds
+        # ~2.1 GHz instead of the ~1.4 it holds over random bytes (tools/mfma_fir2.hip PASSES=1 / ZERO=1 measure the
+        # clock inside the kernel), and a buffer takes a quarter less time.
+        if matrix and B > 1:
+            def headline_form(inputs, steps=288, warm=144):
+                chp = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_decimate(taps, D)
+                if piped:
+                    chp.pipeline(True)
+                pos = [0]
+
+                def go(cnt):
+                    for _ in range(cnt // B):
+                        i = pos[0]
+                        pos[0] = i + B
+                        chp.run_batch([inputs[(i + j) % len(inputs)] for j in range(B)], [ys[(i + j) % len(ys)] for j in range(B)], after=piped)
+                go(warm)
+                torch.cuda.synchronize()
+                pa, pb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                pa.record()
+                go(steps)
+                pb.record()
+                torch.cuda.synchronize()
+                chp.close()
+                return pa.elapsed_time(pb) / (steps // B * B)
+            xq = [torch.full((n, 2), 0x80, dtype=torch.uint8, device="cuda") for _ in range(min(nbuf, 12))]
+            ms_quiet = headline_form(xq)
+            del xq
+            ms_rand = headline_form(xs)
+            extra["power"] = {
+                "headline_form_ms_per_step_random_bytes": round(ms_rand, 4), "headline_form_ms_per_step_constant_input": round(ms_quiet, 4),
+                "ratio": round(ms_rand / ms_quiet, 3),
+                "what": "the benchmarked call form, same run, over the bench's random bytes and over constant input (0x80): identical instruction "
+                        "stream and traffic -- the difference is the clock the chip holds under toggling int8 matrix operands "
+                        "(profiles/r06_pass_breakdown*.txt: 1.41 GHz against 2.10 GHz measured inside the kernel; profiles/r06_mfma_power.txt: "
+                        "bare v_mfma_i32_32x32x32_i8 streams on every SIMD sustain 3.4 Pop/s on random operands, 4.4-4.9 on zeros)"}
         # the same chain on the overlap-save transform kernels (round 2's first implementation)
         ch = ctx.chain(hz.FMT_U8, fs).shift(shift).fir_options(hz.FIR_IMPL_TRANSFORMS).fir_decimate(taps, D)
         _, ms = timed(torch, lambda: ch.run(x, y), k, w)

@@ -30,8 +30,15 @@ template <int FMT>
 static int launch_fmt(hipStream_t stream, int num_cus, unsigned D, const void *in, float2 *out, const float2 *hist,
                       float2 *new_hist, const uint8_t *rhist, uint8_t *new_rhist, const float2 *taps, size_t n, const Geom &g,
                       Plan L, const EwProgram &P, const Fix &F, const Batch &B, int rolled) {
-    if (D != 8) return HZSDR_ERR_INVALID_ARGUMENT;
+    if (!factor_ok(D)) return HZSDR_ERR_INVALID_ARGUMENT;
     const size_t lds = lds_bytes((int)D, g.ks, g.ne, g.ntaps);
+    if (D == 16) {  // (256 outputs per pass, one column block; the straight-line loop for the 1024-tap window: 9 groups of 8 steps)
+        const int grid16 = std::max(1, L.grid);
+        unsigned long long *no_stamps16 = nullptr;
+        if (g.ks == 9 * 8 && rolled == 0)
+            return launch(fir_mm2_kernel<FMT, 16, 9, kLibExp>, dim3(grid16), lds, stream, in, out, hist, new_hist, rhist, new_rhist, taps, n, g, L, P, F, B, no_stamps16);
+        return launch(fir_mm2_kernel<FMT, 16, 0, kLibExp>, dim3(grid16), lds, stream, in, out, hist, new_hist, rhist, new_rhist, taps, n, g, L, P, F, B, no_stamps16);
+    }
     // one workgroup per CU; a call with fewer passes than CUs: one pass per workgroup
     const int grid = std::max(1, L.grid);  // (the planner's: min(CUs, passes))
     (void)num_cus;

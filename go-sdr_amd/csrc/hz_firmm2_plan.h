@@ -27,7 +27,9 @@ constexpr int kMaxFix = kMaxClockRuns + 2;
 constexpr uint64_t kShortRun = 1280;
 constexpr int kU = 12;       // 16-byte pieces per lane of a pass image, any window (768 pieces = 12 KB at most)
 
-constexpr bool factor_ok(unsigned D) { return D == 8; }
+// (round 6: factor 16 as well -- one column block per pass, 256 outputs; 24 ... 64 keep the chunk kernel: their tiles
+// are 24 ... 64 pieces wide and the matrix loop's operand rings are written for groups of 4 or 8 steps)
+constexpr bool factor_ok(unsigned D) { return D == 8 || D == 16; }
 constexpr int blocks_for(int D) { return D >= 16 ? 1 : 2; }
 constexpr int tile_bytes(int D) { return 2 * D * kT; }
 constexpr int pass_tiles(int D) { return 32 * blocks_for(D); }

@@ -153,8 +153,8 @@ int main(int argc, char **argv) {
         if (g_case % 8 == 0) {
             static const unsigned factors[] = {8, 16, 32, 64};
             const bool v2 = rnd() % 2 == 0;
-            const int Dt = v2 ? 8 : (int)factors[rnd() % 4];
-            const int nt = 16 + (int)(rnd() % (v2 ? 1100 : 2000));
+            const int Dt = v2 ? (rnd() % 2 ? 8 : 16) : (int)factors[rnd() % 4];
+            const int nt = 16 + (int)(rnd() % (v2 ? (Dt == 16 ? 1024 : 1100) : 2000));
             std::vector<double> taps(2 * (size_t)nt);
             const double amp = ldexp(1.0, (int)(rnd() % 40) - 30);
             for (auto &t : taps) t = (double)(float)((urand() - 0.5) * amp);
@@ -217,8 +217,8 @@ int main(int argc, char **argv) {
         }
         // ---- the pass planner over these runs
         if (need > (size_t)mm2::kMaxClockRuns) continue;
-        const unsigned D = 8;
-        const int ntaps = 16 + (int)(rnd() % 1140);
+        const unsigned D = rnd() % 3 == 0 ? 16 : 8;  // (the persistent-pass kernel's factors: hz_firmm2_plan.h factor_ok)
+        const int ntaps = 16 + (int)(rnd() % (D == 16 ? 1024 : 1140));
         std::vector<uint64_t> first(need);
         std::vector<double> t0(need), step(need);
         std::vector<const void *> tab(need);
@@ -326,11 +326,11 @@ int main(int argc, char **argv) {
     long cut_cases = 0, cut_outputs = 0;
     for (g_case = 0; g_case < cases / 4; g_case++) {
         const uint64_t fs = rates[rnd() % (sizeof rates / sizeof rates[0])];
-        const unsigned D = 8;
-        const int ntaps = 16 + (int)(rnd() % 1140);
+        const unsigned D = rnd() % 3 == 0 ? 16 : 8;
+        const int ntaps = 16 + (int)(rnd() % (D == 16 ? 1024 : 1140));
         const unsigned off = (unsigned)((ntaps - 1 + D - 1) / D * D);
         const size_t nbuf = 2 + rnd() % 7;
-        const uint64_t ppb = 8 + rnd() % 120, n_each = ppb * 512 * D;
+        const uint64_t ppb = 8 + rnd() % 120, n_each = ppb * (uint64_t)mm2::pass_out((int)D) * D;
         double ts0;
         switch (rnd() % 4) {
         case 0: ts0 = tau - (double)(rnd() % (n_each * nbuf)) / (double)fs; break;  // the wrap somewhere in the stream

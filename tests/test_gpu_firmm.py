@@ -117,7 +117,9 @@ def test_matrix_form_against_the_oracle(hz, ctx, orc, name):
         assert ch.run(x[a:b], out[a // D:b // D]) == (b - a, (b - a) // D)
         assert ch.last_fir_path() == hz.FIR_PATH_MATRIX, (name, a)
         # factor 8 up to ~1150 taps: the persistent-pass kernel (csrc/hz_firmm2.h); the rest: chunk workgroups
-        want_kernel = hz.FIR_KERNEL_MATRIX_PASSES if D == 8 and c["ntaps"] <= 1100 else hz.FIR_KERNEL_MATRIX_CHUNKS
+        # (round 6: factor 16 up to 1040 taps as well -- its fix-up window, taps + 15 x 16 samples, must fit 1280)
+        passes = (D == 8 and c["ntaps"] <= 1100) or (D == 16 and c["ntaps"] <= 1040)
+        want_kernel = hz.FIR_KERNEL_MATRIX_PASSES if passes else hz.FIR_KERNEL_MATRIX_CHUNKS
         assert ch.last_fir_kernel() == want_kernel, (name, a, ch.last_fir_kernel())
     assert_fir_close(out, want, taps, xmax, name)
     # exact integer filter sums: what is left is one float32 rounding of the filter output and one per
@@ -574,8 +576,9 @@ def test_pipelined_chain_keeps_the_context_streams_order(hz):
     ctx.close()
 
 
+@pytest.mark.parametrize("D", [8, 16])
 @pytest.mark.parametrize("piped", [False, True])
-def test_run_batch_one_launch_equals_the_stream(hz, piped):
+def test_run_batch_one_launch_equals_the_stream(hz, piped, D):
     """hzsdr_chain_run_batch: k buffers of the stream in ONE launch of the persistent-pass kernel (separate
     allocations, the first pass of every buffer reaching back into the one before) -- against the oracle over the
     whole stream, and BIT FOR BIT the same stream through single calls (round 6: the mixer's phase and the choice
@@ -584,7 +587,11 @@ def test_run_batch_one_launch_equals_the_stream(hz, piped):
     runs one by one and equals single calls bit for bit as well."""
     import torch
     import oracle as orc
-    n, fs, D = 1 << 18, 20_000_000, 8
+    # (D = 16: the persistent passes' other factor, 256 outputs per pass -- round 6.  Its buffers are twice as long: the
+    # buffer that holds the 2 pi wrap must take the matrix path BY ITSELF for a call over several to take it -- a call
+    # over several buffers promises the bits of single calls -- and the wrap's ~2 600 fix-up outputs are more than an
+    # eighth of 2^18 / 16 outputs: the planner would keep that single call on the transform kernels)
+    n, fs = (1 << 18) * (D // 8), 20_000_000
     taps = taps_for(1024, 1 / 16, 0.0)
     batches = [4, 3, 1, 8]
     total = sum(batches)
@@ -592,7 +599,7 @@ def test_run_batch_one_launch_equals_the_stream(hz, piped):
     xs = [torch.from_numpy(x[j * n:(j + 1) * n]).cuda() for j in range(total)]
     ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.Stream().cuda_stream)
     ts0 = TAU - 0.05  # (wraps 10^6 samples in)
-    single = _north_chain(hz, ctx, taps)
+    single = _north_chain(hz, ctx, taps, fs, D)
     single.set_time(ts0)
     ys = [torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(total)]
     torch.cuda.synchronize()
@@ -600,7 +607,7 @@ def test_run_batch_one_launch_equals_the_stream(hz, piped):
         assert single.run(xs[j], ys[j]) == (n, n // D)
     ctx.synchronize()
     ref = np.concatenate([y.cpu().numpy() for y in ys])
-    ch = _north_chain(hz, ctx, taps)
+    ch = _north_chain(hz, ctx, taps, fs, D)
     if piped:
         ch.pipeline(True)
     ch.set_time(ts0)
@@ -626,7 +633,7 @@ def test_run_batch_one_launch_equals_the_stream(hz, piped):
     ctx.synchronize()
     assert torch.equal(torch.view_as_real(ya).view(torch.int32), torch.view_as_real(yb).view(torch.int32))
     # buffers that do not hold whole passes (n / D not a multiple of 512): one by one, the same bits as single calls
-    m = n - 8 * 24
+    m = n - D * 24
     ch.set_time(1.0), single.set_time(1.0)
     za = [torch.zeros(m // D, dtype=torch.complex64, device="cuda") for _ in range(3)]
     zb = [torch.zeros(m // D, dtype=torch.complex64, device="cuda") for _ in range(3)]
