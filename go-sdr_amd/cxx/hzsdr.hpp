@@ -666,6 +666,19 @@ public:
         stages_.push_back(st);
         return true;
     }
+    // the north-star terminal (kind 4: an N-tap FIR whose output is kept every `factor` samples -- hzsdr_chain_fir_decimate;
+    // the reference has no such Reader): `slots` slots in the pinned ring, `group` of them per call of the chain
+    bool extend_fir(const std::vector<std::complex<float>> &taps, unsigned factor, int slots, int group) {
+        if (!open()) return false;
+        if (!c64_here()) converted_ = true;  // (the terminal converts on its way in, as DownsampleReader does)
+        term_ = 4, factor_ = factor, taps_ = taps;
+        block_ = lcm(block_, factor);
+        rate_ /= factor;
+        slots_ = std::max(2, slots);
+        group_ = std::max(1, std::min(std::min(group, 8), slots_ - 1));
+        return true;
+    }
+    const Chain *chain() const { return chain_.get(); }
     // kind 1 Decimate, 2 Downsample (its own conversion of a raw source included), 3 Convolution
     bool extend_terminal(int kind, unsigned factor, Samples filter, size_t block) {
         if (chain_) return false;
@@ -689,7 +702,13 @@ public:
         if (s.format != SampleFormat() || s.format != HZSDR_FMT_C64) throw Error(HZSDR_ERR_FORMAT_MISMATCH, hzsdr_strerror(HZSDR_ERR_FORMAT_MISMATCH));
         if (!chain_) build();
         if (off_ >= pending_.length) {
-            while (inflight_ < 2 && fill_one()) {}
+            // everything but the slot being consumed is in flight -- refilled `group_` slots at a time, ONE call of the chain
+            // per group (hzsdr_ring_submit_many): a refill waits until that many slots are free, or nothing is in flight
+            for (;;) {
+                const int free_slots = slots_ - 1 - inflight_;
+                if (free_slots < 1 || (free_slots < group_ && inflight_ > 0)) break;
+                if (fill(std::min(group_, free_slots)) == 0) break;
+            }
             if (inflight_ == 0) {
                 if (err_) std::rethrow_exception(err_);
                 throw Eof();
@@ -719,28 +738,59 @@ private:
         if (term_ == 1) chain_->Decimate(factor_);
         else if (term_ == 2) chain_->Downsample(factor_);
         else if (term_ == 3) chain_->Convolution(Samples{HZSDR_FMT_C64, filter_.data(), filter_.size()}, decimate_);
+        else if (term_ == 4) {
+            chain_->FirDecimate(taps_, factor_);
+            check(x_.raw(), hzsdr_chain_pipeline(chain_->raw(), 1));  // (consecutive calls overlap: the ring says what each call's buffers wait for)
+        }
         const size_t unit = block_ > 1 ? block_ : kBlock;
         slot_len_ = std::max<size_t>(1, (size_t)readahead_ * kBlock / unit) * unit;
-        ring_ = std::make_unique<Ring>(*chain_, slot_len_, 3);
+        ring_ = std::make_unique<Ring>(*chain_, slot_len_, slots_);
     }
-    bool fill_one() {
-        if (err_) return false;
-        int slot = -1;
-        Samples iq = ring_->Acquire(src_format_, &slot);
-        size_t n = 0;
-        try {
-            while (n < slot_len_) n += src_->Read(iq.slice(n, slot_len_));
-        } catch (...) {
-            err_ = std::current_exception();
+    // Read the source into up to `want` slots and submit them: the full ones together, ONE call of the chain, a short last
+    // one (the source ended) by itself.  -> slots submitted.  An acquired slot is submitted or released whatever the
+    // source throws (the error is sticky and surfaces behind everything read before it).
+    int fill(int want) {
+        if (err_) return 0;
+        int first = -1, full = 0, done = 0;
+        auto flush = [&]() {
+            if (full) {
+                ring_->SubmitMany(first, full, slot_len_);
+                inflight_ += full;
+                full = 0;
+            }
+        };
+        while (done < want && !err_) {
+            int slot = -1;
+            Samples iq = ring_->Acquire(src_format_, &slot);
+            size_t n = 0;
+            int idle = 0;
+            try {
+                while (n < slot_len_) {
+                    const size_t got = src_->Read(iq.slice(n, slot_len_));
+                    n += got;
+                    idle = got ? 0 : idle + 1;
+                    if (idle >= 100) throw Error(HZSDR_ERR_INVALID_ARGUMENT, "multiple Read calls return no data or error");  // io.ErrNoProgress
+                }
+            } catch (...) {
+                err_ = std::current_exception();
+            }
+            n = n / block_ * block_;
+            if (n == slot_len_) {
+                if (first < 0 || full == 0) first = slot;
+                full++, done++;
+                continue;
+            }
+            flush();
+            if (n == 0) {
+                ring_->Release(slot);
+            } else {
+                ring_->Submit(slot, n);
+                inflight_++, done++;
+            }
+            return done;
         }
-        n = n / block_ * block_;
-        if (n == 0) {
-            ring_->Release(slot);
-            return false;
-        }
-        ring_->Submit(slot, n);
-        inflight_++;
-        return true;
+        flush();
+        return done;
     }
     const Context &x_;
     ReaderPtr src_;
@@ -750,7 +800,8 @@ private:
     std::vector<Stage> stages_;
     int term_ = 0;
     unsigned factor_ = 1, decimate_ = 1;
-    std::vector<std::complex<float>> filter_;
+    std::vector<std::complex<float>> filter_, taps_;
+    int slots_ = 3, group_ = 1;
     size_t block_ = 1, slot_len_ = 0;
     std::unique_ptr<Chain> chain_;
     std::unique_ptr<Ring> ring_;
@@ -807,6 +858,16 @@ struct Fused {
         if (r->SampleFormat() != HZSDR_FMT_C64) throw Error(HZSDR_ERR_FORMAT_UNKNOWN, hzsdr_strerror(HZSDR_ERR_FORMAT_UNKNOWN));
         if (auto f = fused(r, [&](ChainReader &c) { return c.extend_terminal(3, 1, filter, filter.length); })) return f;
         return stream::ConvolutionReader(x, std::move(r), filter);
+    }
+    // The north-star terminal as a Reader (BASELINE.json north_star; the reference's Downsample is the boxcar,
+    // stream/downsample.go:47-64, so name and signature follow DecimateReader's, stream/decimate.go:34): always fused --
+    // ConvertReader / ShiftReader / Gain / Multiply in front of it join its chain -- `slots` slots in the pinned ring,
+    // `group` of them per call of the chain (hzsdr_ring_submit_many: one launch of the int8 matrix kernel per group).
+    std::shared_ptr<ChainReader> FirDecimateReader(ReaderPtr in, const std::vector<std::complex<float>> &taps, unsigned factor, int slots = 5,
+                                                   int group = 4) const {
+        auto f = fused(in, [&](ChainReader &c) { return c.extend_fir(taps, factor, slots, group); });
+        if (!f) throw Error(HZSDR_ERR_INVALID_ARGUMENT, "FirDecimateReader: the stage does not fit the Reader in front of it");
+        return f;
     }
 };
 

@@ -45,6 +45,9 @@ type chainReader struct {
 	term      chainTerm
 	block     int // the stream is consumed in whole multiples of this many samples (1: any)
 
+	slots int // slots of the pinned ring (3 unless FirDecimateReader says otherwise)
+	group int // slots handed to the chain per call (hzsdr_ring_submit_many): 1, or FirDecimateReader's
+
 	ch       *Chain
 	ring     *Ring
 	slotLen  int
@@ -62,9 +65,9 @@ type chainStage struct {
 }
 
 type chainTerm struct {
-	kind     int // 0 none, 1 Decimate, 2 Downsample, 3 Convolution
+	kind     int // 0 none, 1 Decimate, 2 Downsample, 3 Convolution, 4 the north-star FIR-decimate
 	factor   uint
-	filter   []complex64
+	filter   []complex64 // kind 3: the filter's bins; kind 4: the taps
 	decimate uint
 }
 
@@ -79,7 +82,7 @@ func gcd(a, b int) int {
 func lcm(a, b int) int { return a / gcd(a, b) * b }
 
 func (s Readers) newChainReader(src sdr.Reader) *chainReader {
-	return &chainReader{s: s, src: src, srcFormat: src.SampleFormat(), rate: src.SampleRate(), block: 1}
+	return &chainReader{s: s, src: src, srcFormat: src.SampleFormat(), rate: src.SampleRate(), block: 1, slots: 3, group: 1}
 }
 
 // fused returns r as a chainReader extended by how, or nil when the stage cannot join a chain (the caller then
@@ -146,6 +149,34 @@ func (cr *chainReader) extendTerminal(t chainTerm, block int) bool {
 	return true
 }
 
+// extendFir makes the chain's terminal the north-star FIR-decimate (hzsdr_chain_fir_decimate; the reference has no such
+// Reader): the terminal converts a raw source on its way in, as DownsampleReader does.
+func (cr *chainReader) extendFir(taps []complex64, factor uint, slots, group int) bool {
+	if !cr.open() || factor == 0 {
+		return false
+	}
+	if !cr.c64Here() {
+		cr.converted = true
+	}
+	cr.term = chainTerm{kind: 4, factor: factor, filter: append([]complex64(nil), taps...)}
+	cr.block = lcm(cr.block, int(factor))
+	cr.rate /= factor
+	if slots < 2 {
+		slots = 2
+	}
+	if group < 1 {
+		group = 1
+	}
+	if group > 8 {
+		group = 8
+	}
+	if group > slots-1 {
+		group = slots - 1
+	}
+	cr.slots, cr.group = slots, group
+	return true
+}
+
 func (cr *chainReader) SampleFormat() sdr.SampleFormat {
 	if cr.c64Here() {
 		return sdr.SampleFormatC64
@@ -180,6 +211,10 @@ func (cr *chainReader) build() error {
 		err = ch.Downsample(cr.term.factor)
 	case 3:
 		err = ch.Convolution(cr.term.filter, cr.term.decimate)
+	case 4:
+		if err = ch.FIRDecimate(cr.term.filter, cr.term.factor); err == nil {
+			err = ch.Pipeline(true) // consecutive calls overlap: the ring says what each call's buffers wait for
+		}
 	}
 	if err != nil {
 		ch.Close()
@@ -196,7 +231,7 @@ func (cr *chainReader) build() error {
 	cr.slotLen = per * unit
 	var ring *Ring
 	alloc := ch.Allocator(&ring)
-	if _, err = alloc(cr.srcFormat, stream.RingBufferOptions{Slots: 3, SlotLength: cr.slotLen}); err != nil {
+	if _, err = alloc(cr.srcFormat, stream.RingBufferOptions{Slots: cr.slots, SlotLength: cr.slotLen}); err != nil {
 		ch.Close()
 		return err
 	}
@@ -204,39 +239,80 @@ func (cr *chainReader) build() error {
 	return nil
 }
 
-// fillOne reads the source into the next pinned slot and submits it; false: nothing more comes.
-func (cr *chainReader) fillOne() bool {
+// fill reads the source into up to `want` pinned slots and submits them -- the full ones together, ONE call of the
+// chain (hzsdr_ring_submit_many), a short last one (the source ended) by itself -- and returns how many it submitted
+// (0: nothing more comes). An acquired slot is submitted or released whatever happens (ADVICE r05: a failed Submit left
+// the slot acquired and every later Acquire failed); a source that keeps returning (0, nil) ends the stream with
+// io.ErrNoProgress instead of spinning.
+func (cr *chainReader) fill(want int) int {
 	if cr.err != nil {
-		return false
+		return 0
 	}
-	slot, iq, err := cr.ring.Acquire()
-	if err != nil {
-		cr.err = err
-		return false
-	}
-	n := 0
-	for n < cr.slotLen {
-		i, err := cr.src.Read(iq.Slice(n, cr.slotLen))
-		n += i
-		if err != nil {
-			if err == io.ErrUnexpectedEOF {
-				err = io.EOF
+	first, full, done := -1, 0, 0
+	flush := func() {
+		if full == 0 {
+			return
+		}
+		if err := cr.ring.SubmitMany(first, full, cr.slotLen); err != nil {
+			cr.err = err
+			// (the slots stay acquired in the ring: give the newest back first, as hzsdr_ring_release asks)
+			for k := full - 1; k >= 0; k-- {
+				_ = cr.ring.Release((first + k) % cr.slots)
 			}
+		} else {
+			cr.inflight += full
+		}
+		full = 0
+	}
+	for done < want && cr.err == nil {
+		slot, iq, err := cr.ring.Acquire()
+		if err != nil {
 			cr.err = err
 			break
 		}
+		n, idle := 0, 0
+		for n < cr.slotLen {
+			i, err := cr.src.Read(iq.Slice(n, cr.slotLen))
+			n += i
+			if err != nil {
+				if err == io.ErrUnexpectedEOF {
+					err = io.EOF
+				}
+				cr.err = err
+				break
+			}
+			if i == 0 {
+				if idle++; idle >= 100 {
+					cr.err = io.ErrNoProgress
+					break
+				}
+			} else {
+				idle = 0
+			}
+		}
+		n = n / cr.block * cr.block // a block-structured stage: whole blocks only
+		if n == cr.slotLen {
+			if full == 0 {
+				first = slot
+			}
+			full++
+			done++
+			continue
+		}
+		flush() // a short slot: everything full in front of it goes first, then it by itself (or back, if it is empty)
+		if n == 0 {
+			_ = cr.ring.Release(slot)
+		} else if err := cr.ring.Submit(slot, n); err != nil {
+			cr.err = err
+			_ = cr.ring.Release(slot)
+		} else {
+			cr.inflight++
+			done++
+		}
+		return done
 	}
-	n = n / cr.block * cr.block // a block-structured stage: whole blocks only
-	if n == 0 {
-		_ = cr.ring.Release(slot)
-		return false
-	}
-	if err := cr.ring.Submit(slot, n); err != nil {
-		cr.err = err
-		return false
-	}
-	cr.inflight++
-	return true
+	flush()
+	return done
 }
 
 func (cr *chainReader) Read(s sdr.Samples) (int, error) {
@@ -253,7 +329,19 @@ func (cr *chainReader) Read(s sdr.Samples) (int, error) {
 		cr.pending, cr.queue = cr.queue[0], cr.queue[1:]
 	}
 	if len(cr.pending) == 0 {
-		for cr.inflight < 2 && cr.fillOne() { // three slots: two in flight beside the one being handed out
+		// everything but the slot being handed out is in flight -- refilled `group` slots at a time, one call of the chain
+		// per group: a refill waits until that many slots are free, or nothing is in flight
+		for {
+			free := cr.slots - 1 - cr.inflight
+			if free < 1 || (free < cr.group && cr.inflight > 0) {
+				break
+			}
+			if free > cr.group {
+				free = cr.group
+			}
+			if cr.fill(free) == 0 {
+				break
+			}
 		}
 		if cr.inflight == 0 {
 			if cr.err != nil {

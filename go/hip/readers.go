@@ -357,6 +357,33 @@ func (s Readers) DecimateReader(in sdr.Reader, factor uint) (sdr.Reader, error) 
 	})
 }
 
+// FirDecimateReader is the north-star terminal as an sdr.Reader: an N-tap FIR at the input rate whose output is kept
+// every `factor` samples (BASELINE.json north_star; the reference has no such Reader -- its Downsample is the boxcar,
+// stream/downsample.go:47-64 -- so name and signature follow DecimateReader's, stream/decimate.go:34). Always a fused
+// Reader: ConvertReader / ShiftReader / Gain / Multiply in front of it join its chain (one kernel per call: for a
+// u8 / i8 source at factor 8 or 16 the int8 matrix kernel), `slots` slots in the pinned ring, `group` of them per call
+// of the chain (hzsdr_ring_submit_many: one launch each time). slots, group <= 0: nine slots, four per call.
+func (s Readers) FirDecimateReader(in sdr.Reader, taps []complex64, factor uint, slots, group int) (sdr.Reader, error) {
+	if len(taps) == 0 || factor == 0 {
+		return nil, fmt.Errorf("hip.FirDecimateReader: %d taps, factor %d", len(taps), factor)
+	}
+	if slots <= 0 {
+		slots = 9
+	}
+	if group <= 0 {
+		group = 4
+	}
+	how := func(c *chainReader) bool { return c.extendFir(taps, factor, slots, group) }
+	if cr, ok := in.(*chainReader); ok && how(cr) {
+		return cr, nil
+	}
+	cr := s.newChainReader(in)
+	if how(cr) {
+		return cr, nil
+	}
+	return nil, fmt.Errorf("hip.FirDecimateReader: the stage does not fit the Reader in front of it")
+}
+
 // DownsampleReader is stream.DownsampleReader: the boxcar mean of `factor` samples, c64 out.
 func (s Readers) DownsampleReader(in sdr.Reader, factor uint) (sdr.Reader, error) {
 	switch in.SampleFormat() {

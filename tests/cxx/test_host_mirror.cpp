@@ -475,6 +475,47 @@ int main() {
             EXPECT(c2 - c1 < 40 && c1 - c0 >= whole / 32768);
         }
     }
+    {  // the north-star chain as ONE Reader (stream::Fused::FirDecimateReader): ConvertReader -> ShiftReader -> 1024-tap FIR,
+       // decimate by 8, over a u8 source; nine ring slots of 2^18 samples, four per call of the chain -- against the same
+       // stream through the synchronous chain cut at the slots' boundaries, bit for bit, and far fewer library calls than slots
+        const size_t slot = (size_t)1 << 18, n = 13 * slot + 2 * 32768 + 77;  // (13 full slots, a short one, a ragged tail that is dropped)
+        const unsigned D = 8;
+        std::vector<uint8_t> u8(2 * n);
+        for (size_t i = 0; i < u8.size(); i++) u8[i] = (uint8_t)((i * 2246822519u) >> 21);
+        std::vector<c64> taps(1024);
+        for (int k = 0; k < 1024; k++) {
+            const double t = (k - 511.5) / 16.0, w = 0.54 - 0.46 * std::cos(6.283185307179586 * k / 1023.0);
+            taps[k] = c64((float)((std::fabs(t) < 1e-12 ? 1.0 : std::sin(3.141592653589793 * t) / (3.141592653589793 * t)) / 16.0 * w), 0.f);
+        }
+        const stream::Fused f{ctx, 8};  // readahead 8 blocks of 32 Ki = 2^18 samples per slot
+        auto src = std::make_shared<BufferReader>(view(HZSDR_FMT_U8, u8, 2), 20000000u, 99991);
+        auto rd = f.FirDecimateReader(f.ShiftReader(f.ConvertReader(src, HZSDR_FMT_C64), -2.5e6), taps, D, 9, 4);
+        EXPECT(rd->SampleRate() == 20000000u / D && rd->SampleFormat() == HZSDR_FMT_C64);
+        std::vector<c64> got, buf(40000);
+        const unsigned long long c0 = ctx.CallCount();
+        try {
+            for (;;) {
+                const size_t k = rd->Read(Samples{HZSDR_FMT_C64, buf.data(), buf.size()});
+                got.insert(got.end(), buf.begin(), buf.begin() + (long)k);
+            }
+        } catch (const Eof &) {
+        }
+        const unsigned long long calls = ctx.CallCount() - c0;
+        const size_t whole = (13 * slot + 2 * 32768);
+        EXPECT(got.size() == whole / D);
+        EXPECT(calls <= 14 + 8 + 12);  // 14 pops, at most 4 + 1 + 1 submits (groups of four), the chain's and the ring's construction
+        int kern = 0;
+        EXPECT(rd->chain() && hzsdr_chain_last_fir_kernel(rd->chain()->raw(), &kern) == HZSDR_OK && kern == HZSDR_FIR_KERNEL_MATRIX_PASSES);
+        stream::Chain ch(ctx, HZSDR_FMT_U8, 20000000u);
+        ch.Shift(-2.5e6).FirDecimate(taps, D);
+        std::vector<c64> ref(whole / D);
+        for (size_t a = 0; a < whole; a += slot) {
+            const size_t b = std::min(a + slot, whole);
+            const auto r = ch.Run(Samples{HZSDR_FMT_U8, u8.data() + 2 * a, b - a}, Samples{HZSDR_FMT_C64, ref.data() + a / D, (b - a) / D});
+            EXPECT(r.first == b - a && r.second == (b - a) / D);
+        }
+        EXPECT(got.size() == ref.size() && std::memcmp(got.data(), ref.data(), ref.size() * sizeof(c64)) == 0);
+    }
     std::printf(failures ? "%d FAILED\n" : "all host-mirror tests passed\n", failures);
     return failures ? 1 : 0;
 }
