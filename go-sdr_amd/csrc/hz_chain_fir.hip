@@ -370,40 +370,55 @@ static bool mm2_plan(hzsdr_chain *c, const EwProgram &P, size_t n, const void *i
     const uint64_t zero_first = 0;
     const double zero = 0.0;
     const RawCarry k0{c->rh_valid, c->rh_len, c->ts};
-    if (cb && cb->nbuf > 1) {  // (a call over several buffers: every one aligned, whole passes per buffer, the history in the last)
+    const bool batched = cb && cb->nbuf > 1;
+    if (batched) {  // (a call over several buffers: every one aligned, whole passes per buffer, the history in the last)
         if (!mm2::batch_ok(cb->n_each, c->factor, cb->nbuf) || cb->n_each < c->mmg.off) return false;
         for (size_t j = 0; j < cb->nbuf; j++)
             if ((((uintptr_t)cb->ins[j] | (uintptr_t)cb->outs[j]) & 15) != 0) return false;
+    }
+    const int nr = c->has_shift ? P.segs.n : 1;
+    uint64_t fix_total = 0;
+    bool ok = mm2_plan_piece(c, P, k0, n, c->has_shift ? P.segs.first : &zero_first, c->has_shift ? P.segs.t0 : &zero,
+                             c->has_shift ? P.segs.step : &zero, nr, L, F, &fix_total);
+    if (ok && batched) {
         // hzsdr_chain_run_batch promises the results of n_buffers hzsdr_chain_run calls, bit for bit.  What the
         // matrix path computes for an output does not depend on how the stream is cut (hz_firmm2_plan.h: run_line) --
         // but WHETHER a call takes the matrix path does (a short call that is mostly clock boundaries keeps the
         // transform kernels, other arithmetic inside the same error bound).  So the one-launch form is taken only when
-        // every buffer by itself would have taken the matrix path: the single calls are planned here, on the host
-        // (clock runs and planner, a few microseconds per buffer, no device work), and thrown away.
-        RawCarry k = k0;
-        for (size_t j = 0; j < cb->nbuf; j++) {
-            uint64_t first[kNcoMaxSegs];
-            double t0[kNcoMaxSegs], step[kNcoMaxSegs], ts_end = k.ts;
-            int nr = 1;
-            if (c->has_shift) {
-                hzsdr_nco_segment sg[kNcoMaxSegs];
-                size_t need = 0;
-                if (hzsdr_nco_segments(c->sample_rate, k.ts, cb->n_each, sg, kNcoMaxSegs, &need, &ts_end) != HZSDR_OK || need > (size_t)kNcoMaxSegs) return false;
-                nr = (int)need;
-                for (int r = 0; r < nr; r++) first[r] = sg[r].first, t0[r] = sg[r].t0, step[r] = sg[r].step;
-            } else {
-                first[0] = 0, t0[0] = 0.0, step[0] = 0.0;
+        // every buffer by itself would have taken the matrix path.  What a buffer's own plan holds is what the call's
+        // plan holds of it (the same outputs are fix-up outputs either way; an interval that spans a buffer boundary
+        // becomes two), so the call's counts bound every buffer's: if even ALL the call's fix-up outputs in one buffer
+        // would pass that buffer's checks, every buffer passes -- the common case, decided here at no cost.
+        const uint64_t out_each = cb->n_each / c->factor;
+        const int grid_each = (int)std::min<uint64_t>((uint64_t)c->ctx->num_cus, out_each / (uint64_t)mm2::pass_out((int)c->factor));
+        const bool surely = fix_total * 8 <= out_each && F->n + 1 <= mm2::kMaxFix && F->n_task + 2 <= 4 * grid_each;
+        if (!surely) {
+            // otherwise the single calls are planned here, on the host (clock runs and planner, a few microseconds per
+            // buffer, no device work), and thrown away
+            RawCarry k = k0;
+            for (size_t j = 0; j < cb->nbuf && ok; j++) {
+                uint64_t first[kNcoMaxSegs];
+                double t0[kNcoMaxSegs], step[kNcoMaxSegs], ts_end = k.ts;
+                int nrj = 1;
+                if (c->has_shift) {
+                    hzsdr_nco_segment sg[kNcoMaxSegs];
+                    size_t need = 0;
+                    if (hzsdr_nco_segments(c->sample_rate, k.ts, cb->n_each, sg, kNcoMaxSegs, &need, &ts_end) != HZSDR_OK || need > (size_t)kNcoMaxSegs) {
+                        ok = false;
+                        break;
+                    }
+                    nrj = (int)need;
+                    for (int r = 0; r < nrj; r++) first[r] = sg[r].first, t0[r] = sg[r].t0, step[r] = sg[r].step;
+                } else {
+                    first[0] = 0, t0[0] = 0.0, step[0] = 0.0;
+                }
+                mm2::Plan Lj;
+                mm2::Fix Fj;
+                if (!mm2_plan_piece(c, P, k, cb->n_each, first, t0, step, nrj, &Lj, &Fj, nullptr)) ok = false;
+                else carry_after(c, &k, cb->n_each, first, nrj, Lj.cont != 0, ts_end);
             }
-            mm2::Plan Lj;
-            mm2::Fix Fj;
-            if (!mm2_plan_piece(c, P, k, cb->n_each, first, t0, step, nr, &Lj, &Fj, nullptr)) return false;
-            carry_after(c, &k, cb->n_each, first, nr, Lj.cont != 0, ts_end);
         }
     }
-    const int nr = c->has_shift ? P.segs.n : 1;
-    uint64_t fix_total = 0;
-    const bool ok = mm2_plan_piece(c, P, k0, n, c->has_shift ? P.segs.first : &zero_first, c->has_shift ? P.segs.t0 : &zero,
-                                   c->has_shift ? P.segs.step : &zero, nr, L, F, &fix_total);
     if (c->debug_mm) {
         fprintf(stderr, "hzsdr mm2: %s: %d of %d runs on the matrix path, cont %d, %d passes, %d fix intervals (%d tasks, %llu outputs)\n",
                 ok ? "matrix path" : "transform kernels", L->n, nr, L->cont, L->n_pass, F->n, F->n_task, (unsigned long long)fix_total);

@@ -968,7 +968,10 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
 #pragma unroll
                     for (int f = 0; f < 2; f++)
 #pragma unroll
-                        for (int q = 0; q < NB; q++) {
+                        for (int qq = 0; qq < NB; qq++) {
+                            // (1 << 28: the step's MFMAs in "snake" order -- (A0,B0) (A0,B1) (A1,B1) (A1,B0): one operand
+                            // changes between neighbours -- an experiment on the operands' toggling, tools/mfma_fir2.hip AB8)
+                            const int q = ((EXP & (1 << 28)) != 0 && f == 1) ? NB - 1 - qq : qq;
                             if constexpr (kFirstC0 && SC == 0)
                                 asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(acc[f][q]) : "v"(a[sx % RG][f]), "v"(b[sx % RG][q]));
                             else

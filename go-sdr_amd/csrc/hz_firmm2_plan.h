@@ -135,7 +135,7 @@ inline bool batch_ok(uint64_t n_each, unsigned D, size_t nbuf) {
     // buffer 0, past its end; such buffers, 512 outputs each, go one by one)
     // (and a buffer of fewer than 4096 outputs does not take the matrix path by itself -- plan_call -- so a call over
     // several of them must not either: hzsdr_chain_run_batch promises the bits of single calls)
-    return ppb >= 8 && nbuf * ppb * ppb < (1ull << 32);
+    return n_each / D >= 4096 && nbuf * ppb * ppb < (1ull << 32);
 }
 inline Batch make_batch(const void *const *ins, void *const *outs, size_t nbuf, uint64_t n_each, unsigned D) {
     Batch B{};

@@ -422,7 +422,8 @@ int hzsdr_chain_shift_ulp1(hzsdr_chain *c, int on);
  * logs; the results are held to the same bound either way):
  *   HZSDR_FIR_PATH_NONE       no run yet / no FIR-decimate terminal
  *   HZSDR_FIR_PATH_TRANSFORM  overlap-save transforms (any source format, any factor)
- *   HZSDR_FIR_PATH_MATRIX     int8 matrix form (csrc/hz_firmm.h): u8 / i8 sources, factor 8, 16, 24, 32,
+ *   HZSDR_FIR_PATH_MATRIX     int8 matrix form (csrc/hz_firmm2.h: factor 8 up to ~1100 taps, 16 up to 1040; csrc/hz_firmm.h
+ *                             the rest): u8 / i8 sources, factor 8, 16, 24, 32,
  *                             40, 48 or 64, 16..1536 taps (factor 16 / 24: ..2560, larger: ..4096), default mixer order, 16-byte aligned device buffers,
  *                             at least 4096 outputs per call.  Environment HZ_FIR_FFT=1 (read when
  *                             the terminal is created) keeps a chain on the transforms. */
@@ -463,13 +464,19 @@ int hzsdr_chain_run_after(hzsdr_chain *c, const void *in, size_t n_in, void *out
                           size_t *n_consumed, size_t *n_out, void *ready_event);
 /* n_buffers (1..8) consecutive buffers of the stream, n_in samples each, in ONE call: the results, the chain's state
  * and the ordering on the context's stream are those of n_buffers hzsdr_chain_run calls in a row (outs[j]: out_cap
- * samples each; *n_consumed / *n_out: per buffer; a batch's buffers must be consumed whole).  A FIR-decimate chain
- * on the persistent-pass matrix kernel (hzsdr_chain_last_fir_kernel) whose buffers hold a whole number of 512-output
- * passes takes the batch in ONE launch -- the kernel's head, launch and tail are paid once per batch instead of once
- * per buffer: 2^24-sample buffers by four, ~30 us per buffer where single calls take ~36 -- with the mixer's phase
- * carried through the batch (outputs may differ from single calls' in the last bit; the FIR's error bound holds).
- * Every other chain runs the buffers one after the other.  _after: the START as in hzsdr_chain_run_after (all the
- * batch's buffers ready at the event).  No reference counterpart (a Reader hands over one slice per Read). */
+ * samples each; *n_consumed / *n_out: per buffer; a batch's buffers must be consumed whole) -- BIT FOR BIT: what the
+ * chain computes for a sample does not depend on how the stream was cut into calls, as stream/shifter.go:68-79's
+ * clock does not (round 6: the mixer's phase and the split between the matrix path and the reference-order fix-up
+ * outputs belong to the clock run's line in its binade, csrc/hz_firmm2_plan.h run_line; round 5's batches differed from
+ * single calls in a last bit).  A FIR-decimate chain on the persistent-pass matrix kernel
+ * (hzsdr_chain_last_fir_kernel; u8 / i8 sources at factor 8 or 16) whose buffers hold a whole number of passes (512
+ * outputs at factor 8, 256 at 16), at least eight, takes the batch in ONE launch -- the kernel's head, launch and tail
+ * are paid once per batch instead of once per buffer: 2^24-sample buffers by four, ~28-30 us per buffer where single
+ * calls take ~34-36 -- PROVIDED every buffer by itself would have taken that kernel too (a short buffer that is
+ * mostly clock boundaries keeps the transform kernels -- other arithmetic inside the same error bound -- and a call
+ * over several then runs them one by one: the single calls are planned on the host first, a few microseconds per
+ * buffer).  Every other chain runs the buffers one after the other.  _after: the START as in hzsdr_chain_run_after
+ * (all the batch's buffers ready at the event).  No reference counterpart (a Reader hands over one slice per Read). */
 int hzsdr_chain_run_batch(hzsdr_chain *c, const void *const *ins, void *const *outs, size_t n_buffers, size_t n_in,
                           size_t out_cap, size_t *n_consumed, size_t *n_out);
 int hzsdr_chain_run_batch_after(hzsdr_chain *c, const void *const *ins, void *const *outs, size_t n_buffers, size_t n_in,

@@ -323,7 +323,7 @@ int main(int argc, char **argv) {
     // the run's table (its step), and the mixer's 64-bit phase at the output -- then the two forms agree bit for bit.
     // The chain's state between calls (hz_chain_fir.hip: fir_run / mm2_plan) is restated here: the clock, and how many
     // samples of the current run the raw history holds.
-    long cut_cases = 0, cut_outputs = 0;
+    long cut_cases = 0, cut_outputs = 0, sure_cases = 0;
     for (g_case = 0; g_case < cases / 4; g_case++) {
         const uint64_t fs = rates[rnd() % (sizeof rates / sizeof rates[0])];
         const unsigned D = rnd() % 3 == 0 ? 16 : 8;
@@ -339,6 +339,8 @@ int main(int argc, char **argv) {
         }
         const double tsh = tau * 2.5e6 * (urand() - 0.5);
         struct OutInfo { uint8_t kind; double step; uint64_t phase; };
+        uint64_t pp_fix_total = 0;
+        int pp_fn = 0, pp_ntask = 0;  // (of the last piece planned)
         auto plan_piece = [&](double ts_in, uint64_t n, uint64_t back, std::vector<OutInfo> &info, double *ts_out, uint64_t *last_len, bool *last_is_run0, bool *ok) {
             std::vector<hzsdr_nco_segment> segs(4096);
             size_t need = 0;
@@ -360,7 +362,8 @@ int main(int argc, char **argv) {
             in.back = (back && mm2::continues(ts_in, t0[0], step[0])) ? (back < off ? back : off) : 0;
             mm2::Plan L;
             mm2::Fix F;
-            if (!mm2::plan_call(in, cr, &L, &F, nullptr)) return;
+            if (!mm2::plan_call(in, cr, &L, &F, &pp_fix_total)) return;
+            pp_fn = F.n, pp_ntask = F.n_task;
             *ok = true;
             info.assign(n / D, OutInfo{0, 0.0, 0});
             for (int r = 0; r < L.n; r++)
@@ -378,6 +381,11 @@ int main(int argc, char **argv) {
         if (!mm2::batch_ok(n_each, D, nbuf)) continue;
         plan_piece(ts0, n_each * nbuf, 0, big, &ts_big, &ll, &l0, &ok_big);
         if (!ok_big) continue;
+        // (hz_chain_fir.hip: mm2_plan's shortcut -- when even ALL the call's fix-up outputs in one buffer would pass that
+        // buffer's checks, every single call plans: checked below)
+        const uint64_t out_each = n_each / D;
+        const int grid_each = (int)(ppb < 256 ? ppb : 256);
+        const bool surely = pp_fix_total * 8 <= out_each && pp_fn + 1 <= mm2::kMaxFix && pp_ntask + 2 <= 4 * grid_each;
         // the single calls
         double ts = ts0;
         uint64_t rh_len = 0;
@@ -396,6 +404,8 @@ int main(int argc, char **argv) {
             ts = ts_next;
             cat.insert(cat.end(), piece.begin(), piece.end());
         }
+        REQUIRE(all_ok || !surely);
+        if (surely) sure_cases++;
         if (!all_ok) continue;
         REQUIRE(ts == ts_big && cat.size() == big.size());
         for (size_t m = 0; m < big.size(); m++) {
@@ -410,7 +420,7 @@ int main(int argc, char **argv) {
         const size_t nbuf = 1 + rnd() % 8;
         const uint64_t ppb = g_case < 64 ? 1 + (uint64_t)g_case : 1 + rnd() % 40000, n_each = ppb * 512 * 8;
         if (!mm2::batch_ok(n_each, 8, nbuf)) {
-            REQUIRE(ppb < 8 || nbuf * ppb * ppb >= (1ull << 32) || n_each * nbuf / 8 >= (1ull << 31));
+            REQUIRE(ppb * 512 < 4096 || nbuf * ppb * ppb >= (1ull << 32) || n_each * nbuf / 8 >= (1ull << 31));
             continue;
         }
         std::vector<const void *> ins(nbuf, (const void *)(uintptr_t)0x10000000);
@@ -421,7 +431,7 @@ int main(int argc, char **argv) {
         for (uint64_t p = 0; p < np; p += stride) REQUIRE((((uint64_t)(uint32_t)p * B.rcp) >> 32) == p / ppb);
         for (uint64_t j = 1; j <= nbuf; j++) REQUIRE((((j * ppb - 1) * B.rcp) >> 32) == j - 1);  // (every buffer's last pass)
     }
-    printf("plan_fuzz cuts: %ld streams planned as one call and as single calls agree output for output (%ld outputs)\n", cut_cases, cut_outputs);
+    printf("plan_fuzz cuts: %ld streams planned as one call and as single calls agree output for output (%ld outputs); %ld decided by the call's own counts\n", cut_cases, cut_outputs, sure_cases);
     printf("plan_fuzz ok: %d cases, %ld planned, %ld kept the transforms; %ld chunk plans, %ld digit tables (%ld refused the int32 plane sum)\n", cases, planned, fell_back, chunks_planned, tables, combine_refused);
     return 0;
 }

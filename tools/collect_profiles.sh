@@ -4,7 +4,7 @@
 # (FETCH_SIZE / WRITE_SIZE in separate passes), SQ wave-state counters, big-FFT timings.
 #   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r05'
 set -u
-tag=${1:-r05}
+tag=${1:-r06}
 out=gpurun_out/prof_$tag
 export TMPDIR=/tmp
 mkdir -p $out
@@ -52,6 +52,15 @@ timeout 900 python3 tools/repeat_check.py 300 > $out/repeat_check.txt 2>&1
 PIPELINE=1 timeout 900 python3 tools/repeat_check.py 200 > $out/repeat_check_pipelined_run.txt 2>&1
 BATCH=1 timeout 900 python3 tools/repeat_check.py 200 > $out/repeat_check_batch_run.txt 2>&1
 python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" > $out/firmm_probe.txt
+# round 6: per-pass stamps of the benchmarked form, the clock the chip holds (random bytes / constant input), what the chip
+# sustains of bare MFMAs by operand content and duty, the round's A/Bs, config 2 and Downsample from HBM
+(cd tools; BATCH=4 PASSES=1 ./bin/mfma_fir2 > ../$out/pass_breakdown.txt 2>&1; ZERO=1 BATCH=4 PASSES=1 ./bin/mfma_fir2 > ../$out/pass_breakdown_zero.txt 2>&1
+ for v in "" ZERO_IN=1 ZERO_TAB=1 ZERO=1; do echo "== $v"; env $v BATCH=4 PASSES=1 SPLIT=1 ./bin/mfma_fir2 2>&1 | grep "MIX\|shader clock"; done > ../$out/power_split.txt 2>&1
+ ./bin/mfma_power > ../$out/mfma_power.txt 2>&1
+ BATCH=4 AB6=1 ./bin/mfma_fir2 > ../$out/ab6_batch4.txt 2>&1; BATCH=4 AB7=1 ./bin/mfma_fir2 2>&1 | grep MIX > ../$out/ab7.txt; BATCH=8 AB6=1 ./bin/mfma_fir2 2>&1 | grep MIX > ../$out/ab6_batch8.txt)
+python3 tools/shift_time.py 2>&1 | grep -v amdgpu > $out/shift_time_final.txt
+python3 tools/downsample_time.py 2>&1 | grep -v amdgpu > $out/downsample_time_final.txt
+for d in 16; do for t in 1024 512 256; do for impl in 0 2; do PROBE_D=$d PROBE_TAPS=$t PROBE_IMPL=$impl python3 tools/firmm_probe.py 2>/dev/null | head -2; done; done; done > $out/firmm_probe_d16.txt
 for f in $out/bench_trace/*/*kernel_stats.csv $out/bench_trace_batch/*/*kernel_stats.csv $out/kern_trace/*/*kernel_stats.csv; do echo "== $f"; cut -d, -f1-4 $f | cut -c1-160 | head -14; done
 cat $out/sq_counters.txt | tail -30
 tail -3 $out/bench.err

@@ -370,6 +370,13 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
+    if (getenv("AB8")) {  // the MFMAs of a step in snake order (one operand changes between neighbours)
+        for (int r = 0; r < 5; r++) {
+            run<LIB6, 0>(in, out, taps, tab, n, ntaps, true);
+            run<LIB6 | (1 << 28), 0>(in, out, taps, tab, n, ntaps, true);
+        }
+        return 0;
+    }
     if (getenv("AB7")) {  // what the float64 plane combination costs in the benchmarked form: the same kernel with a float32 one (NOT exact: timing only)
         for (int r = 0; r < 5; r++) {
             run<LIB6, 0>(in, out, taps, tab, n, ntaps, true);
