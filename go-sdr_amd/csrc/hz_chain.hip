@@ -291,6 +291,7 @@ int hzsdr_chain_convolution(hzsdr_chain *c, const void *filter_freq, size_t filt
         return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: filter length 1 ... 2^24 (a power of two) or 1 ... 2^23 (any other)");
     if (decimate_factor == 0 || decimate_factor > kReaderBlock) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "chain: decimate factor");
     HZ_TRY(enter(ctx));
+    HZ_TRY(fft_prepare(ctx, filter_len));  // (a length that is not a power of two: its chirp tables now, not inside the first run)
     void *filt = nullptr;
     HZ_HIP(ctx, hipMalloc(&filt, filter_len * 8));
     int rc = upload_filter(ctx, filt, filter_freq, filter_len * 8);

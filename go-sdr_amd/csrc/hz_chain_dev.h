@@ -330,6 +330,14 @@ __global__ __launch_bounds__(kShiftThreads) void shift_exact_kernel(const void *
     size_t t0 = (size_t)blockIdx.x * tile;
     if (kShiftPrefetch && t0 + tile <= nvec) fetch(a, t0);  // (whole tiles only: the ragged last one goes to the queue)
     for (; t0 < nvec; t0 += hop) {
+#ifdef HZ_SHIFT_EARLY
+        // (-DHZ_SHIFT_EARLY, measured and left off: the tile's vectors asked for BEFORE the tile's clock run is looked up
+        // -- a scan of the run table and a dozen float64 instructions on the tile's bounds stand between a workgroup's
+        // start and its loads.  From HBM 49.8-50.1 us out of place against 51.0-51.2, 52.4-52.7 in place against
+        // 50.8-51.3: nothing)
+        const bool whole_early = !kShiftPrefetch && t0 + tile <= nvec;
+        if (whole_early) fetch(a, t0);
+#endif
         const uint64_t j_lo = base + 2 * t0;
         const NcoWin w = nco_window(P.segs, j_lo, j_lo + 2 * tile - 1);
         const uint64_t d0 = j_lo - nco_first(P.segs, w.lo);
@@ -348,7 +356,11 @@ __global__ __launch_bounds__(kShiftThreads) void shift_exact_kernel(const void *
         const bool more = kShiftPrefetch && t0 + hop + tile <= nvec;  // uniform
         if (more) fetch(nx, t0 + hop);
         if (__builtin_amdgcn_readfirstlane((int)straight)) {
+#ifdef HZ_SHIFT_EARLY
+            if constexpr (false) fetch(a, t0);
+#else
             if constexpr (!kShiftPrefetch) fetch(a, t0);
+#endif
             const double k0 = (double)((uint32_t)d0 + 2u * threadIdx.x);
 #pragma unroll
             for (int u = 0; u < U; u++) {

@@ -163,6 +163,7 @@ int hzsdr_convolve_freq_create(hzsdr_ctx *ctx, void *dst, size_t dst_len, const 
     if (n == 0 || !fft_length_ok(n) || !dst || !src || !freq)
         return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "convolve: 1 ... 2^24 samples (a power of two) or 1 ... 2^23 (any other length), non-null buffers");
     HZ_TRY(enter(ctx));
+    HZ_TRY(fft_prepare(ctx, n));  // (plan-time cost, like any planner: a chirp transform's tables are built here)
     void *filt = nullptr;
     HZ_HIP(ctx, hipMalloc(&filt, n * 8));
     int rc = upload_filter(ctx, filt, freq, n * 8);
@@ -185,6 +186,8 @@ int hzsdr_convolve_create(hzsdr_ctx *ctx, void *dst, size_t dst_len, const void 
     if (n == 0 || !fft_length_ok(n) || !dst || !iq1 || !iq2)
         return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "convolve: 1 ... 2^24 samples (a power of two) or 1 ... 2^23 (any other length), non-null buffers");
     if (mode != HZSDR_CONV_CONVOLVE && mode != HZSDR_CONV_CROSS_CORRELATE) return HZSDR_ERR_INVALID_ARGUMENT;
+    HZ_TRY(enter(ctx));
+    HZ_TRY(fft_prepare(ctx, n));  // (plan-time cost: a chirp transform's tables are built here, not inside the first exec)
     *out = new hzsdr_conv{ctx, mode == HZSDR_CONV_CONVOLVE ? 1 : 2, dst, iq1, iq2, n, nullptr};
     return HZSDR_OK;
 }

@@ -546,7 +546,9 @@ static int get_bluestein(hzsdr_ctx *ctx, size_t n, Bluestein *out) {
     size_t m = 1;
     while (m < 2 * n - 1) m <<= 1;
     out->m = m;
-    // (keys: the plain tables use n, the big twiddles 2 n + 1, the packed core's tables their own high bits)
+    // (keys of ctx->twiddles: the plain tables use n, the big twiddles 2 n + 1 -- both below 2^26 --, the packed core's
+    // tables and this one a tag in bits 48 and up: disjoint by construction)
+    static_assert(kBluesteinMax < ((size_t)1 << 40), "the length must stay below the key's tag");
     const size_t key = ((size_t)0xB1 << 48) | n;
     auto it = ctx->twiddles.find(key);
     if (it != ctx->twiddles.end()) {
@@ -622,6 +624,14 @@ __global__ __launch_bounds__(kThreads) void blue_post_kernel(const float2 *__res
 }
 
 int fft_device(hzsdr_ctx *ctx, const void *in, void *out, size_t n, size_t batch, bool fwd);
+
+int fft_prepare(hzsdr_ctx *ctx, size_t n) {
+    if (n <= 1 || !fft_length_ok(n)) return HZSDR_OK;
+    if ((n & (n - 1)) == 0) return HZSDR_OK;  // (powers of two: their tables are small and formed where they are first used)
+    Bluestein bl{};
+    HZ_TRY(get_bluestein(ctx, n, &bl));
+    return fft_prepare(ctx, bl.m);
+}
 
 static int fft_bluestein(hzsdr_ctx *ctx, const float2 *in, float2 *out, size_t n, size_t batch, bool fwd) {
     if (n > kBluesteinMax) return fail(ctx, HZSDR_ERR_INVALID_ARGUMENT, "fft: a length that is not a power of two must be <= 2^23");

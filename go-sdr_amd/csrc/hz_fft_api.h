@@ -18,6 +18,11 @@ int get_fv_poly_tables(hzsdr_ctx *ctx, size_t n, unsigned fold, fv::PolyTabs *ou
 // `batch` consecutive length-n transforms, device pointers, any length (powers of two directly, others by Bluestein's
 // chirp transform over them: scratch slots 12 and 13).
 int fft_device(hzsdr_ctx *ctx, const void *in, void *out, size_t n, size_t batch, bool fwd);
+// Everything fft_device(.., n, ..) would otherwise build on its first call for a length -- for a length that is not
+// a power of two the chirp and its spectrum: ~50 n bytes of host vectors, a float64 transform of M >= 2n - 1 points
+// on the host, a blocking upload; seconds at n ~ 2^23 -- built NOW: called where a chain, a convolution closure or a
+// plan is created, so that no call on the data path stalls for it.
+int fft_prepare(hzsdr_ctx *ctx, size_t n);
 // f1 *= f2 (or conj(f2)) with Go complex64 multiply semantics.
 void pointwise_mul_device(hzsdr_ctx *ctx, void *f1, const void *f2, size_t n, bool conj);
 // the same over nblocks blocks of `period` values each against ONE f2 of `period` values
