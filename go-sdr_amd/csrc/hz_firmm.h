@@ -92,13 +92,18 @@ __device__ __forceinline__ int find_le(const int *tab, int n, int key) {
 }
 
 // One post-elementwise sample in reference order: position p of the buffer (p < 0: history).
-template <int FMT>
+// LATE: the Shift's Sincos flavour (ew_apply_n: 1 = sincos_late, 2 = sincos_turns32).  The persistent-pass kernel's
+// history (hz_firmm2.h) is formed with 2, the flavour its fix-up tasks stage their windows with: a task that reads a
+// sample from the history then gets the bits it would have computed from the previous buffer's bytes itself -- which is
+// what a call over several buffers does (round 6: a batch equals single calls bit for bit; with 1 the first forty
+// outputs of a buffer that starts less than a window behind a clock boundary differed in the last place).
+template <int FMT, int LATE = 1>
 __device__ __forceinline__ float2 ordered_sample(const void *in, const EwProgram &P, int64_t p, const float2 *hist,
                                                  unsigned off, NcoWin w) {
     using R = typename Raw<FMT>::t;
     if (p < 0) return hist ? hist[p + (int64_t)off] : make_float2(0.f, 0.f);
     float2 v[1] = {Raw<FMT>::cvt(((const R *)in)[p])};
-    ew_apply_n<1, true>(P, v, (uint64_t)p, w);
+    ew_apply_n<1, LATE>(P, v, (uint64_t)p, w);
     return v[0];
 }
 

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kThreads) void fir_mm2_kernel(
             const NcoWin tw = task_window(P, h_lo, h_lo + kHistPer - 1);
             if (idx < G.off) {
                 const int64_t p = (int64_t)n_in - (int64_t)G.off + idx;
-                new_hist[idx] = mm::ordered_sample<FMT>(in, P, p, hist, G.off, tw);
+                new_hist[idx] = mm::ordered_sample<FMT, 2>(in, P, p, hist, G.off, tw);  // (the tasks' own Sincos flavour: hz_firmm.h)
                 reinterpret_cast<RWT *>(new_rhist)[idx] = p >= 0 ? ((const RWT *)in)[p] : reinterpret_cast<const RWT *>(rhist)[p + (int64_t)G.off];
             }
         }

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64) void history_kernel(const void *__restrict__ in
     const NcoWin tw = mm::task_window(P, h_lo, h_lo + 63);
     if (idx < off) {
         const int64_t p = (int64_t)n_in - (int64_t)off + idx;
-        new_hist[idx] = mm::ordered_sample<FMT>(in, P, p, nullptr, off, tw);
+        new_hist[idx] = mm::ordered_sample<FMT, 2>(in, P, p, nullptr, off, tw);
         reinterpret_cast<RWT *>(new_rhist)[idx] = ((const RWT *)in)[p];
     }
 }

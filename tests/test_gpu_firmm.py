@@ -683,6 +683,68 @@ def test_run_batch_of_very_short_buffers(hz, nbuf, n):
     ctx.close()
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("HZ_FUZZ_SEEDS", "32"))))
+def test_batches_equal_single_calls_on_random_streams(hz, seed):
+    """hzsdr_chain_run_batch against the same buffers through hzsdr_chain_run, bit for bit, on random streams: sample
+    rate (incl. a power-of-two one, whose clock steps never change), factor 8 / 16, 16 ... 1040 taps, 2 ... 8 buffers of
+    16 ... 48 passes, one to three elementwise stages, the clock started a random distance in front of a binade edge or
+    of the 2 pi wrap -- so that clock boundaries fall a few samples to a few thousand in front of, behind and onto
+    buffer boundaries (round 6 found the one case the directed tests had missed that way: a boundary less than a window
+    in front of a buffer's start, where the fix-up outputs read the history a single call keeps and a batch recomputes)
+    -- plain and overlapped, two calls in a row.  Whatever path each form takes, the bits must agree."""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    fs = int(rng.choice([2_400_000, 8_000_000, 20_000_000, 1_048_576, 200_000_000]))
+    D = int(rng.choice([8, 16]))
+    ntaps = int(rng.integers(16, 1041))
+    taps = taps_for(ntaps, 1 / (2 * D), float(rng.uniform(-0.3, 0.3)))
+    pass_out = 512 if D == 8 else 256
+    ppb = int(rng.integers(4096 // pass_out, 49))
+    n = ppb * pass_out * D
+    nbuf = int(rng.integers(2, 9))
+    piped = bool(rng.integers(0, 2))
+    total = 2 * nbuf
+    # the clock: a boundary (a binade edge or the wrap) somewhere in the stream, offset by anything from 0 to a few windows
+    edge = TAU if rng.integers(0, 2) else float(2.0 ** -int(rng.integers(0, 8)))
+    into = int(rng.integers(0, total * n))                       # the boundary falls `into` samples into the stream ...
+    if rng.integers(0, 2):                                       # ... or right around a buffer boundary
+        into = int(rng.integers(1, total)) * n + int(rng.integers(-3 * ntaps, 3 * ntaps))
+    ts0 = edge - into / fs
+    while ts0 < 0.0:
+        ts0 += TAU
+    ops = [("shift", float(rng.uniform(-0.4, 0.4)) * fs)]
+    if rng.integers(0, 3) == 0:
+        ops.append(("gain", 0.5))
+    if rng.integers(0, 4) == 0:
+        ops.insert(0, ("rotate", 0.6 - 0.8j))
+    x = rand_u8(5000 + seed, n * total)
+    xs = [torch.from_numpy(x[j * n:(j + 1) * n]).cuda() for j in range(total)]
+    ctx = hz.Context(0, hz.MEM_DEVICE, stream=torch.cuda.Stream().cuda_stream)
+    outs, clocks = [], []
+    for form in ("single", "batch"):
+        ch = build(hz, ctx, hz.FMT_U8, fs, ops, taps, D)
+        if piped and form == "batch":
+            ch.pipeline(True)
+        ch.set_time(ts0)
+        ys = [torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(total)]
+        torch.cuda.synchronize()
+        if form == "single":
+            for j in range(total):
+                assert ch.run(xs[j], ys[j]) == (n, n // D)
+        else:
+            for j in range(0, total, nbuf):
+                assert ch.run_batch(xs[j:j + nbuf], ys[j:j + nbuf], after=piped) == (n, n // D)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        outs.append(np.concatenate([y.cpu().numpy() for y in ys]))
+        clocks.append(ch.time())
+        ch.close()
+    ctx.close()
+    assert clocks[0] == clocks[1]
+    bad = np.nonzero(outs[0].view(np.int64) != outs[1].view(np.int64))[0]
+    assert len(bad) == 0, (len(bad), bad[:8], dict(fs=fs, D=D, ntaps=ntaps, n=n, nbuf=nbuf, piped=piped, ts0=ts0, ops=ops))
+
+
 def test_run_batch_other_chains_and_errors(hz):
     """A chain without a one-launch form takes a batch buffer by buffer: the same bits as single calls (Shift + Gain map,
     a c64 FIR on the transform kernels, HOST space).  Argument errors: 0 or 9 buffers, a short output, ragged buffers."""

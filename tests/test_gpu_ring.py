@@ -172,6 +172,47 @@ def test_ring_submit_many_is_one_call_per_group(hz, ctx, orc, kind, group):
     ref_chain.close()
 
 
+@pytest.mark.parametrize("piped", [False, True])
+def test_ring_submit_many_of_slots_that_do_not_qualify_goes_slot_by_slot(hz, ctx, piped):
+    """Slots of 2^16 samples across the 2 pi wrap: the slot that holds the wrap is mostly fix-up outputs and keeps the
+    transform kernels when it runs by itself, so a call over several slots must not take it into one launch of the matrix
+    kernel either (hzsdr_chain_run_batch promises the bits of single calls): hzsdr_ring_submit_many falls back to one
+    launch per slot -- overlapped where the chain is pipelined -- and the outputs equal the synchronous chain's bit for
+    bit."""
+    TAU = 6.283185307179586476925286766559
+    slot_len, slots, group, trips = 1 << 16, 9, 4, 12
+    chain, gen, D = build(hz, ctx, "u8_fir8")
+    if piped:
+        chain.pipeline(True)
+    ref_chain, _, _ = build(hz, ctx, "u8_fir8")
+    data = gen(47, slot_len * trips)
+    ts0 = TAU - 0.004  # (the wrap 80 000 samples in: slot 1)
+    chain.set_time(ts0), ref_chain.set_time(ts0)
+    want = np.zeros(slot_len * trips // D, np.complex64)
+    kinds = []
+    for t in range(trips):
+        assert ref_chain.run(data[t * slot_len:(t + 1) * slot_len], want[t * slot_len // D:(t + 1) * slot_len // D]) == (slot_len, slot_len // D)
+        kinds.append(ref_chain.last_fir_path())
+    assert hz.FIR_PATH_TRANSFORM in kinds and hz.FIR_PATH_MATRIX in kinds  # (the stream meets both implementations)
+    ring = chain.ring(slot_len, slots)
+    got = []
+    for t in range(0, trips, group):
+        first = None
+        for j in range(group):
+            slot, iq = ring.acquire()
+            first = slot if first is None else first
+            iq[:] = data[(t + j) * slot_len:(t + j + 1) * slot_len]
+        ring.submit_many(first, group)
+        for _ in range(group):
+            got.append(ring.pop().copy())
+    got = np.concatenate(got)
+    assert bits_equal(got, want), int((got.view(np.int64) != want.view(np.int64)).sum())
+    assert chain.time() == ref_chain.time()
+    ring.close()
+    chain.close()
+    ref_chain.close()
+
+
 def test_fir_decimate_reader_is_the_north_star_chain_as_one_reader(hz, orc):
     """Stream.fir_decimate_reader(ShiftReader(ConvertReader(u8 source))): the north-star chain behind sdr.Reader --
     ONE chain (the int8 matrix kernel), a pinned ring that reads ahead, four slots per launch.  Against the oracle
