@@ -740,8 +740,23 @@ def main():
             bf = np.zeros(nb * n, np.complex64)
             orc.par_u8_to_c64(xf, bf, threads)
             ts_want = orc.par_shift_gain(ts1, fs, shift, 1.0, bf, threads)  # (gain 1.0: the Shift alone)
+            # (every output where the host has the cores for it -- 2 s on the 256-core boxes of this pool; on a small host
+            # the first, middle and last 2^16 outputs of every buffer: each slice filtered from 1024 samples in front of it)
+            check_all = threads >= 48 and not os.environ.get("HZ_BENCH_SLICE_PARITY")
             wantf = np.zeros(nb * n // D, np.complex64)
-            orc.par_fir_decimate_f64(wantf, bf, taps, D)
+            slices = []
+            if check_all:
+                orc.par_fir_decimate_f64(wantf, bf, taps, D)
+            else:
+                no, cnt, lead = n // D, min(1 << 16, n // D), (ntaps + D - 1) // D
+                for j in range(nb):
+                    for m0 in sorted({j * no, j * no + (no - cnt) // 2, j * no + no - cnt}):
+                        a = max(0, m0 - lead)
+                        tmp = np.zeros(m0 + cnt - a, np.complex64)
+                        orc.par_fir_decimate_f64(tmp, bf[a * D:(m0 + cnt) * D], taps, D)
+                        if a > 0 or m0 == 0:  # (outputs whose window reaches in front of the slice's samples are dropped; the stream's first are whole)
+                            wantf[m0:m0 + cnt] = tmp[m0 - a:]
+                            slices.append((m0, m0 + cnt))
             xmaxf = float(np.abs(bf[:1 << 20]).max())
             del bf
             xg = [torch.from_numpy(xf[j * n:(j + 1) * n]).cuda() for j in range(nb)]
@@ -759,21 +774,31 @@ def main():
             torch.cuda.synchronize()
             boundf = 6e-7 * float(np.abs(taps).sum()) * xmaxf
             per_buf = []
+            checked = 0
             for j in range(nb):
                 g = yg[j].cpu().numpy().astype(np.complex128)
                 w = wantf[j * (n // D):(j + 1) * (n // D)]
+                if not check_all:  # (the slices of this buffer)
+                    keep = np.zeros(n // D, bool)
+                    for a, b in slices:
+                        lo, hi = max(a, j * (n // D)) - j * (n // D), min(b, (j + 1) * (n // D)) - j * (n // D)
+                        if lo < hi:
+                            keep[lo:hi] = True
+                    g, w = g[keep], w[keep]
+                checked += len(w)
                 per_buf.append((float(np.abs(g - w).max()), float(np.linalg.norm(g - w) / np.linalg.norm(w.astype(np.complex128)))))
             ok_full = bool(all(e <= boundf and r <= 3e-7 for e, r in per_buf) and chk.time() == ts_want
                            and all(kq == hz.FIR_KERNEL_MATRIX_PASSES for kq in kernels))
             result["parity"]["timed_form"] = {
                 "calls": nb // B, "buffers_per_call": B, "samples_per_buffer": n, "overlapped": bool(piped),
-                "checked_outputs": nb * n // D, "max_abs_err": max(e for e, _ in per_buf), "bound": boundf,
+                "checked_outputs": checked, "checked": "every output" if check_all else "the first, middle and last 2^16 outputs of every buffer",
+                "max_abs_err": max(e for e, _ in per_buf), "bound": boundf,
                 "rel_l2_err_worst_buffer": max(r for _, r in per_buf), "rel_l2_bound": 3e-7, "clock_start": ts1,
                 "clock_after_equal": bool(chk.time() == ts_want), "one_launch_per_call": bool(all(kq == hz.FIR_KERNEL_MATRIX_PASSES for kq in kernels)),
                 "ok": ok_full,
                 "what": "the benchmarked entry point at the benchmarked size: every output of two consecutive calls over "
                         "separately allocated buffers (the 2*pi wrap inside the first) against the oracle, per buffer"}
-            result["parity"]["checked_outputs"] += nb * n // D
+            result["parity"]["checked_outputs"] += checked
             result["parity"]["ok"] = parity_ok = bool(parity_ok and ok_full)
             chk.close()
             del xg, yg, wantf
