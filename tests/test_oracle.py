@@ -295,6 +295,33 @@ def test_go_sincos_table_and_accuracy(orc):
     assert c0.tolist() == [1.0, 1.0] and np.signbit(s0).tolist() == [False, True]
 
 
+def test_go_sincos_against_the_go_math_packages_own_vectors(orc):
+    """math.Sincos is not under the reference tree (Go's standard library: SURVEY.md 8c (ii)), but the library that
+    holds it publishes the vectors it is tested with: src/math/all_test.go's vf / sin / cos, held with `veryclose`
+    (relative 4e-16).  The oracle's restatement passes Go's own test; mod 2 pi, with Go's tenfold arguments too
+    (TestSincos also runs vf[i] * 10 against the same function: here against a 40-digit evaluation)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "go_math_sincos_kats.json")) as f:
+        k = json.load(f)
+    vf = np.array(k["vf"], np.float64)
+    s, c = orc.go_sincos(vf)
+    tol = k["tolerance_relative"]
+    for i in range(len(vf)):
+        ws, wc = float(k["sin"][i]), float(k["cos"][i])
+        assert abs(s[i] - ws) <= tol * abs(ws), (i, s[i], ws)
+        assert abs(c[i] - wc) <= tol * abs(wc), (i, c[i], wc)
+    try:
+        import mpmath as mp
+    except ImportError:
+        return
+    mp.mp.dps = 40
+    s10, c10 = orc.go_sincos(vf * 10)
+    for i in range(len(vf)):
+        ws, wc = mp.sin(mp.mpf(float(vf[i] * 10))), mp.cos(mp.mpf(float(vf[i] * 10)))
+        assert abs(mp.mpf(float(s10[i])) - ws) <= tol * abs(ws) and abs(mp.mpf(float(c10[i])) - wc) <= tol * abs(wc), i
+
+
 def test_sincos_narrow_never_accepts_a_pair_that_differs_from_math_sincos(orc):
     """The straight path of shift_exact_kernel (csrc/hz_device.h sincos_narrow, restated in the oracle): wherever its
     check on the float64 bits accepts, the float32 pair IS complex64(math.Sincos(x)) -- over random phases of every
