@@ -198,6 +198,139 @@ template <int BURST, int SLEEP, int READS> static void run_lds(unsigned long lon
            mode == 3 ? "random bytes" : "zeros       ", BURST, SLEEP, ms * 1e3, ghz[waves / 2], ns_per, mfma_per_simd * 32.0 / (ghz[waves / 2] * 1e9 * ms * 1e-3), 1024.0 * 65536.0 / ns_per * 1e-6);
 }
 
+// v_mfma_i32_16x16x64_i8 (half the multiply-adds per instruction, a quarter of the accumulators): what does THIS shape
+// sustain on random operands?
+template <int BURST, int SLEEP>
+__global__ __launch_bounds__(512) void k16(unsigned long long *out, int trips, int mode, int *sink) {
+    const unsigned tid = threadIdx.x + blockIdx.x * 512u;
+    v4i a[4], b[4];
+    for (int i = 0; i < 4; i++) {
+        unsigned h = (tid * 2654435761u) ^ (0x9E3779B9u * (i + 1));
+        auto nx = [&]() { h ^= h << 13; h ^= h >> 17; h ^= h << 5; return (int)h; };
+        a[i] = (mode & 1) ? v4i{nx(), nx(), nx(), nx()} : v4i{0, 0, 0, 0};
+        b[i] = (mode & 2) ? v4i{nx(), nx(), nx(), nx()} : v4i{0, 0, 0, 0};
+    }
+    v4i c[8];
+    for (int i = 0; i < 8; i++) c[i] = v4i{0, 0, 0, 0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+    for (int t = 0; t < trips; t++) {
+#pragma unroll
+        for (int m = 0; m < BURST; m++) c[m & 7] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[(m + (m >> 2)) & 3], b[(m >> 1) & 3], c[m & 7], 0, 0, 0);
+        if constexpr (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    int s = 0;
+    for (int i = 0; i < 8; i++) s += c[i][0] + c[i][1] + c[i][2] + c[i][3];
+    if (s == 0x12345678) *sink = s;
+    if ((threadIdx.x & 63) == 0) {
+        out[2 * (tid >> 6)] = t1 - t0;
+        out[2 * (tid >> 6) + 1] = r1 - r0;
+    }
+}
+// ... and with its operands read from LDS in the blocking a FIR pass would use: four A fragments (the four digit planes of
+// eight outputs) x four B fragments (four column blocks of sixteen tiles) = sixteen accumulators of four registers,
+// eight ds_read_b128 per sixteen MFMAs -- the same LDS bytes per multiply-add as the 32x32x32 loop's two by two.
+template <int STEPS, int SLEEP>
+__global__ __launch_bounds__(512) void kl16(unsigned long long *out, int trips, int mode, int *sink) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
+    const unsigned tid = threadIdx.x + blockIdx.x * 512u;
+    {
+        unsigned h = tid * 2654435761u + 12345u;
+        for (int i = threadIdx.x; i < 65536 / 4; i += 512) {
+            h ^= h << 13, h ^= h >> 17, h ^= h << 5;
+            reinterpret_cast<unsigned *>(lds)[i] = mode == 3 ? h : 0u;
+        }
+    }
+    __syncthreads();
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned char *base = lds + wave * 8192 + lane * 16;
+    v4i a[2][4], b[2][4];
+    for (int i = 0; i < 4; i++) a[0][i] = *reinterpret_cast<const v4i *>(base + 1024 * i), b[0][i] = *reinterpret_cast<const v4i *>(base + 1024 * (i + 4));
+    v4i c[4][4];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) c[i][j] = v4i{0, 0, 0, 0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned off = 0;
+#pragma unroll 1
+    for (int t = 0; t < trips; t++) {
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            const int cur = s & 1, nxt = cur ^ 1;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    c[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[cur][i], b[cur][j], c[i][j], 0, 0, 0);
+                    // (the next step's fragments, one read per two MFMAs)
+                    if (j == 0) a[nxt][i] = *reinterpret_cast<const v4i *>(base + ((off + 1024 * i) & 7168));
+                    if (j == 2) b[nxt][i] = *reinterpret_cast<const v4i *>(base + ((off + 1024 * (i + 4)) & 7168));
+                }
+            }
+            off += 3072;
+        }
+        if constexpr (SLEEP > 0) __builtin_amdgcn_s_sleep(SLEEP);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    int sacc = 0;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) sacc += c[i][j][0] + c[i][j][1] + c[i][j][2] + c[i][j][3];
+    if (sacc == 0x12345678) *sink = sacc;
+    if ((threadIdx.x & 63) == 0) {
+        out[2 * (tid >> 6)] = t1 - t0;
+        out[2 * (tid >> 6) + 1] = r1 - r0;
+    }
+}
+template <int STEPS, int SLEEP> static void run_lds16(unsigned long long *dout, int *sink, int mode, double target_us) {
+    const int grid = 256, waves = grid * 8;
+    const int trips = (int)(target_us * 1500.0 / (2.0 * STEPS * 16 * 16.0)) + 1;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int rep = 0; rep < 3; rep++) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((kl16<STEPS, SLEEP>), dim3(grid), dim3(512), 0, 0, dout, trips, mode, sink);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    std::vector<unsigned long long> h(2 * waves);
+    CK(hipMemcpy(h.data(), dout, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> ghz;
+    for (int w = 0; w < waves; w++) ghz.push_back((double)h[2 * w] / (double)h[2 * w + 1] / 10.0);
+    std::sort(ghz.begin(), ghz.end());
+    const double mfma_per_simd = 2.0 * (double)trips * STEPS * 16;
+    const double ns_per = ms * 1e6 / mfma_per_simd;
+    printf("  v_mfma_i32_16x16x64_i8, 4 x 4 fragments from LDS (8 reads per 16 MFMAs), %s, sleep %2d: %7.1f us  clock %.3f GHz  %.2f ns per MFMA per SIMD (%.1f cycles)  chip %.2f Pop/s\n",
+           mode == 3 ? "random bytes" : "zeros       ", SLEEP, ms * 1e3, ghz[waves / 2], ns_per, ns_per * ghz[waves / 2], 1024.0 * 32768.0 / ns_per * 1e-6);
+}
+
+template <int BURST, int SLEEP> static void run16(unsigned long long *dout, int *sink, int mode, double target_us) {
+    const int grid = 256, waves = grid * 8;
+    const int trips = (int)(target_us * 1500.0 / (2.0 * BURST * 16.0)) + 1;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float ms = 0;
+    for (int rep = 0; rep < 3; rep++) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((k16<BURST, SLEEP>), dim3(grid), dim3(512), 0, 0, dout, trips, mode, sink);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+    }
+    std::vector<unsigned long long> h(2 * waves);
+    CK(hipMemcpy(h.data(), dout, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> ghz;
+    for (int w = 0; w < waves; w++) ghz.push_back((double)h[2 * w] / (double)h[2 * w + 1] / 10.0);
+    std::sort(ghz.begin(), ghz.end());
+    const double mfma_per_simd = 2.0 * (double)trips * BURST;
+    const double ns_per = ms * 1e6 / mfma_per_simd;
+    printf("  v_mfma_i32_16x16x64_i8, %s, burst %3d sleep %3d: %7.1f us  clock %.3f GHz  %.2f ns per MFMA per SIMD (%.1f cycles)  chip %.2f Pop/s\n",
+           mode == 3 ? "A random, B random" : "zeros             ", BURST, SLEEP, ms * 1e3, ghz[waves / 2], ns_per, ns_per * ghz[waves / 2], 1024.0 * 32768.0 / ns_per * 1e-6);
+}
+
 template <int BURST, int SLEEP> static void run(unsigned long long *dout, int *sink, int mode, double target_us) {
     const int grid = 256, waves = grid * 8;
     // trips for ~target_us: a burst is BURST x 32 cycles per wave, two waves share a SIMD
@@ -274,6 +407,18 @@ int main(int argc, char **argv) {
         run_pass<0, 0>(dout, sink, big, big_n, us);
         CK(hipFree(big));
     }
+    printf("the other int8 shape:\n");
+    run16<32, 0>(dout, sink, 0, us);
+    run16<32, 0>(dout, sink, 3, us);
+    run16<32, 8>(dout, sink, 3, us);
+    run<16, 0>(dout, sink, 3, us);
+    for (int rep = 0; rep < 2; rep++) {
+        run_lds16<4, 0>(dout, sink, 3, us);
+        run_lds<16, 0, 4>(dout, sink, 3, us);
+        run_lds16<4, 4>(dout, sink, 3, us);
+        run_lds<16, 4, 4>(dout, sink, 3, us);
+    }
+    run_lds16<4, 0>(dout, sink, 0, us);
     printf("long launches (4 ms), both operands random:\n");
     run<16, 0>(dout, sink, 3, 4000.0);
     run<16, 12>(dout, sink, 3, 4000.0);
