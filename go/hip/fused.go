@@ -249,20 +249,27 @@ func (cr *chainReader) fill(want int) int {
 		return 0
 	}
 	first, full, done := -1, 0, 0
-	flush := func() {
+	// flush submits the full slots gathered so far as one call. `newer`: a slot acquired behind them that is still
+	// acquired (-1: none) -- on failure every acquired slot goes back, the newest first, as hzsdr_ring_release asks.
+	flush := func(newer int) bool {
 		if full == 0 {
-			return
+			return true
 		}
-		if err := cr.ring.SubmitMany(first, full, cr.slotLen); err != nil {
+		err := cr.ring.SubmitMany(first, full, cr.slotLen)
+		if err != nil {
 			cr.err = err
-			// (the slots stay acquired in the ring: give the newest back first, as hzsdr_ring_release asks)
+			if newer >= 0 {
+				_ = cr.ring.Release(newer)
+			}
 			for k := full - 1; k >= 0; k-- {
 				_ = cr.ring.Release((first + k) % cr.slots)
 			}
+			done -= full
 		} else {
 			cr.inflight += full
 		}
 		full = 0
+		return err == nil
 	}
 	for done < want && cr.err == nil {
 		slot, iq, err := cr.ring.Acquire()
@@ -299,7 +306,10 @@ func (cr *chainReader) fill(want int) int {
 			done++
 			continue
 		}
-		flush() // a short slot: everything full in front of it goes first, then it by itself (or back, if it is empty)
+		// a short slot: everything full in front of it goes first, then it by itself (or back, if it is empty)
+		if !flush(slot) {
+			return done
+		}
 		if n == 0 {
 			_ = cr.ring.Release(slot)
 		} else if err := cr.ring.Submit(slot, n); err != nil {
@@ -311,7 +321,7 @@ func (cr *chainReader) fill(want int) int {
 		}
 		return done
 	}
-	flush()
+	flush(-1)
 	return done
 }
 
