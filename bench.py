@@ -203,6 +203,8 @@ def main():
     # ---- the headline step: fused north-star chain ---------------------------------
     nbuf = max(1, args.buffers)
     xs = [torch.from_numpy(synth_u8(9 + rank + 101 * i, n)).cuda() for i in range(nbuf)]
+    if os.environ.get("HZ_BENCH_CONSTANT_INPUT") == "1":  # (tools/power_watch.sh only: NOT the benchmark -- the line says so)
+        xs = [torch.full((n, 2), 0x80, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
     B = max(1, min(8, args.batch, nbuf))
     # (outputs: two calls' worth in rotation -- an overlapped call must not write what the call before it writes)
     ys = [torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(max(4, 2 * B))]
@@ -385,7 +387,9 @@ def main():
         "vs_baseline": None,
         "dtype": "u8 x int32 fixed-point taps (int8 MFMA digit planes, exact) -> c64(f32), NCO phase 64-bit fixed point"
                  if matrix else "u8->c64(f32), NCO phase f64",
-        "data": f"synthetic (splitmix64 u8 IQ, seeds 9+rank+101i; {nbuf} distinct buffers in rotation, "
+        "data": ("DIAGNOSTIC RUN, NOT THE BENCHMARK: constant input (HZ_BENCH_CONSTANT_INPUT=1, tools/power_watch.sh); "
+                 if os.environ.get("HZ_BENCH_CONSTANT_INPUT") == "1" else "")
+                + f"synthetic (splitmix64 u8 IQ, seeds 9+rank+101i; {nbuf} distinct buffers in rotation, "
                 f"{nbuf * 2 * n >> 20} MiB resident in HBM); windowed-sinc taps",
         "config": {
             "workload": ("north-star chain: u8->c64->Shift(-fs/8)->1024-tap FIR->decimate-by-8, one "
