@@ -321,29 +321,97 @@ __device__ __forceinline__ float2 big_twiddle(const BigTw &t, uint32_t m, bool i
 // register slot then sit 32 KB apart and the slots of all workgroups hit the same channels together); two adjacent
 // columns per lane, 16-byte loads and stores, 256-byte pieces, the two transforms one behind the other through the
 // same LDS (tools/fftbig_time.py: 120.8 us for both passes against 111.3 -- worse as well).)
+// Which tile a workgroup takes.  The dispatcher deals a launch's workgroups to the eight XCDs in turn (linear index
+// mod 8), and a tile's global pieces sit at (tile index) * 128 bytes modulo the row pitch: taken in launch order, the
+// workgroups of ONE XCD would touch only the pieces whose index is congruent to that XCD's number -- the same few
+// address bits, that XCD's same few L2 channels and fabric links, for the whole launch.  Instead every XCD walks its
+// own CONTIGUOUS eighth of the launch's tiles (transforms and all).  A launch whose tile count is no multiple of eight
+// keeps the launch order.
+#ifndef HZ_FFT2_XCD
+#define HZ_FFT2_XCD 1
+#endif
+#ifndef HZ_FFT2_ABL
+#define HZ_FFT2_ABL 0  // timing ablations of the column pass (wrong results): 1 no big twiddle, 2 contiguous reads, 4 contiguous writes, 8 no transform
+#endif
+__device__ __forceinline__ void fft2_tile(uint32_t &bx, uint32_t &by) {
+    bx = blockIdx.x, by = blockIdx.y;
+    if constexpr (HZ_FFT2_XCD != 0) {
+        const uint32_t total = gridDim.x * gridDim.y;
+        if (total & 7u) return;
+        const uint32_t w = blockIdx.x + gridDim.x * blockIdx.y, g = (w & 7u) * (total >> 3) + (w >> 3);
+        bx = g % gridDim.x, by = g / gridDim.x;
+    }
+}
+
 template <int N1, bool FWD>
 __global__ __launch_bounds__(256) void fft2_cols_kernel(const float2 *__restrict__ in, float2 *__restrict__ a_out,
                                                         fv::FvTabs tabs, BigTw bt, uint32_t n2_total) {
     using fv::cf;
     constexpr int C = 4096 / N1, TPT = fv::tpt(N1), R0 = fv::first_radix(N1);
     static_assert(C * TPT == 256, "one 256-lane workgroup per column tile");
-    __shared__ cf lds_all[C * fv::lds_elems(N1)];
+    // A wave holds 64 / C lanes of each of its C columns: the columns' LDS regions sit 64 / C elements (mod 32) apart,
+    // so that one LDS instruction's C groups of lanes fall on disjoint banks (lds_elems(256) = 272 = 16 mod 32 alone
+    // put all sixteen columns on two bank groups: eight lanes to a bank).
+#ifndef HZ_FFT2_LDS_SKEW
+#define HZ_FFT2_LDS_SKEW 1
+#endif
+    constexpr int SKEW = HZ_FFT2_LDS_SKEW && C > 1 ? ((64 / C) % 32 - fv::lds_elems(N1) % 32 + 32) % 32 : 0;
+    constexpr int REGION = fv::lds_elems(N1) + SKEW;
+    __shared__ cf lds_all[C * REGION];
     const int sub = threadIdx.x % C, lane = threadIdx.x / C;  // column-fastest
-    cf *lds = lds_all + sub * fv::lds_elems(N1);
-    const uint32_t n2 = blockIdx.x * C + sub;
-    const size_t base = (size_t)blockIdx.y * N1 * n2_total;  // batch
+    cf *lds = lds_all + sub * REGION;
+    uint32_t bx, by;
+    fft2_tile(bx, by);
+    const uint32_t n2 = bx * C + sub;
+    const size_t base = (size_t)by * N1 * n2_total;  // batch
+    // The twiddle of output k1 = lane + E(q) (E(q) = edge_off, the same for every lane) is W^(n2 lane) W^(n2 E(q)): the
+    // second factor belongs to the COLUMN, sixteen values each -- one per lane of the workgroup, formed here from the
+    // two tables and left in LDS (the transform's barriers order it); the first is one more table product per lane.
+    // Four gathers per lane, issued beside the sixteen loads of the samples, where there were thirty-two behind the
+    // transform (HZ_FFT2_TW=0): with those the pass took 68.5 us per 2^24 points at N = 2^16, without any twiddle 50.6
+    // (tools/fft_ab.sh over -DHZ_FFT2_ABL builds; contiguous instead of strided pieces changed nothing).
+#ifndef HZ_FFT2_TW
+#define HZ_FFT2_TW 1
+#endif
+    __shared__ cf col_tw[HZ_FFT2_TW ? 16 * C : 1];
+    cf w_lane;
+    if constexpr (HZ_FFT2_TW != 0) {
+        if (threadIdx.x < 16 * C) {
+            const int q = threadIdx.x / C;
+            constexpr int R = FWD ? 16 : R0;  // (edge_off<N1, R>(q) for a run-time q)
+            const uint32_t e = (q / R) * TPT + (q % R) * (N1 / R);
+            col_tw[threadIdx.x] = fv::from2(big_twiddle(bt, (bx * C + threadIdx.x % C) * e, !FWD));
+        }
+        w_lane = fv::from2(big_twiddle(bt, n2 * lane, !FWD));
+    }
     cf v[16];
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const int n1 = FWD ? fv::edge_index<N1, R0>(q, lane) : fv::edge_index<N1, 16>(q, lane);
+#if HZ_FFT2_ABL & 2
+        v[q] = fv::from2(in[base + (size_t)bx * 4096 + q * 256 + threadIdx.x]);
+#else
         v[q] = fv::from2(in[base + (size_t)n1 * n2_total + n2]);
+#endif
     }
+#if !(HZ_FFT2_ABL & 8)
     if constexpr (FWD) fv::forward<N1>(v, lds, tabs.fwd, lane); else fv::backward<N1>(v, lds, tabs.bwd, lane);
+#endif
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const uint32_t k1 = FWD ? fv::edge_index<N1, 16>(q, lane) : fv::edge_index<N1, R0>(q, lane);
-        const float2 w = big_twiddle(bt, n2 * k1, !FWD);
-        a_out[base + (size_t)k1 * n2_total + n2] = fv::to2(fv::cmul(v[q], fv::from2(w)));
+#if HZ_FFT2_ABL & 1
+        const cf w = fv::from2(make_float2(1.0f, (float)bt.s));
+#else
+        cf w;
+        if constexpr (HZ_FFT2_TW != 0) w = fv::cmul(w_lane, col_tw[q * C + sub]);
+        else w = fv::from2(big_twiddle(bt, n2 * k1, !FWD));
+#endif
+#if HZ_FFT2_ABL & 4
+        a_out[base + (size_t)bx * 4096 + q * 256 + threadIdx.x] = fv::to2(fv::cmul(v[q], w));
+#else
+        a_out[base + (size_t)k1 * n2_total + n2] = fv::to2(fv::cmul(v[q], w));
+#endif
     }
 }
 
@@ -356,8 +424,10 @@ __global__ __launch_bounds__(256) void fft2_rows_kernel(const float2 *__restrict
     __shared__ cf lds_all[C * fv::lds_elems(N2)];
     const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;  // lane-fastest: rows are contiguous
     cf *lds = lds_all + sub * fv::lds_elems(N2);
-    const uint32_t k1 = blockIdx.x * C + sub;
-    const size_t base = (size_t)blockIdx.y * N2 * n1_total;
+    uint32_t bx, by;
+    fft2_tile(bx, by);
+    const uint32_t k1 = bx * C + sub;
+    const size_t base = (size_t)by * N2 * n1_total;
     cf v[16];
 #pragma unroll
     for (int q = 0; q < 16; q++) {
@@ -375,7 +445,7 @@ __global__ __launch_bounds__(256) void fft2_rows_kernel(const float2 *__restrict
     // X[k1 + N1*k2]: C adjacent k1 per k2
     for (int e = threadIdx.x; e < C * N2; e += 256) {
         const int s2 = e % C, k2 = e / C;
-        out[base + (size_t)k2 * n1_total + blockIdx.x * C + s2] = fv::to2(lds_all[s2 * fv::lds_elems(N2) + fv::pad(k2)]);
+        out[base + (size_t)k2 * n1_total + bx * C + s2] = fv::to2(lds_all[s2 * fv::lds_elems(N2) + fv::pad(k2)]);
     }
 }
 
@@ -388,8 +458,10 @@ __global__ __launch_bounds__(256) void fft2_rows_small_kernel(const float2 *__re
     __shared__ float2 lds_all[C * N2];
     const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
     float2 *lds = lds_all + sub * N2;
-    const uint32_t k1 = blockIdx.x * C + sub;
-    const size_t base = (size_t)blockIdx.y * N2 * n1_total;
+    uint32_t bx, by;
+    fft2_tile(bx, by);
+    const uint32_t k1 = bx * C + sub;
+    const size_t base = (size_t)by * N2 * n1_total;
     FftRegs<N2> R;
 #pragma unroll
     for (int q = 0; q < CNT; q++) {
@@ -406,7 +478,7 @@ __global__ __launch_bounds__(256) void fft2_rows_small_kernel(const float2 *__re
     __syncthreads();
     for (int e = threadIdx.x; e < C * N2; e += 256) {
         const int s2 = e % C, k2 = e / C;
-        out[base + (size_t)k2 * n1_total + blockIdx.x * C + s2] = lds_all[s2 * N2 + k2];
+        out[base + (size_t)k2 * n1_total + bx * C + s2] = lds_all[s2 * N2 + k2];
     }
 }
 
@@ -469,13 +541,16 @@ template <int N2> static void launch_rows(hzsdr_ctx *ctx, const float2 *a, float
 
 static bool fft_two_step_ok(size_t n) { return n >= ((size_t)1 << 14) && n <= ((size_t)1 << 24) && (n & (n - 1)) == 0; }
 
-static int fft_two_step(hzsdr_ctx *ctx, const float2 *in, float2 *out, size_t n, size_t batch, bool fwd) {
-    int L = 0;
+// N1 as small as the packed-math core allows (best column coalescing), N2 = N / N1 <= 4096
+static size_t two_step_n1(size_t n) {
+    int L = 0, l1 = 8;
     while (((size_t)1 << L) < n) L++;
-    // N1 as small as the packed-math core allows (best column coalescing), N2 = N / N1 <= 4096
-    int l1 = 8;
     while (L - l1 > 12) l1++;
-    const size_t n1 = (size_t)1 << l1, n2 = n >> l1;
+    return (size_t)1 << l1;
+}
+
+static int fft_two_step(hzsdr_ctx *ctx, const float2 *in, float2 *out, size_t n, size_t batch, bool fwd) {
+    const size_t n1 = two_step_n1(n), n2 = n / n1;
     fv::FvTabs tw1{}, tw2{};
     const float2 *tw2s = nullptr;
     BigTw bt;
@@ -627,7 +702,13 @@ int fft_device(hzsdr_ctx *ctx, const void *in, void *out, size_t n, size_t batch
 
 int fft_prepare(hzsdr_ctx *ctx, size_t n) {
     if (n <= 1 || !fft_length_ok(n)) return HZSDR_OK;
-    if ((n & (n - 1)) == 0) return HZSDR_OK;  // (powers of two: their tables are small and formed where they are first used)
+    if ((n & (n - 1)) == 0) {
+        // (powers of two: their tables are small and formed where they are first used -- the two-step lengths' big
+        // twiddles here, so that a first transform inside somebody's timed or captured region finds them)
+        if (!fft_two_step_ok(n)) return HZSDR_OK;
+        BigTw bt;
+        return get_big_twiddles(ctx, n, &bt);
+    }
     Bluestein bl{};
     HZ_TRY(get_bluestein(ctx, n, &bl));
     return fft_prepare(ctx, bl.m);
