@@ -421,9 +421,13 @@ __global__ __launch_bounds__(256) void fft2_rows_kernel(const float2 *__restrict
     using fv::cf;
     constexpr int C = 4096 / N2, TPT = fv::tpt(N2), R0 = fv::first_radix(N2);
     static_assert(C * TPT == 256, "one 256-lane workgroup per row tile");
-    __shared__ cf lds_all[C * fv::lds_elems(N2)];
+    // (the transposed read-out below has C adjacent rows' lanes eight to a bank at lds_elems(256) = 272; regions set
+    // apart to spread them, as in the column pass, were measured in round 6 and changed nothing: this pass does not
+    // wait for its LDS)
+    constexpr int REGION = fv::lds_elems(N2);
+    __shared__ cf lds_all[C * REGION];
     const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;  // lane-fastest: rows are contiguous
-    cf *lds = lds_all + sub * fv::lds_elems(N2);
+    cf *lds = lds_all + sub * REGION;
     uint32_t bx, by;
     fft2_tile(bx, by);
     const uint32_t k1 = bx * C + sub;
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(256) void fft2_rows_kernel(const float2 *__restrict
     // X[k1 + N1*k2]: C adjacent k1 per k2
     for (int e = threadIdx.x; e < C * N2; e += 256) {
         const int s2 = e % C, k2 = e / C;
-        out[base + (size_t)k2 * n1_total + bx * C + s2] = fv::to2(lds_all[s2 * fv::lds_elems(N2) + fv::pad(k2)]);
+        out[base + (size_t)k2 * n1_total + bx * C + s2] = fv::to2(lds_all[s2 * REGION + fv::pad(k2)]);
     }
 }
 
@@ -455,9 +459,10 @@ template <int N2, bool FWD>
 __global__ __launch_bounds__(256) void fft2_rows_small_kernel(const float2 *__restrict__ a_in, float2 *__restrict__ out,
                                                               const float2 *__restrict__ tw2, uint32_t n1_total) {
     constexpr int TPT = fft_tpt(N2), C = 256 / TPT, CNT = N2 / TPT;
-    __shared__ float2 lds_all[C * N2];
+    constexpr int REGION = N2;
+    __shared__ float2 lds_all[C * REGION];
     const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;
-    float2 *lds = lds_all + sub * N2;
+    float2 *lds = lds_all + sub * REGION;
     uint32_t bx, by;
     fft2_tile(bx, by);
     const uint32_t k1 = bx * C + sub;
@@ -478,7 +483,7 @@ __global__ __launch_bounds__(256) void fft2_rows_small_kernel(const float2 *__re
     __syncthreads();
     for (int e = threadIdx.x; e < C * N2; e += 256) {
         const int s2 = e % C, k2 = e / C;
-        out[base + (size_t)k2 * n1_total + bx * C + s2] = lds_all[s2 * N2 + k2];
+        out[base + (size_t)k2 * n1_total + bx * C + s2] = lds_all[s2 * REGION + k2];
     }
 }
 
@@ -546,6 +551,8 @@ static size_t two_step_n1(size_t n) {
     int L = 0, l1 = 8;
     while (((size_t)1 << L) < n) L++;
     while (L - l1 > 12) l1++;
+    // (measured, round 6: N1 = N2 = 512 at 2^18 and 1024 at 2^20 -- 64- and 32-byte pieces on both sides instead of
+    // 128-byte columns and short row pieces -- 120 against 117 us and 160 against 152 per 2^24 points: not better)
     return (size_t)1 << l1;
 }
 
