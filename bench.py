@@ -614,6 +614,14 @@ def main():
         chf = ctx.chain(hz.FMT_C64, fs).fir_decimate(taps, 1)
         both("fir_1024_overlap_save_c64", lambda i: chf.run(cs[i % kRot], outs[i % kRot]), 16)
         chf.close()
+        # fft.Planner lengths of the reference's own callers, 2^24 points per call (16 B / point: in once, out once;
+        # the two-step lengths move their scratch as well -- 32 B / point -- and are quoted by the ALGORITHMIC 16):
+        # 4096 (ConvolutionReader blocks), 64 Ki (rtl/kerberos/internal/align.go), 256 Ki (internal/graft.go)
+        for lg in (12, 16, 18):
+            plan = ctx.fft_plan(cs[0], outs[0], hz.FFT_FORWARD, batch=n >> lg)
+            plans = [plan] + [ctx.fft_plan(cs[i], outs[i], hz.FFT_FORWARD, batch=n >> lg) for i in range(1, kRot)]
+            both("fft_forward_2p%d" % lg, lambda i: plans[i % kRot].transform(), 16)
+            del plan, plans
         del cs[1:], outs[1:]
         # cfg 4: Downsample by 8 from i16 (5 B/input sample)
         xi = torch.from_numpy(synth_i16(4, n)).cuda()
