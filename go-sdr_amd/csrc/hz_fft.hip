@@ -415,17 +415,23 @@ __global__ __launch_bounds__(256) void fft2_cols_kernel(const float2 *__restrict
     }
 }
 
-template <int N2, bool FWD>
-__global__ __launch_bounds__(256) void fft2_rows_kernel(const float2 *__restrict__ a_in, float2 *__restrict__ out,
-                                                        fv::FvTabs tabs, uint32_t n1_total) {
+// THREADS: 256, or more for the long rows -- C = 16 THREADS / N2 adjacent rows per tile, so that the output pieces (C
+// adjacent k1 per k2) do not shrink to 32 and 8 bytes at N2 = 1024 and 4096 (dynamic LDS: above 64 KiB there).
+// Measured (round 6, the row pass per 2^24 points, 256 | 512 | 1024 threads): N2 = 1024: 50 | 48 | 68 us;
+// 2048: 72 | 59 | 65; 4096: 103 | 75 | 67.5 (profiles/r06_fft2_rowthreads.txt).
+template <int N2> constexpr int rows_threads() { return N2 >= 4096 ? 1024 : N2 >= 1024 ? 512 : 256; }
+template <int N2, bool FWD, int THREADS>
+__global__ __launch_bounds__(THREADS) void fft2_rows_kernel(const float2 *__restrict__ a_in, float2 *__restrict__ out,
+                                                            fv::FvTabs tabs, uint32_t n1_total) {
     using fv::cf;
-    constexpr int C = 4096 / N2, TPT = fv::tpt(N2), R0 = fv::first_radix(N2);
-    static_assert(C * TPT == 256, "one 256-lane workgroup per row tile");
+    constexpr int TPT = fv::tpt(N2), C = THREADS / TPT, R0 = fv::first_radix(N2);
+    static_assert(C * TPT == THREADS && C >= 1, "whole rows per workgroup");
     // (the transposed read-out below has C adjacent rows' lanes eight to a bank at lds_elems(256) = 272; regions set
     // apart to spread them, as in the column pass, were measured in round 6 and changed nothing: this pass does not
     // wait for its LDS)
     constexpr int REGION = fv::lds_elems(N2);
-    __shared__ cf lds_all[C * REGION];
+    extern __shared__ __attribute__((aligned(16))) unsigned char fft2_rows_lds[];
+    cf *lds_all = reinterpret_cast<cf *>(fft2_rows_lds);
     const int sub = threadIdx.x / TPT, lane = threadIdx.x % TPT;  // lane-fastest: rows are contiguous
     cf *lds = lds_all + sub * REGION;
     uint32_t bx, by;
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(256) void fft2_rows_kernel(const float2 *__restrict
     }
     __syncthreads();
     // X[k1 + N1*k2]: C adjacent k1 per k2
-    for (int e = threadIdx.x; e < C * N2; e += 256) {
+    for (int e = threadIdx.x; e < C * N2; e += THREADS) {
         const int s2 = e % C, k2 = e / C;
         out[base + (size_t)k2 * n1_total + bx * C + s2] = fv::to2(lds_all[s2 * REGION + fv::pad(k2)]);
     }
@@ -536,12 +542,13 @@ template <int N1> static void launch_cols(hzsdr_ctx *ctx, const float2 *in, floa
     if (fwd) hipLaunchKernelGGL((fft2_cols_kernel<N1, true>), grid, dim3(256), 0, ctx->stream, in, a, tw1, bt, (uint32_t)n2);
     else hipLaunchKernelGGL((fft2_cols_kernel<N1, false>), grid, dim3(256), 0, ctx->stream, in, a, tw1, bt, (uint32_t)n2);
 }
-template <int N2> static void launch_rows(hzsdr_ctx *ctx, const float2 *a, float2 *out, const fv::FvTabs &tw2,
-                                          size_t n1, size_t batch, bool fwd) {
-    constexpr int C = 4096 / N2;
-    dim3 grid((unsigned)(n1 / C), (unsigned)batch);
-    if (fwd) hipLaunchKernelGGL((fft2_rows_kernel<N2, true>), grid, dim3(256), 0, ctx->stream, a, out, tw2, (uint32_t)n1);
-    else hipLaunchKernelGGL((fft2_rows_kernel<N2, false>), grid, dim3(256), 0, ctx->stream, a, out, tw2, (uint32_t)n1);
+template <int N2> static int launch_rows(hzsdr_ctx *ctx, const float2 *a, float2 *out, const fv::FvTabs &tw2,
+                                         size_t n1, size_t batch, bool fwd) {
+    constexpr int T = rows_threads<N2>(), C = T / fv::tpt(N2);
+    const dim3 grid((unsigned)(n1 / C), (unsigned)batch);
+    const size_t lds = (size_t)C * fv::lds_elems(N2) * sizeof(fv::cf);
+    if (fwd) return launch_dyn(fft2_rows_kernel<N2, true, T>, grid, dim3(T), lds, ctx->stream, a, out, tw2, (uint32_t)n1);
+    return launch_dyn(fft2_rows_kernel<N2, false, T>, grid, dim3(T), lds, ctx->stream, a, out, tw2, (uint32_t)n1);
 }
 
 static bool fft_two_step_ok(size_t n) { return n >= ((size_t)1 << 14) && n <= ((size_t)1 << 24) && (n & (n - 1)) == 0; }
@@ -577,11 +584,11 @@ static int fft_two_step(hzsdr_ctx *ctx, const float2 *in, float2 *out, size_t n,
     switch (n2) {
     case 64: launch_rows_small<64>(ctx, a, out, tw2s, n1, batch, fwd); break;
     case 128: launch_rows_small<128>(ctx, a, out, tw2s, n1, batch, fwd); break;
-    case 256: launch_rows<256>(ctx, a, out, tw2, n1, batch, fwd); break;
-    case 512: launch_rows<512>(ctx, a, out, tw2, n1, batch, fwd); break;
-    case 1024: launch_rows<1024>(ctx, a, out, tw2, n1, batch, fwd); break;
-    case 2048: launch_rows<2048>(ctx, a, out, tw2, n1, batch, fwd); break;
-    default: launch_rows<4096>(ctx, a, out, tw2, n1, batch, fwd); break;
+    case 256: HZ_TRY(launch_rows<256>(ctx, a, out, tw2, n1, batch, fwd)); break;
+    case 512: HZ_TRY(launch_rows<512>(ctx, a, out, tw2, n1, batch, fwd)); break;
+    case 1024: HZ_TRY(launch_rows<1024>(ctx, a, out, tw2, n1, batch, fwd)); break;
+    case 2048: HZ_TRY(launch_rows<2048>(ctx, a, out, tw2, n1, batch, fwd)); break;
+    default: HZ_TRY(launch_rows<4096>(ctx, a, out, tw2, n1, batch, fwd)); break;
     }
     return HZSDR_OK;
 }

@@ -621,6 +621,33 @@ def test_fft_against_float64(env, n):
     p.close()
 
 
+@pytest.mark.parametrize("n,batch", [(1 << 14, 3), (1 << 14, 40), (1 << 15, 5), (1 << 16, 3), (1 << 16, 24), (1 << 17, 9),
+                                     (1 << 18, 8), (1 << 19, 2), (1 << 21, 1), (1 << 21, 3), (1 << 23, 1), (1 << 24, 1)])
+def test_fft_two_step_tilings(env, n, batch):
+    """The two-step lengths over batches whose tile counts are and are not multiples of eight (the XCD-contiguous
+    tile order applies to the first only), every column / row kernel width (N1 = 256 .. 4096; rows of 64 .. 4096
+    points on 256, 512 and 1024 lanes), forward and backward.  Same bound as test_fft_against_float64."""
+    tol = 3e-7 * math.log2(n) + 1e-7
+    x = rand_c64(n + batch, n * batch)
+    xs = x.astype(np.complex128).reshape(batch, n)
+    iq, fr = env.put(x), env.zeros("c64", n * batch)
+    p = env.ctx.fft_plan(iq, fr, env.hz.FFT_FORWARD, batch=batch)
+    p.transform()
+    got = env.get(fr).reshape(batch, n)
+    want = np.fft.fft(xs, axis=1)
+    for b in range(batch):  # per transform: one transform's tiles in the wrong place must not hide in the batch's norm
+        assert _rel_l2(got[b], want[b]) < tol, b
+    p.close()
+    fr, iq = env.put(x), env.zeros("c64", n * batch)
+    p = env.ctx.fft_plan(iq, fr, env.hz.FFT_BACKWARD, batch=batch)
+    p.transform()
+    got = env.get(iq).reshape(batch, n)
+    want = np.fft.ifft(xs, axis=1) * n
+    for b in range(batch):
+        assert _rel_l2(got[b], want[b]) < tol, b
+    p.close()
+
+
 @pytest.mark.parametrize("n", [3, 5, 12, 1000, 1200, 1536, 4099, 3 << 10, 3 << 15, 100_003, (1 << 20) + 7])
 def test_fft_any_length_against_float64(env, n):
     """fft.Planner takes whatever length its buffers have (fft/fft.go:45-48): lengths that are not powers of two run as
