@@ -22,7 +22,7 @@ python3 tools/pmc_summary.py $out/pmc_fetch $out/pmc_write $out/traffic.json > /
 REPS=6 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $out/sq1 -- python3 tools/prof_kernels.py chain chain_fft conv chain_c64 > /dev/null 2>&1
 REPS=6 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_LDS_UNALIGNED_STALL --output-format csv -d $out/sq2 -- python3 tools/prof_kernels.py chain chain_fft conv chain_c64 > /dev/null 2>&1
 python3 tools/pmc_sq.py $out/sq1 $out/sq2 > $out/sq_counters.txt
-REPS=6 rocprofv3 --kernel-trace --stats --output-format csv -d $out/fft_trace -- python3 tools/prof_kernels.py fft1024 fft4096 fftbig13 fftbig14 fftbig15 fftbig16 fftbig18 > /dev/null 2>&1
+REPS=6 rocprofv3 --kernel-trace --stats --output-format csv -d $out/fft_trace -- python3 tools/prof_kernels.py fft1024 fft4096 fftbig13 fftbig14 fftbig15 fftbig16 fftbig18 fftbig20 > /dev/null 2>&1
 REPS=10 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kern_trace -- python3 tools/prof_kernels.py $K chain shift rotate > /dev/null 2>&1
 python3 tools/host_path_bench.py > $out/host_path.txt 2>&1
 tools/bin/fir_ablate > $out/fir_ablate.txt 2>&1
@@ -61,6 +61,8 @@ python3 tools/firmm_probe.py 2>/dev/null | grep "path\|mean\|calls" > $out/firmm
 python3 tools/shift_time.py 2>&1 | grep -v amdgpu > $out/shift_time_final.txt
 python3 tools/downsample_time.py 2>&1 | grep -v amdgpu > $out/downsample_time_final.txt
 for d in 16; do for t in 1024 512 256; do for impl in 0 2; do PROBE_D=$d PROBE_TAPS=$t PROBE_IMPL=$impl python3 tools/firmm_probe.py 2>/dev/null | head -2; done; done; done > $out/firmm_probe_d16.txt
+python3 tools/fftbig_time.py 2>&1 | grep "N =" > $out/fftbig_time.txt
+(python3 tools/clock_watch.py; HZ_QUIET_INPUT=1 python3 tools/clock_watch.py) 2>&1 | grep -v amdgpu > $out/clock_watch.txt
 for f in $out/bench_trace/*/*kernel_stats.csv $out/bench_trace_batch/*/*kernel_stats.csv $out/kern_trace/*/*kernel_stats.csv; do echo "== $f"; cut -d, -f1-4 $f | cut -c1-160 | head -14; done
 cat $out/sq_counters.txt | tail -30
 tail -3 $out/bench.err

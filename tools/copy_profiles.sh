@@ -19,5 +19,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   f=$(newest "$d/*/*_counter_collection.csv")
   (head -1 $f; grep "hz::" $f) > profiles/${tag}_pmc_$c.csv
 done
-for t in sq_counters fir_ablate host_path mfma_fir mfma_fir2 mfma_fir2_ab mfma_fir2_batch4 mfma_rate firmm_probe pk_glitch mm2_glitch mm2_glitch_unpatched_build mfma_hazard repeat_check repeat_check_pipelined_run repeat_check_batch_run nco_ablate copy_rate issue_rate conv_time shift_in_place epi_cost stream_rate pipeline_time pass_breakdown pass_breakdown_zero power_split mfma_power ab6_batch4 ab6_batch8 ab7 shift_time_final downsample_time_final firmm_probe_d16; do [ -f $src/$t.txt ] && cp $src/$t.txt profiles/${tag}_$t.txt; done
+for t in sq_counters fir_ablate host_path mfma_fir mfma_fir2 mfma_fir2_ab mfma_fir2_batch4 mfma_rate firmm_probe pk_glitch mm2_glitch mm2_glitch_unpatched_build mfma_hazard repeat_check repeat_check_pipelined_run repeat_check_batch_run nco_ablate copy_rate issue_rate conv_time shift_in_place epi_cost stream_rate pipeline_time pass_breakdown pass_breakdown_zero power_split mfma_power ab6_batch4 ab6_batch8 ab7 shift_time_final downsample_time_final firmm_probe_d16 fftbig_time clock_watch; do [ -f $src/$t.txt ] && cp $src/$t.txt profiles/${tag}_$t.txt; done
 ls -la profiles/${tag}_*
