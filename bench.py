@@ -416,7 +416,7 @@ def main():
     chain.close()
     # HBM traffic per launch of the dominant kernel comes from separate rocprofv3 --pmc
     # passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_summary.py), not from this process.
-    tname = next((t for t in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), "r05_traffic.json")
+    tname = next((t for t in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", t))), "r05_traffic.json")
     tpath = os.path.join(ROOT, "profiles", tname)
     if n == (1 << 24) and os.path.exists(tpath):
         try:

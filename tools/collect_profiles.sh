@@ -15,7 +15,7 @@ python3 bench.py --no-extra --no-cpu-baseline --steps 20 --warmup 5 > $out/bench
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_trace -- python3 bench.py --no-oracle --no-extra --no-pipeline --batch 1 > $out/bench_profiled.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_trace_batch -- python3 bench.py --no-oracle --no-extra --no-pipeline > $out/bench_profiled_batch.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_trace_pipelined -- python3 bench.py --no-oracle --no-extra > $out/bench_profiled_pipelined.json 2> /dev/null
-K="chain_batch4 chain_fft convert shift_gain conv chain_c64 beamform downsample scale"
+K="chain_batch4 chain_fft convert shift_gain conv chain_c64 beamform downsample scale fftbig16 fftbig18"
 REPS=6 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 tools/prof_kernels.py $K > /dev/null 2>&1
 REPS=6 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 tools/prof_kernels.py $K > /dev/null 2>&1
 python3 tools/pmc_summary.py $out/pmc_fetch $out/pmc_write $out/traffic.json > /dev/null
