@@ -1,9 +1,9 @@
 """The shader clock the chip holds UNDER each of the library's kernels (tools/clock_witness.hip beside the work).
 
 For every workload: the witness samples (shader cycles, 100 MHz ticks) every 20 us on a side stream for 64 ms; the
-workload runs back to back on the main stream from about 1 ms in, for about 40 ms (HZ_WORK_US; the power management
-settles over milliseconds: a 3 ms burst still runs at the idle clock), between two marks that write the same 100 MHz
-counter.  Printed: the clock before the work, the median / lowest / highest clock of the samples taken in the SECOND
+workload runs back to back on the main stream from about 1 ms in, for about 40 ms (HZ_WORK_US; HZ_TRACE=1 prints the
+clock by tenths of the work: under the matrix kernel it is down within the first tenth of a 0.5 ms burst, under the
+vector kernels it keeps sinking for milliseconds), between two marks that write the same 100 MHz counter.  Printed: the clock before the work, the median / lowest / highest clock of the samples taken in the SECOND
 HALF of the work, and the time of one call by events over the whole of it.
 Usage: python tools/clock_watch.py [workload ...]   (default: all)
 """
@@ -64,7 +64,7 @@ def workloads():
     return w
 
 
-def watch(name, fn, samples=3200, period=2000):
+def watch(name, fn, samples=int(os.environ.get("HZ_SAMPLES", "3200")), period=int(os.environ.get("HZ_PERIOD_TICKS", "2000"))):
     buf = torch.zeros(2 * samples, dtype=torch.int64, device="cuda")
     for i in range(20):
         fn(i)
@@ -93,7 +93,11 @@ def watch(name, fn, samples=3200, period=2000):
     inside = mhz[(lo >= 0.5 * (m0 + m1)) & (hi <= m1 - 0.02 * (m1 - m0))]
     before = mhz[hi <= m0]
     total = (m1 - m0) / 100.0
-    assert len(inside) > 10 and len(before) > 10, (len(inside), len(before), "the witness ended before the work did")
+    assert len(inside) > 3 and len(before) > 3, (len(inside), len(before), "the witness ended before the work did")
+    if os.environ.get("HZ_TRACE") == "1":  # the clock by tenths of the work's span (a short burst: HZ_WORK_US=700 HZ_PERIOD_TICKS=100)
+        mid = 0.5 * (lo + hi)
+        tenths = [mhz[(mid >= m0 + k * (m1 - m0) / 10) & (mid < m0 + (k + 1) * (m1 - m0) / 10)] for k in range(10)]
+        print("    clock by tenths of the work: " + " ".join("%4.0f" % float(np.median(t)) if len(t) else "   -" for t in tenths) + " MHz")
     print("%-28s %8.1f us per call | clock before %5.0f MHz | under the work: median %5.0f, lowest %5.0f, highest %5.0f MHz (%d samples over %.0f us)"
           % (name, per_call, float(np.median(before)), float(np.median(inside)), float(inside.min()), float(inside.max()), len(inside), total))
 
