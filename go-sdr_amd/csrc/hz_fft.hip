@@ -343,12 +343,18 @@ __device__ __forceinline__ void fft2_tile(uint32_t &bx, uint32_t &by) {
     }
 }
 
-template <int N1, bool FWD>
-__global__ __launch_bounds__(256) void fft2_cols_kernel(const float2 *__restrict__ in, float2 *__restrict__ a_out,
-                                                        fv::FvTabs tabs, BigTw bt, uint32_t n2_total) {
+// THREADS: 256 lanes hold C = 4096 / N1 columns -- 128-byte pieces at N1 = 256, 8-byte ones at N1 = 4096 (N = 2^24);
+// the long columns take wider workgroups, like the long rows below (dynamic LDS: up to 140 KB).  Measured (round 6,
+// the column pass per 2^24 points, 256 | 512 | 1024 lanes): N1 = 512: 72 | 70 | 76 us; 1024: 96 | 86 | 93;
+// 2048: 153 | 113 | 115; 4096: 278 | 161 | 121 (profiles/r06_fft2_colthreads.txt).
+template <int N1> constexpr int cols_threads() { return N1 >= 4096 ? 1024 : N1 >= 1024 ? 512 : 256; }
+template <int N1, bool FWD, int THREADS>
+__global__ __launch_bounds__(THREADS) void fft2_cols_kernel(const float2 *__restrict__ in, float2 *__restrict__ a_out,
+                                                            fv::FvTabs tabs, BigTw bt, uint32_t n2_total) {
     using fv::cf;
-    constexpr int C = 4096 / N1, TPT = fv::tpt(N1), R0 = fv::first_radix(N1);
-    static_assert(C * TPT == 256, "one 256-lane workgroup per column tile");
+    constexpr int TPT = fv::tpt(N1), C = THREADS / TPT, R0 = fv::first_radix(N1);
+    [[maybe_unused]] constexpr int TILE = C * N1;  // (the ablation builds' contiguous tile)
+    static_assert(C * TPT == THREADS && C >= 1, "whole columns per workgroup");
     // A wave holds 64 / C lanes of each of its C columns: the columns' LDS regions sit 64 / C elements (mod 32) apart,
     // so that one LDS instruction's C groups of lanes fall on disjoint banks (lds_elems(256) = 272 = 16 mod 32 alone
     // put all sixteen columns on two bank groups: eight lanes to a bank).
@@ -357,7 +363,8 @@ __global__ __launch_bounds__(256) void fft2_cols_kernel(const float2 *__restrict
 #endif
     constexpr int SKEW = HZ_FFT2_LDS_SKEW && C > 1 ? ((64 / C) % 32 - fv::lds_elems(N1) % 32 + 32) % 32 : 0;
     constexpr int REGION = fv::lds_elems(N1) + SKEW;
-    __shared__ cf lds_all[C * REGION];
+    extern __shared__ __attribute__((aligned(16))) unsigned char fft2_cols_lds[];
+    cf *lds_all = reinterpret_cast<cf *>(fft2_cols_lds);
     const int sub = threadIdx.x % C, lane = threadIdx.x / C;  // column-fastest
     cf *lds = lds_all + sub * REGION;
     uint32_t bx, by;
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(256) void fft2_cols_kernel(const float2 *__restrict
 #ifndef HZ_FFT2_TW
 #define HZ_FFT2_TW 1
 #endif
-    __shared__ cf col_tw[HZ_FFT2_TW ? 16 * C : 1];
+    cf *col_tw = lds_all + C * REGION;  // 16 * C entries behind the columns' regions
     cf w_lane;
     if constexpr (HZ_FFT2_TW != 0) {
         if (threadIdx.x < 16 * C) {
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(256) void fft2_cols_kernel(const float2 *__restrict
     for (int q = 0; q < 16; q++) {
         const int n1 = FWD ? fv::edge_index<N1, R0>(q, lane) : fv::edge_index<N1, 16>(q, lane);
 #if HZ_FFT2_ABL & 2
-        v[q] = fv::from2(in[base + (size_t)bx * 4096 + q * 256 + threadIdx.x]);
+        v[q] = fv::from2(in[base + (size_t)bx * TILE + q * THREADS + threadIdx.x]);
 #else
         v[q] = fv::from2(in[base + (size_t)n1 * n2_total + n2]);
 #endif
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(256) void fft2_cols_kernel(const float2 *__restrict
         else w = fv::from2(big_twiddle(bt, n2 * k1, !FWD));
 #endif
 #if HZ_FFT2_ABL & 4
-        a_out[base + (size_t)bx * 4096 + q * 256 + threadIdx.x] = fv::to2(fv::cmul(v[q], w));
+        a_out[base + (size_t)bx * TILE + q * THREADS + threadIdx.x] = fv::to2(fv::cmul(v[q], w));
 #else
         a_out[base + (size_t)k1 * n2_total + n2] = fv::to2(fv::cmul(v[q], w));
 #endif
@@ -535,12 +542,14 @@ static int get_big_twiddles(hzsdr_ctx *ctx, size_t n, BigTw *bt) {
     return HZSDR_OK;
 }
 
-template <int N1> static void launch_cols(hzsdr_ctx *ctx, const float2 *in, float2 *a, const fv::FvTabs &tw1,
-                                          const BigTw &bt, size_t n2, size_t batch, bool fwd) {
-    constexpr int C = 4096 / N1;
-    dim3 grid((unsigned)(n2 / C), (unsigned)batch);
-    if (fwd) hipLaunchKernelGGL((fft2_cols_kernel<N1, true>), grid, dim3(256), 0, ctx->stream, in, a, tw1, bt, (uint32_t)n2);
-    else hipLaunchKernelGGL((fft2_cols_kernel<N1, false>), grid, dim3(256), 0, ctx->stream, in, a, tw1, bt, (uint32_t)n2);
+template <int N1> static int launch_cols(hzsdr_ctx *ctx, const float2 *in, float2 *a, const fv::FvTabs &tw1,
+                                         const BigTw &bt, size_t n2, size_t batch, bool fwd) {
+    constexpr int T = cols_threads<N1>(), C = T / fv::tpt(N1);
+    constexpr int SKEW = HZ_FFT2_LDS_SKEW && C > 1 ? ((64 / C) % 32 - fv::lds_elems(N1) % 32 + 32) % 32 : 0;
+    const dim3 grid((unsigned)(n2 / C), (unsigned)batch);
+    const size_t lds = ((size_t)C * (fv::lds_elems(N1) + SKEW) + 16 * C) * sizeof(fv::cf);
+    if (fwd) return launch_dyn(fft2_cols_kernel<N1, true, T>, grid, dim3(T), lds, ctx->stream, in, a, tw1, bt, (uint32_t)n2);
+    return launch_dyn(fft2_cols_kernel<N1, false, T>, grid, dim3(T), lds, ctx->stream, in, a, tw1, bt, (uint32_t)n2);
 }
 template <int N2> static int launch_rows(hzsdr_ctx *ctx, const float2 *a, float2 *out, const fv::FvTabs &tw2,
                                          size_t n1, size_t batch, bool fwd) {
@@ -575,11 +584,11 @@ static int fft_two_step(hzsdr_ctx *ctx, const float2 *in, float2 *out, size_t n,
     HZ_TRY(ensure_slot(ctx, 10, n * batch * sizeof(float2)));
     float2 *a = (float2 *)ctx->slots[10].ptr;
     switch (n1) {
-    case 256: launch_cols<256>(ctx, in, a, tw1, bt, n2, batch, fwd); break;
-    case 512: launch_cols<512>(ctx, in, a, tw1, bt, n2, batch, fwd); break;
-    case 1024: launch_cols<1024>(ctx, in, a, tw1, bt, n2, batch, fwd); break;
-    case 2048: launch_cols<2048>(ctx, in, a, tw1, bt, n2, batch, fwd); break;
-    default: launch_cols<4096>(ctx, in, a, tw1, bt, n2, batch, fwd); break;
+    case 256: HZ_TRY(launch_cols<256>(ctx, in, a, tw1, bt, n2, batch, fwd)); break;
+    case 512: HZ_TRY(launch_cols<512>(ctx, in, a, tw1, bt, n2, batch, fwd)); break;
+    case 1024: HZ_TRY(launch_cols<1024>(ctx, in, a, tw1, bt, n2, batch, fwd)); break;
+    case 2048: HZ_TRY(launch_cols<2048>(ctx, in, a, tw1, bt, n2, batch, fwd)); break;
+    default: HZ_TRY(launch_cols<4096>(ctx, in, a, tw1, bt, n2, batch, fwd)); break;
     }
     switch (n2) {
     case 64: launch_rows_small<64>(ctx, a, out, tw2s, n1, batch, fwd); break;
