@@ -355,13 +355,20 @@ __global__ __launch_bounds__(THREADS) void fft2_cols_kernel(const float2 *__rest
     constexpr int TPT = fv::tpt(N1), C = THREADS / TPT, R0 = fv::first_radix(N1);
     [[maybe_unused]] constexpr int TILE = C * N1;  // (the ablation builds' contiguous tile)
     static_assert(C * TPT == THREADS && C >= 1, "whole columns per workgroup");
-    // A wave holds 64 / C lanes of each of its C columns: the columns' LDS regions sit 64 / C elements (mod 32) apart,
-    // so that one LDS instruction's C groups of lanes fall on disjoint banks (lds_elems(256) = 272 = 16 mod 32 alone
-    // put all sixteen columns on two bank groups: eight lanes to a bank).
+    // An 8-byte LDS access is served in two groups of 32 lanes over 64 banks: a group holds 32 / C lanes of each of
+    // the C columns, so the columns' regions sit 32 / C elements (mod 32) apart and a group's 64 dwords fall on 64
+    // banks -- both for the exchange's loads (a column's lanes an element apart) and for its stores at NS = 1 (17
+    // elements apart).  lds_elems(256) = 272 = 16 mod 32 alone put all sixteen columns on two bank groups, eight lanes
+    // to a bank: SQ_LDS_BANK_CONFLICT 31.5 M of 34.7 M LDS cycles per launch and XCD, waves waiting for LDS 21 % of their
+    // time; now 2.1 M of 5.3 M, 0.4 % (profiles/r06_fft2_lds_conflicts*.txt; regions 64 / C apart, the first attempt:
+    // 6.3 M of 9.5 M -- the two columns that then share a bank group still took turns).
 #ifndef HZ_FFT2_LDS_SKEW
 #define HZ_FFT2_LDS_SKEW 1
 #endif
-    constexpr int SKEW = HZ_FFT2_LDS_SKEW && C > 1 ? ((64 / C) % 32 - fv::lds_elems(N1) % 32 + 32) % 32 : 0;
+#ifndef HZ_FFT2_SKEW_UNIT
+#define HZ_FFT2_SKEW_UNIT 32
+#endif
+    constexpr int SKEW = HZ_FFT2_LDS_SKEW && C > 1 ? ((HZ_FFT2_SKEW_UNIT / C) % 32 - fv::lds_elems(N1) % 32 + 32) % 32 : 0;
     constexpr int REGION = fv::lds_elems(N1) + SKEW;
     extern __shared__ __attribute__((aligned(16))) unsigned char fft2_cols_lds[];
     cf *lds_all = reinterpret_cast<cf *>(fft2_cols_lds);
@@ -545,7 +552,7 @@ static int get_big_twiddles(hzsdr_ctx *ctx, size_t n, BigTw *bt) {
 template <int N1> static int launch_cols(hzsdr_ctx *ctx, const float2 *in, float2 *a, const fv::FvTabs &tw1,
                                          const BigTw &bt, size_t n2, size_t batch, bool fwd) {
     constexpr int T = cols_threads<N1>(), C = T / fv::tpt(N1);
-    constexpr int SKEW = HZ_FFT2_LDS_SKEW && C > 1 ? ((64 / C) % 32 - fv::lds_elems(N1) % 32 + 32) % 32 : 0;
+    constexpr int SKEW = HZ_FFT2_LDS_SKEW && C > 1 ? ((HZ_FFT2_SKEW_UNIT / C) % 32 - fv::lds_elems(N1) % 32 + 32) % 32 : 0;
     const dim3 grid((unsigned)(n2 / C), (unsigned)batch);
     const size_t lds = ((size_t)C * (fv::lds_elems(N1) + SKEW) + 16 * C) * sizeof(fv::cf);
     if (fwd) return launch_dyn(fft2_cols_kernel<N1, true, T>, grid, dim3(T), lds, ctx->stream, in, a, tw1, bt, (uint32_t)n2);

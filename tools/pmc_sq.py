@@ -14,7 +14,7 @@ for d in sys.argv[1:]:
             short = name.split("(")[0].replace("void hz::", "")[:60]
             acc[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in acc.items():
-            if "fir_" not in k and "conv_" not in k and "chain" not in k:
+            if "fir_" not in k and "conv_" not in k and "chain" not in k and "fft2_" not in k:
                 continue
             print(k)
             for c, vals in sorted(cs.items()):
