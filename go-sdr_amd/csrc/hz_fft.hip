@@ -733,11 +733,20 @@ int fft_device(hzsdr_ctx *ctx, const void *in, void *out, size_t n, size_t batch
 int fft_prepare(hzsdr_ctx *ctx, size_t n) {
     if (n <= 1 || !fft_length_ok(n)) return HZSDR_OK;
     if ((n & (n - 1)) == 0) {
-        // (powers of two: their tables are small and formed where they are first used -- the two-step lengths' big
-        // twiddles here, so that a first transform inside somebody's timed or captured region finds them)
-        if (!fft_two_step_ok(n)) return HZSDR_OK;
-        BigTw bt;
-        return get_big_twiddles(ctx, n, &bt);
+        // every table the length's kernels read, so that a first transform inside somebody's timed or captured region
+        // finds them (each getter uploads with a blocking copy the first time)
+        const float2 *tw;
+        fv::FvTabs tabs{};
+        if (fft_two_step_ok(n)) {
+            const size_t n1 = two_step_n1(n), n2 = n / n1;
+            BigTw bt;
+            HZ_TRY(get_fv_tables(ctx, n1, &tabs));
+            if (n2 >= 256) HZ_TRY(get_fv_tables(ctx, n2, &tabs));
+            else HZ_TRY(get_twiddles(ctx, n2, &tw));
+            return get_big_twiddles(ctx, n, &bt);
+        }
+        if (fv::ok((int)n)) return get_fv_tables(ctx, n, &tabs);
+        return get_twiddles(ctx, n, &tw);
     }
     Bluestein bl{};
     HZ_TRY(get_bluestein(ctx, n, &bl));
@@ -848,13 +857,10 @@ int hzsdr_fft_plan_batch(hzsdr_ctx *ctx, void *iq, void *freq, size_t n, size_t 
     if (batch == 0 || !iq || !freq) return HZSDR_ERR_INVALID_ARGUMENT;
     if (direction != HZSDR_FFT_FORWARD && direction != HZSDR_FFT_BACKWARD) return HZSDR_ERR_INVALID_ARGUMENT;
     HZ_TRY(enter(ctx));
-    if (n > 1) {  // plan-time cost, like any planner
-        const float2 *tw;
-        fv::FvTabs tabs{};
-        Bluestein bl{};
-        if (!pow2) HZ_TRY(get_bluestein(ctx, n, &bl));  // (the chirp and its spectrum: formed once per context and length)
-        else if (fv::ok((int)n)) HZ_TRY(get_fv_tables(ctx, n, &tabs));
-        else if (n <= 128) HZ_TRY(get_twiddles(ctx, n, &tw));
+    if (n > 1) {  // plan-time cost, like any planner: the tables (a chirp transform's: formed once per context and length)
+        HZ_TRY(fft_prepare(ctx, n));
+        // ... and the two-step lengths' scratch between the passes
+        if (pow2 && fft_two_step_ok(n)) HZ_TRY(ensure_slot(ctx, 10, n * batch * sizeof(float2)));
     }
     *out = new hzsdr_fft{ctx, iq, freq, n, batch, direction == HZSDR_FFT_FORWARD};
     return HZSDR_OK;
