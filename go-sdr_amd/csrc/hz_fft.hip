@@ -475,6 +475,8 @@ __global__ __launch_bounds__(THREADS) void fft2_rows_kernel(const float2 *__rest
 
 // rows of 64 or 128 points (N = 2^14, 2^15: N1 = 256 columns on the packed-math core, the
 // short rows on the radix-4 core of hz_fft.h, four points per lane)
+// (round 6, measured: sixteen rows of 128 points per tile on 512 lanes -- 128-byte output pieces instead of 64 --
+// 62-65 us per 2^24 points against 54-59 on 256 lanes: not the pieces; profiles/r06_fft2_smallrows.txt)
 template <int N2, bool FWD>
 __global__ __launch_bounds__(256) void fft2_rows_small_kernel(const float2 *__restrict__ a_in, float2 *__restrict__ out,
                                                               const float2 *__restrict__ tw2, uint32_t n1_total) {
