@@ -718,7 +718,13 @@ int fir_run(hzsdr_chain *c, const void *in, size_t n_cons, void *out, const EwPr
         }
         if (batched) return kBatchFallback;  // (the transform kernels take one buffer at a time)
         if (!fv::ok((int)c->nfft)) return HZSDR_ERR_INVALID_ARGUMENT;
-        HZ_TRY(pipeline_drain(c));  // (the transform kernels run on the context's stream)
+        // (the transform kernels run on the context's stream.  Round 6 built the overlapped form of the two-kernel calls --
+        // call k + 1's analysis beside call k's synthesis, first with the calls alternating between the chain's two
+        // streams, then with every analysis on one stream and every synthesis on the other -- bit-identical and
+        // SLOWER both ways: 57-58 against 50-52 us per 2^24 i16 samples at 1024 taps, 47-49 against 38-42 at 256
+        // (profiles/r06_transform_pipeline_attempt.txt): the events a 45 us call then carries between its kernels cost
+        // more than the 12 us synthesis can hide.  Taken out; tests/test_gpu_firmm.py keeps the equality test.)
+        HZ_TRY(pipeline_drain(c));
         FvTabs tabs{}, tabs_m{};
         PolyTabs ptabs{};
         HZ_TRY(get_fv_tables(ctx, c->nfft, &tabs));

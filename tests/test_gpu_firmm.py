@@ -430,6 +430,59 @@ def test_pipelined_chain_over_a_small_rotation_of_buffers(hz, sets):
         assert np.array_equal(a, b), "call %d differs" % i
 
 
+@pytest.mark.parametrize("fmt,D,shift", [("i16", 8, True), ("i16", 16, False), ("c64", 4, True), ("u8", 2, True), ("i16", 8, "mixed")])
+def test_run_after_on_transform_chains_bit_identical(hz, fmt, D, shift):
+    """The transform kernels' two-kernel form (analysis + synthesis: every source format and factor the matrix path does
+    not take) under hzsdr_chain_pipeline + hzsdr_chain_run_after.  These calls run on the context's stream whatever the
+    mode (an overlapped form was built in round 6, passed this test and was slower: csrc/hz_chain_fir.hip, fir_run);
+    the entry point's contract holds all the same.  A rotation of three (input, output) sets, ragged and short calls
+    among whole ones, a 2*pi wrap of the clock inside, and ('mixed') ordinary hzsdr_chain_run calls between the others:
+    every output and the clock equal the plain chain's bit for bit."""
+    import torch
+    from util import rand_c64, rand_i16
+    fs, sets, calls = 20_000_000, 3, 18
+    taps = taps_for(1024 if D >= 8 else 256, 1 / (2 * D), 0.0)
+    gen = {"i16": rand_i16, "u8": rand_u8, "c64": rand_c64}[fmt]
+    F = {"i16": hz.FMT_I16, "u8": hz.FMT_U8, "c64": hz.FMT_C64}[fmt]
+    n = 1 << 19
+    sizes = [n, n, n - 16 * D * 37, n, 4096 * D, n, n, n - D, n] * 2
+    res, clocks = [], []
+    for piped in (False, True):
+        s = torch.cuda.Stream()
+        ctx = hz.Context(0, hz.MEM_DEVICE, stream=s.cuda_stream)
+        ch = ctx.chain(F, fs)
+        if shift:
+            ch = ch.shift(-fs / 8)
+        ch = ch.gain(0.75).fir_decimate(taps, D)
+        if piped:
+            ch.pipeline(True)
+        ch.set_time(TAU - 0.05)
+        xs = [torch.from_numpy(gen(700 + i, n)).cuda() for i in range(sets)]
+        ys = [torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(sets)]
+        keep = [torch.zeros(n // D, dtype=torch.complex64, device="cuda") for _ in range(calls)]
+        copied = [torch.cuda.Event() for _ in range(sets)]
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s):
+            for i in range(calls):
+                m = sizes[i]
+                x, y = xs[i % sets][:m], ys[i % sets][: m // D]
+                if piped and not (shift == "mixed" and i % 5 == 3):
+                    assert ch.run_after(x, y, copied[i % sets] if i >= sets else None) == (m, m // D)
+                else:
+                    assert ch.run(x, y) == (m, m // D)
+                assert ch.last_fir_path() == hz.FIR_PATH_TRANSFORM
+                keep[i][: m // D].copy_(y)  # (on the context's stream: behind the call)
+                copied[i % sets].record(s)
+        ctx.synchronize()
+        clocks.append(ch.time())
+        res.append([torch.view_as_real(k).view(torch.int32).cpu().numpy() for k in keep])
+        ch.close()
+        ctx.close()
+    assert clocks[0] == clocks[1]
+    for i, (a, b) in enumerate(zip(*res)):
+        assert np.array_equal(a, b), "call %d differs" % i
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_pipelined_chain_random_calls_bit_identical(hz, seed):
     """Random call lengths (whole tiles and ragged, some below the matrix path's minimum), i8 and u8 sources, random
