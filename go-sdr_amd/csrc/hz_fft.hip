@@ -348,6 +348,16 @@ __device__ __forceinline__ void fft2_tile(uint32_t &bx, uint32_t &by) {
 // the column pass per 2^24 points, 256 | 512 | 1024 lanes): N1 = 512: 72 | 70 | 76 us; 1024: 96 | 86 | 93;
 // 2048: 153 | 113 | 115; 4096: 278 | 161 | 121 (profiles/r06_fft2_colthreads.txt).
 template <int N1> constexpr int cols_threads() { return N1 >= 4096 ? 1024 : N1 >= 1024 ? 512 : 256; }
+#ifndef HZ_FFT2_LDS_SKEW
+#define HZ_FFT2_LDS_SKEW 1
+#endif
+#ifndef HZ_FFT2_SKEW_UNIT
+#define HZ_FFT2_SKEW_UNIT 32
+#endif
+// elements from one column's LDS region to the next (the kernel's comment says why), for the kernel and its launcher
+template <int N1, int C> constexpr int cols_region() {
+    return fv::lds_elems(N1) + (HZ_FFT2_LDS_SKEW && C > 1 ? ((HZ_FFT2_SKEW_UNIT / C) % 32 - fv::lds_elems(N1) % 32 + 32) % 32 : 0);
+}
 template <int N1, bool FWD, int THREADS>
 __global__ __launch_bounds__(THREADS) void fft2_cols_kernel(const float2 *__restrict__ in, float2 *__restrict__ a_out,
                                                             fv::FvTabs tabs, BigTw bt, uint32_t n2_total) {
@@ -362,14 +372,7 @@ __global__ __launch_bounds__(THREADS) void fft2_cols_kernel(const float2 *__rest
     // to a bank: SQ_LDS_BANK_CONFLICT 31.5 M of 34.7 M LDS cycles per launch and XCD, waves waiting for LDS 21 % of their
     // time; now 2.1 M of 5.3 M, 0.4 % (profiles/r06_fft2_lds_conflicts*.txt; regions 64 / C apart, the first attempt:
     // 6.3 M of 9.5 M -- the two columns that then share a bank group still took turns).
-#ifndef HZ_FFT2_LDS_SKEW
-#define HZ_FFT2_LDS_SKEW 1
-#endif
-#ifndef HZ_FFT2_SKEW_UNIT
-#define HZ_FFT2_SKEW_UNIT 32
-#endif
-    constexpr int SKEW = HZ_FFT2_LDS_SKEW && C > 1 ? ((HZ_FFT2_SKEW_UNIT / C) % 32 - fv::lds_elems(N1) % 32 + 32) % 32 : 0;
-    constexpr int REGION = fv::lds_elems(N1) + SKEW;
+    constexpr int REGION = cols_region<N1, C>();
     extern __shared__ __attribute__((aligned(16))) unsigned char fft2_cols_lds[];
     cf *lds_all = reinterpret_cast<cf *>(fft2_cols_lds);
     const int sub = threadIdx.x % C, lane = threadIdx.x / C;  // column-fastest
@@ -554,9 +557,8 @@ static int get_big_twiddles(hzsdr_ctx *ctx, size_t n, BigTw *bt) {
 template <int N1> static int launch_cols(hzsdr_ctx *ctx, const float2 *in, float2 *a, const fv::FvTabs &tw1,
                                          const BigTw &bt, size_t n2, size_t batch, bool fwd) {
     constexpr int T = cols_threads<N1>(), C = T / fv::tpt(N1);
-    constexpr int SKEW = HZ_FFT2_LDS_SKEW && C > 1 ? ((HZ_FFT2_SKEW_UNIT / C) % 32 - fv::lds_elems(N1) % 32 + 32) % 32 : 0;
     const dim3 grid((unsigned)(n2 / C), (unsigned)batch);
-    const size_t lds = ((size_t)C * (fv::lds_elems(N1) + SKEW) + 16 * C) * sizeof(fv::cf);
+    const size_t lds = ((size_t)C * cols_region<N1, C>() + 16 * C) * sizeof(fv::cf);
     if (fwd) return launch_dyn(fft2_cols_kernel<N1, true, T>, grid, dim3(T), lds, ctx->stream, in, a, tw1, bt, (uint32_t)n2);
     return launch_dyn(fft2_cols_kernel<N1, false, T>, grid, dim3(T), lds, ctx->stream, in, a, tw1, bt, (uint32_t)n2);
 }
