@@ -343,6 +343,12 @@ __device__ __forceinline__ void fft2_tile(uint32_t &bx, uint32_t &by) {
     }
 }
 
+// (Round 6, measured and not kept: the column pass at N1 = 256 as PERSISTENT workgroups that walk their XCD's eighth of
+// the tiles, the next tile's sixteen loads and four twiddle gathers in flight under this tile's transform, the
+// transform's own twiddle rows in LDS -- what round 3's walk lost to, the gathers behind the prefetch, no longer exists.
+// Correct (the FFT tests pass on it) and slower: 58-65 us per 2^24 points with three workgroups per CU, 57-63 with two,
+// 65-69 with four, against 52-56 (profiles/r06_fft2_walk.txt; 140 registers).  As with the Shift map: what the pass lacks
+// is not overlap inside a workgroup but workgroups in flight, and a walk has fewer.)
 // THREADS: 256 lanes hold C = 4096 / N1 columns -- 128-byte pieces at N1 = 256, 8-byte ones at N1 = 4096 (N = 2^24);
 // the long columns take wider workgroups, like the long rows below (dynamic LDS: up to 140 KB).  Measured (round 6,
 // the column pass per 2^24 points, 256 | 512 | 1024 lanes): N1 = 512: 72 | 70 | 76 us; 1024: 96 | 86 | 93;
